@@ -1,0 +1,76 @@
+/*
+ * svt_hip.h — common part of the C-ABI of libsvtav1_hip (MI355X / gfx950 hot path for SVT-AV1).
+ *
+ * The library is a drop-in for the encoder's per-superblock DSP hot path.  It replaces
+ * entries of the reference's process-global function-pointer tables ("RTCD"):
+ *   /root/reference/Source/Lib/Codec/aom_dsp_rtcd.h:24-29   (RTCD_EXTERN pointers, encoder only)
+ *   /root/reference/Source/Lib/Codec/common_dsp_rtcd.h      (shared pointers)
+ * which are filled once from svt_av1_enc_init (Source/Lib/Globals/enc_handle.c:1475-1476).
+ *
+ * Two tiers:
+ *   Tier A  *_hip functions with EXACTLY the RTCD signature of the pointer they replace.
+ *           Host pointers in, host pointers out; one call = one block.  Used for parity and
+ *           as the literal drop-in (svt_hip_install_rtcd).
+ *   Tier B  svt_hip_*_frame / *_batch functions working on DEVICE-resident pictures; one call =
+ *           all blocks of one or more pictures.  Called from the kernel-process loops
+ *           (me_process.c:174-290, pic_analysis_process.c:2126,2137, ...) for throughput.
+ *
+ * Plain C, no torch / C++ types.  All functions are thread-safe and re-entrant (the reference
+ * calls the pointers concurrently from many worker threads, enc_handle.c:2283-2331).
+ */
+#ifndef SVT_HIP_H
+#define SVT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVT_HIP_API __attribute__((visibility("default")))
+
+/* Error convention mirrors EbErrorType (Source/API/EbSvtAv1.h:126-132): 0 = EB_ErrorNone. */
+typedef enum SvtHipStatus {
+    SVT_HIP_OK                = 0,
+    SVT_HIP_ERR_NO_DEVICE     = (int32_t)0x80001000, /* == EB_ErrorInsufficientResources */
+    SVT_HIP_ERR_BAD_PARAMETER = (int32_t)0x80001005, /* == EB_ErrorBadParameter */
+    SVT_HIP_ERR_RUNTIME       = (int32_t)0x80001001  /* == EB_ErrorUndefined: a HIP call failed */
+} SvtHipStatus;
+
+/* Library / device life-cycle.  svt_hip_init must succeed before any other call; on failure the
+ * caller keeps its CPU pointers installed (SURVEY §8b "Error convention"). */
+SVT_HIP_API int32_t     svt_hip_init(int32_t device_ordinal);
+SVT_HIP_API void        svt_hip_shutdown(void);
+SVT_HIP_API int32_t     svt_hip_device_count(void);
+SVT_HIP_API const char *svt_hip_last_error(void);   /* thread-local message of the last failure */
+SVT_HIP_API const char *svt_hip_version(void);
+
+/* Device memory + streams for hosts that do not bring their own (the C encoder).  A `stream`
+ * argument anywhere in this API is a hipStream_t passed as void*; NULL = the calling thread's
+ * private stream owned by the library. */
+SVT_HIP_API int32_t svt_hip_malloc(void **dptr, size_t bytes);
+SVT_HIP_API int32_t svt_hip_free(void *dptr);
+SVT_HIP_API int32_t svt_hip_memset(void *dptr, int value, size_t bytes, void *stream);
+SVT_HIP_API int32_t svt_hip_upload(void *dptr, const void *hptr, size_t bytes, void *stream);
+SVT_HIP_API int32_t svt_hip_download(void *hptr, const void *dptr, size_t bytes, void *stream);
+SVT_HIP_API int32_t svt_hip_upload_2d(void *dptr, size_t dpitch, const void *hptr, size_t hpitch,
+                                      size_t width_bytes, size_t height, void *stream);
+SVT_HIP_API int32_t svt_hip_stream_create(void **stream);
+SVT_HIP_API int32_t svt_hip_stream_destroy(void *stream);
+SVT_HIP_API int32_t svt_hip_stream_sync(void *stream);
+
+/* One padded 8-bit plane (mirror of the luma part of EbPictureBufferDesc,
+ * Source/Lib/Codec/pic_buffer_desc.h:34-75).  `buf` points at the first byte of the padded
+ * buffer (buffer_y); sample (x,y) of the picture is buf[(org_y+y)*stride + org_x + x]. */
+typedef struct SvtHipPlane8 {
+    uint8_t *buf;
+    uint32_t stride;
+    uint16_t org_x, org_y;   /* left / top padding */
+    uint16_t width, height;  /* picture size without padding */
+} SvtHipPlane8;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_H */

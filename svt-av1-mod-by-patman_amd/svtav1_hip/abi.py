@@ -1,0 +1,146 @@
+"""ctypes mirror of include/svt_hip.h and include/svt_hip_me.h (the C-ABI of libsvtav1_hip).
+
+This module only describes the binary interface; it contains no compute and no CPU fallback.
+`load()` raises if the HIP library has not been built (product path must fail loudly).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+LIB_PATH = os.path.join(PKG_ROOT, "csrc", "libsvtav1_hip.so")
+
+ME_MAX_LIST, ME_MAX_REF, ME_SQUARE_PUS = 2, 4, 85
+
+
+class Plane8(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("stride", C.c_uint32), ("org_x", C.c_uint16), ("org_y", C.c_uint16),
+                ("width", C.c_uint16), ("height", C.c_uint16)]
+
+
+class SearchArea(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16)]
+
+
+class MeParams(C.Structure):
+    _fields_ = [
+        ("hme_search_method", C.c_uint8), ("me_search_method", C.c_uint8),
+        ("enable_hme_flag", C.c_uint8), ("enable_hme_level0_flag", C.c_uint8),
+        ("enable_hme_level1_flag", C.c_uint8), ("enable_hme_level2_flag", C.c_uint8),
+        ("num_hme_sa_w", C.c_uint8), ("num_hme_sa_h", C.c_uint8),
+        ("hme_l0_sa_min", SearchArea), ("hme_l0_sa_max", SearchArea), ("hme_l1_sa", SearchArea),
+        ("hme_l2_sa", SearchArea), ("me_sa_min", SearchArea), ("me_sa_max", SearchArea),
+        ("prehme_enable", C.c_uint8), ("prehme_skip_search_line", C.c_uint8),
+        ("prehme_l1_early_exit", C.c_uint8), ("pad0_", C.c_uint8),
+        ("prehme_sa_min", SearchArea * 2), ("prehme_sa_max", SearchArea * 2),
+        ("enable_me_hme_ref_pruning", C.c_uint8), ("pad1_", C.c_uint8),
+        ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16),
+        ("prune_ref_if_me_sad_dev_bigger_than_th", C.c_uint16),
+        ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("pad2_", C.c_uint16),
+        ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
+        ("enable_me_sr_adjustment", C.c_uint8), ("distance_based_hme_resizing", C.c_uint8),
+        ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16),
+        ("stationary_me_sr_divisor", C.c_uint16), ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16),
+        ("me_sr_divisor_for_low_hme_sad", C.c_uint16),
+        ("me_8x8_var_enabled", C.c_uint8), ("pad3_", C.c_uint8 * 3),
+        ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32), ("me_sr_mult2_th", C.c_uint32),
+        ("mv_sa_adj_enabled", C.c_uint8), ("mv_sa_adj_nearest_ref_only", C.c_uint8),
+        ("mv_sa_adj_mv_size_th", C.c_uint16), ("mv_sa_adj_sa_multiplier", C.c_uint16),
+        ("reduce_hme_l0_sr_th_min", C.c_uint8), ("reduce_hme_l0_sr_th_max", C.c_uint8),
+        ("me_early_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32),
+        ("prev_me_stage_based_exit_th", C.c_uint32), ("prune_me_candidates_th", C.c_int32),
+        ("use_best_unipred_cand_only", C.c_uint8),
+        ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2),
+        ("temporal_layer_index", C.c_uint8), ("is_ref", C.c_uint8), ("hierarchical_levels", C.c_uint8),
+        ("similar_brightness_refs", C.c_uint8),
+        ("enable_me_8x8", C.c_uint8), ("enable_me_16x16", C.c_uint8), ("max_number_of_pus_per_sb", C.c_uint8),
+        ("max_cand", C.c_uint8), ("max_refs", C.c_uint8), ("max_l0", C.c_uint8),
+        ("only_l_bwd", C.c_uint8), ("input_resolution_le_480p", C.c_uint8), ("pad4_", C.c_uint8 * 2),
+        ("picture_number", C.c_uint64), ("ref_picture_number", (C.c_uint64 * 4) * 2),
+    ]
+
+    def stored_pus(self):
+        return (85 if self.enable_me_8x8 else 21) if self.enable_me_16x16 else 5
+
+    def to_dict(self):
+        def conv(v):
+            if isinstance(v, SearchArea):
+                return [v.width, v.height]
+            if hasattr(v, "__len__"):
+                return [conv(x) for x in v]
+            return int(v)
+        return {n: conv(getattr(self, n)) for n, _ in self._fields_ if not n.startswith("pad")}
+
+    @classmethod
+    def from_dict(cls, d):
+        p = cls()
+        for n, t in cls._fields_:
+            if n.startswith("pad") or n not in d:
+                continue
+            v = d[n]
+            if t is SearchArea:
+                setattr(p, n, SearchArea(*v))
+            elif n in ("prehme_sa_min", "prehme_sa_max"):
+                for i in range(2):
+                    getattr(p, n)[i] = SearchArea(*v[i])
+            elif n == "ref_picture_number":
+                for l in range(2):
+                    for r in range(4):
+                        p.ref_picture_number[l][r] = v[l][r]
+            elif n == "num_of_ref_pic_to_search":
+                p.num_of_ref_pic_to_search[0], p.num_of_ref_pic_to_search[1] = v
+            else:
+                setattr(p, n, v)
+        return p
+
+
+class Pyramid8(C.Structure):
+    _fields_ = [("full", Plane8), ("quarter", Plane8), ("sixteenth", Plane8)]
+
+
+class MeSearchResult(C.Structure):
+    _fields_ = [("hme_sad", C.c_uint64), ("hme_sc_x", C.c_int16), ("hme_sc_y", C.c_int16),
+                ("do_ref", C.c_uint8), ("pad_", C.c_uint8 * 3)]
+
+
+class MeFrameOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "best_sad", "best_mv", "search_results", "me_mv_array", "me_candidate_array",
+        "total_me_candidate_index", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
+        "me_8x8_distortion", "me_8x8_cost_variance", "rc_me_distortion")]
+
+
+class MeFrameJob(C.Structure):
+    _fields_ = [("prm", MeParams), ("src", Pyramid8), ("ref", (Pyramid8 * 4) * 2), ("out", MeFrameOut)]
+
+
+class SadLoopDesc(C.Structure):
+    _fields_ = [("src_off", C.c_uint64), ("ref_off", C.c_uint64), ("src_stride", C.c_uint32),
+                ("ref_stride", C.c_uint32), ("src_stride_raw", C.c_uint32), ("block_width", C.c_uint16),
+                ("block_height", C.c_uint16), ("search_area_width", C.c_int16),
+                ("search_area_height", C.c_int16), ("skip_search_line", C.c_uint8), ("pad_", C.c_uint8 * 7)]
+
+
+class SadLoopResult(C.Structure):
+    _fields_ = [("best_sad", C.c_uint64), ("x", C.c_int16), ("y", C.c_int16), ("pad_", C.c_uint32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libsvtav1_hip.so (built by __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP path has no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.svt_hip_last_error.restype = C.c_char_p
+        _lib.svt_hip_version.restype = C.c_char_p
+        _lib.svt_nxm_sad_kernel_hip.restype = C.c_uint32
+        for n in ("svt_compute_sub_mean_8x8_hip", "svt_compute_mean_8x8_hip",
+                  "svt_compute_mean_square_values_8x8_hip"):
+            getattr(_lib, n).restype = C.c_uint64
+    return _lib
