@@ -347,3 +347,8 @@ void orc_variance_frame(const SvtHipPlane8 *full, uint16_t *variance, uint64_t *
                 memcpy(mean + (size_t)85 * (by * bw + bx), m, sizeof(m));
         }
 }
+
+/* layout checks for the ctypes mirrors (tests/test_abi.py) */
+ORC_API uint32_t orc_sizeof_me_params(void) { return (uint32_t)sizeof(SvtHipMeParams); }
+ORC_API uint32_t orc_sizeof_me_job(void) { return (uint32_t)sizeof(SvtHipMeFrameJob); }
+ORC_API uint32_t orc_sizeof_plane(void) { return (uint32_t)sizeof(SvtHipPlane8); }

@@ -1,0 +1,1218 @@
+// me_frame.hip — whole-picture open-loop motion estimation on gfx950.
+//
+// Replaces the per-64x64 loop of the reference's ME kernel thread (Source/Lib/Codec/me_process.c:174-290)
+// and everything it calls (svt_aom_motion_estimation_b64, motion_estimation.c:3146-3223).
+//
+// Mapping: ONE workgroup (4 wave64) owns ONE 64x64 block (b64) of ONE picture and walks the whole
+// per-block pipeline — zero-MV SADs, pre-HME, HME level 0/1/2, search-centre selection, reference
+// pruning, full-pel 85-PU search, candidate list — without leaving the chip: the three source blocks
+// (64x64, 32x32, 16x16) and every search window live in LDS, intermediate state never touches HBM.
+// Data-dependent control flow (early exits, pruning, search-area adaptation) is evaluated by lane 0 on
+// LDS state between barriers; the pixel work (SAD searches, 8x8 SAD pyramids, arg-min reductions) is
+// spread over all 256 lanes.  A launch covers all b64 of all pictures of a batch (grid = b64 x jobs), so
+// thousands of independent workgroups hide each other's barriers and global-load latency.
+//
+// Exactness: integer types, wrap-arounds and tie-breaking follow the reference expression by expression
+// (see oracle/src/orc_me.c for the line-by-line citations; this file mirrors its structure).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+#include "sad_device.hpp"
+
+using namespace svthip;
+using namespace svthip::dev;
+
+namespace {
+
+#define NL 2
+#define NR 4
+#define MAX_SAD_VALUE_ (128 * 128 * 255) /* motion_estimation.h:85 */
+#define MAX_U32_ 0xFFFFFFFFu
+
+constexpr uint32_t ME_WIN_DW   = 4096;  // 16 KiB LDS window buffer
+constexpr uint32_t TILE_MAXPOS = 128;   // full-pel positions per tile
+
+struct PreHme {
+    uint64_t sad;
+    uint16_t sa_w, sa_h;
+    int16_t  col, row;
+    uint8_t  valid, pad_[7];
+};
+
+struct B64State {
+    uint32_t org_x, org_y, b64_w, b64_h;
+    SvtHipMeSearchResult sr[NL][NR];
+    uint32_t reduce_div[NL][NR];
+    uint32_t zz_sad[NL][NR];
+    PreHme   ph[NL][NR][2];
+    uint8_t  performed_phme[NL][NR][2];
+    int16_t  l0x[NL][NR][2][2], l0y[NL][NR][2][2], l1x[NL][NR][2][2], l1y[NL][NR][2][2], l2x[NL][NR][2][2],
+        l2y[NL][NR][2][2];
+    uint64_t l0s[NL][NR][2][2], l1s[NL][NR][2][2], l2s[NL][NR][2][2];
+    SvtHipSearchArea l0_min, l0_max;
+    // scratch shared between lane 0 and the workgroup
+    uint32_t wg_sum;
+    int32_t  go;             // stage decision broadcast by lane 0
+    int16_t  q_ox[4], q_oy[4];  // per-search origin offsets (pre-HME regions / HME quadrants)
+    // integer search of the current reference
+    int16_t  xc, yc, sw, sh, ox, oy;
+    int32_t  do_centre, need_zero_sad, need_hme_sad;
+    uint32_t zero_sad, hme_mv_sad;
+};
+
+struct MeLds {
+    SearchShared sh;
+    B64State     st;
+    uint32_t     win[ME_WIN_DW];
+    uint32_t     src_full[64 * 16];
+    uint32_t     src_q[32 * 8];
+    uint32_t     src_s[16 * 4];
+    uint16_t     sad8[TILE_MAXPOS][64];
+    uint64_t     bestkey[85];
+    uint32_t     best_sad[NL][NR][85], best_mv[NL][NR][85];
+    uint32_t     me_dist[85];
+};
+
+#define MINV(a, b) ((a) < (b) ? (a) : (b))
+#define MAXV(a, b) ((a) > (b) ? (a) : (b))
+#define ABSV(a) ((a) < 0 ? -(a) : (a))
+
+__device__ __forceinline__ uint16_t scaled_dist(uint16_t dist) {
+    return (uint16_t)(((dist * 5) / 8) + ((dist % 8) == 0 ? 0 : 1));
+}
+__device__ __forceinline__ uint16_t pic_dist(const SvtHipMeParams &p, int li, int ri) {
+    const int64_t d = (int64_t)p.picture_number - (int64_t)p.ref_picture_number[li][ri];
+    return (uint16_t)(int16_t)ABSV(d);
+}
+__device__ __forceinline__ const uint8_t *plane_at(const SvtHipPlane8 &pl, int x, int y) {
+    return pl.buf + (ptrdiff_t)((int)pl.org_y + y) * (ptrdiff_t)pl.stride + (int)pl.org_x + x;
+}
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *g) {
+    const uint32_t  a  = (uint32_t)((uintptr_t)g & 3u);
+    const uint32_t *gb = (const uint32_t *)(g - a);
+    const uint32_t  lo = gb[0];
+    const uint32_t  hi = a ? gb[1] : 0u;
+    return __builtin_amdgcn_alignbyte(hi, lo, a);
+}
+
+// Workgroup-wide SAD between the staged 64x64 source (rows 0,2,4.. when `sub`) and a global block.
+// Result in L.st.wg_sum (valid after the trailing barrier).  width must be a multiple of 4.
+__device__ void wg_block_sad(MeLds &L, const uint8_t *ref, uint32_t ref_stride, uint32_t width, uint32_t rows,
+                             uint32_t row_step) {
+    if (threadIdx.x == 0)
+        L.st.wg_sum = 0;
+    __syncthreads();
+    const uint32_t ndw = width >> 2;
+    uint32_t       acc = 0;
+    for (uint32_t idx = threadIdx.x; idx < ndw * rows; idx += WG_THREADS) {
+        const uint32_t r = idx / ndw, i = idx - r * ndw;
+        const uint32_t s = L.src_full[(r * row_step) * 16 + i];
+        const uint32_t v = load_u32_unaligned(ref + (size_t)(r * row_step) * ref_stride + 4 * i);
+        acc              = __builtin_amdgcn_sad_u8(s, v, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(&L.st.wg_sum, acc);
+    __syncthreads();
+}
+
+// The window clamp shared by hme_level_0/1/2 (motion_estimation.c:837-888, 940-990, 1041-1084).
+__device__ void hme_clamp(int16_t org_x, int16_t org_y, int16_t pad_w, int16_t pad_h, int16_t W, int16_t H, int16_t *pox,
+                          int16_t *poy, int16_t *pw, int16_t *ph) {
+    int16_t ox = *pox, oy = *poy, sa_w = *pw, sa_h = *ph;
+    if ((org_x + ox) < -pad_w) {
+        ox   = (int16_t)(-pad_w - org_x);
+        sa_w = (int16_t)(sa_w - (-pad_w - (org_x + ox)));
+    }
+    if ((org_x + ox) > W - 1)
+        ox = (int16_t)(ox - ((org_x + ox) - (W - 1)));
+    if ((org_x + ox + sa_w) > W)
+        sa_w = (int16_t)MAXV(1, sa_w - ((org_x + ox + sa_w) - W));
+    sa_w = (sa_w < 8) ? sa_w : (int16_t)(sa_w & ~0x07);
+    if ((org_y + oy) < -pad_h) {
+        oy   = (int16_t)(-pad_h - org_y);
+        sa_h = (int16_t)(sa_h - (-pad_h - (org_y + oy)));
+    }
+    if ((org_y + oy) > H - 1)
+        oy = (int16_t)(oy - ((org_y + oy) - (H - 1)));
+    if ((org_y + oy + sa_h) > H)
+        sa_h = (int16_t)MAXV(1, sa_h - ((org_y + oy + sa_h) - H));
+    *pox = ox, *poy = oy, *pw = sa_w, *ph = sa_h;
+}
+
+// Fill one search descriptor for an HME-style call (SUB_SAD/FULL_SAD argument rewrite of
+// motion_estimation.c:891-909).
+__device__ void set_desc(SearchDesc &d, const SvtHipMeParams &p, const SvtHipPlane8 &rp, int x_tl, int y_tl, int16_t sa_w,
+                         int16_t sa_h, uint32_t skip) {
+    const bool full = p.hme_search_method == 1;
+    d.ref           = rp.buf + (ptrdiff_t)y_tl * (ptrdiff_t)rp.stride + x_tl;
+    d.ref_stride    = full ? rp.stride : rp.stride * 2;
+    d.raw_stride    = rp.stride;
+    d.sa_w          = sa_w;
+    d.sa_h          = sa_h;
+    d.skip          = skip;
+}
+
+__device__ void decode_result(const SearchShared &sh, uint32_t i, bool sub, uint64_t *sad, int16_t *x, int16_t *y) {
+    const uint64_t key = sh.best[i];
+    uint64_t       s   = key >> 32;
+    if (key != KEY_NONE) {
+        const uint32_t idx = (uint32_t)key, w = (uint32_t)sh.desc[i].sa_w;
+        *x = (int16_t)(idx % w);
+        *y = (int16_t)(idx / w);
+    }
+    if (sub)
+        s *= 2;
+    *sad = s;
+}
+
+__device__ void set_quadrants(int16_t x[2][2], int16_t y[2][2], uint64_t s[2][2], int16_t vx, int16_t vy, uint64_t vs) {
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) x[a][b] = vx, y[a][b] = vy, s[a][b] = vs;
+}
+
+__device__ void best_quadrant(int16_t x[2][2], int16_t y[2][2], uint64_t s[2][2], int16_t *bx, int16_t *by, uint64_t *bs) {
+    *bx = x[0][0], *by = y[0][0], *bs = s[0][0];
+    if (s[1][0] < *bs) *bx = x[1][0], *by = y[1][0], *bs = s[1][0];
+    if (s[0][1] < *bs) *bx = x[0][1], *by = y[0][1], *bs = s[0][1];
+    if (s[1][1] < *bs) *bx = x[1][1], *by = y[1][1], *bs = s[1][1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// full-pel 85-PU search of one tile of positions (open_loop_me_fullpel_search_sblock semantics).
+//   win_org : global pointer of the window sample that tile position (0,0) puts under source (0,0)
+//   tw x th : tile size in positions (tw*th <= TILE_MAXPOS)
+//   order0, order_pitch : raster order key of tile position (x,y) = order0 + y*order_pitch + x
+// Updates L.bestkey[85] (sad<<32 | order) with atomic minima => first minimum in raster order wins.
+// ------------------------------------------------------------------------------------------------
+__device__ void fullpel_tile(MeLds &L, const uint8_t *win_org, uint32_t stride, uint32_t tw, uint32_t th, uint32_t order0,
+                             uint32_t order_pitch, bool sub) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nq  = (tw + 3) >> 2;
+    const uint32_t pitch = (nq + 16 + 1) | 1u;
+    const uint32_t rows  = th + 63;
+    // stage window
+    for (uint32_t idx = tid; idx < rows * pitch; idx += WG_THREADS) {
+        const uint32_t r = idx / pitch, i = idx - r * pitch;
+        L.win[idx]       = load_u32_unaligned(win_org + (size_t)r * stride + 4 * i);
+    }
+    __syncthreads();
+    // 8x8 SADs: item = (8x8 block b, quad q, row y)
+    const uint8_t  z16[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+    const uint32_t nitems  = 64 * nq * th;
+    const uint32_t rstep   = sub ? 2 : 1;
+    for (uint32_t item = tid; item < nitems; item += WG_THREADS) {
+        const uint32_t b = item & 63, rest = item >> 6;
+        const uint32_t q = rest % nq, y = rest / nq;
+        const uint32_t by = b >> 3, bx = b & 7;
+        const uint32_t *s = &L.src_full[(8 * by) * 16 + 2 * bx];
+        const uint32_t *w = &L.win[(y + 8 * by) * pitch + q + 2 * bx];
+        uint64_t        acc = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r += 1) {
+            if (sub && (r & 1))
+                continue;
+            const uint32_t d0 = w[r * pitch], d1 = w[r * pitch + 1], d2 = w[r * pitch + 2];
+            acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d0, d1), s[r * 16], acc);
+            acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d1, d2), s[r * 16 + 1], acc);
+        }
+        (void)rstep;
+        const uint32_t z = 4 * z16[4 * (by >> 1) + (bx >> 1)] + 2 * (by & 1) + (bx & 1);
+#pragma unroll
+        for (uint32_t pp = 0; pp < 4; pp++) {
+            const uint32_t x = 4 * q + pp;
+            if (x < tw) {
+                uint32_t v = (uint32_t)((acc >> (16 * pp)) & 0xffff);
+                if (sub)
+                    v <<= 1;
+                L.sad8[y * tw + x][z] = (uint16_t)v;
+            }
+        }
+    }
+    __syncthreads();
+    // pyramid sums + arg-min: item = (position, 16x16 slot); 16 lanes per position
+    const uint32_t npos = tw * th;
+    const uint32_t iters = (npos * 16 + WG_THREADS - 1) / WG_THREADS;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t item = it * WG_THREADS + tid;
+        const uint32_t pos = item >> 4, z = item & 15;
+        const bool     on  = pos < npos;
+        uint32_t       s16 = 0;
+        uint64_t       ord = 0;
+        if (on) {
+            const uint32_t y = pos / tw, x = pos - y * tw;
+            ord              = order0 + y * order_pitch + x;
+            const uint2 v2   = *(const uint2 *)&L.sad8[pos][4 * z];
+            const uint32_t c0 = v2.x & 0xffff, c1 = v2.x >> 16, c2 = v2.y & 0xffff, c3 = v2.y >> 16;
+            atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 0], ((unsigned long long)c0 << 32) | ord);
+            atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 1], ((unsigned long long)c1 << 32) | ord);
+            atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 2], ((unsigned long long)c2 << 32) | ord);
+            atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 3], ((unsigned long long)c3 << 32) | ord);
+            s16 = c0 + c1 + c2 + c3;
+            atomicMin((unsigned long long *)&L.bestkey[5 + z], ((unsigned long long)s16 << 32) | ord);
+        }
+        uint32_t s32 = s16 + __shfl_xor(s16, 1, 64);
+        s32 += __shfl_xor(s32, 2, 64);
+        uint32_t s64 = s32 + __shfl_xor(s32, 4, 64);
+        s64 += __shfl_xor(s64, 8, 64);
+        if (on && (z & 3) == 0)
+            atomicMin((unsigned long long *)&L.bestkey[1 + (z >> 2)], ((unsigned long long)s32 << 32) | ord);
+        if (on && z == 0)
+            atomicMin((unsigned long long *)&L.bestkey[0], ((unsigned long long)s64 << 32) | ord);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// candidate construction (motion_estimation.c:2602-2905), one lane per PU n
+// ------------------------------------------------------------------------------------------------
+__device__ const uint8_t z_to_raster_d[85] = {
+    0,  1,  2,  3,  4,  5,  6,  9,  10, 7,  8,  11, 12, 13, 14, 17, 18, 15, 16, 19, 20, 21, 22, 29, 30, 23, 24, 31, 32,
+    37, 38, 45, 46, 39, 40, 47, 48, 25, 26, 33, 34, 27, 28, 35, 36, 41, 42, 49, 50, 43, 44, 51, 52, 53, 54, 61, 62, 55,
+    56, 63, 64, 69, 70, 77, 78, 71, 72, 79, 80, 57, 58, 65, 66, 59, 60, 67, 68, 73, 74, 81, 82, 75, 76, 83, 84};
+__device__ const uint8_t tab8x8_d[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,  18, 19, 22, 23,
+                                         8,  9,  12, 13, 24, 25, 28, 29, 10, 11, 14, 15, 26, 27, 30, 31,
+                                         32, 33, 36, 37, 48, 49, 52, 53, 34, 35, 38, 39, 50, 51, 54, 55,
+                                         40, 41, 44, 45, 56, 57, 60, 61, 42, 43, 46, 47, 58, 59, 62, 63};
+
+__device__ __forceinline__ uint8_t pack_cand(uint32_t direction, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1) {
+    return (uint8_t)((direction & 3) | ((l0 & 3) << 2) | ((l1 & 3) << 4) | ((r0 & 1) << 6) | ((r1 & 1) << 7));
+}
+__device__ __forceinline__ int use_me_pu(const SvtHipMeParams &p, uint32_t n) {
+    return p.enable_me_16x16 ? (p.enable_me_8x8 || n < 21) : (n < 5);
+}
+
+__device__ void cand_single_ref(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint32_t *mv, uint8_t *cand) {
+    const uint8_t pu = z_to_raster_d[n];
+    L.me_dist[pu]    = L.best_sad[0][0][n];
+    if (!L.st.sr[0][0].do_ref)
+        return;
+    if (use_me_pu(p, n)) {
+        cand[pu * p.max_cand] = pack_cand(0, 0, 0, 0, 0);
+        mv[pu * p.max_refs]   = L.best_mv[0][0][n];
+    }
+}
+
+__device__ void cand_mrp_off(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint32_t nlist, uint32_t *mv, uint8_t *cand,
+                             uint8_t *total) {
+    const uint8_t org0 = L.st.sr[0][0].do_ref, org1 = (uint8_t)((nlist == 1) ? 0 : L.st.sr[1][0].do_ref);
+    if (nlist < 2 || !L.st.sr[1][0].do_ref)
+        nlist = 1;
+    const uint32_t prune_th = (org0 && org1) ? (uint32_t)p.prune_me_candidates_th : 0;
+    const uint8_t  pu  = z_to_raster_d[n];
+    uint8_t        off = 0;
+    const int      use = use_me_pu(p, n);
+    uint8_t       *ca  = cand + pu * p.max_cand;
+    uint8_t        dr[2] = {org0, org1};
+    const uint32_t s0 = L.best_sad[0][0][n], s1 = L.best_sad[1][0][n];
+    const uint32_t best = (org0 && org1) ? MINV(s0, s1) : org0 ? s0 : s1;
+    L.me_dist[pu]       = best;
+    int min_list        = -1;
+    if (p.use_best_unipred_cand_only && dr[0] && dr[1])
+        min_list = s0 < s1 ? 0 : 1;
+    for (uint32_t li = 0; li < nlist && (use || off == 0); ++li) {
+        if (dr[li] == 0)
+            continue;
+        const uint32_t sl = li ? s1 : s0;
+        if (prune_th > 0) {
+            const uint32_t d = (sl - best) * 100u;
+            if (d > (uint32_t)(best * prune_th)) {
+                dr[li] = 0;
+                continue;
+            }
+        }
+        if (min_list != -1 && min_list != (int)li) {
+            if (use)
+                mv[pu * p.max_refs + (li ? p.max_l0 : 0)] = L.best_mv[li][0][n];
+            continue;
+        }
+        if (use) {
+            ca[off] = pack_cand(li, 0, 0, li == 0 ? li : 24, li == 1 ? li : 24);
+            mv[pu * p.max_refs + (li ? p.max_l0 : 0)] = L.best_mv[li][0][n];
+        }
+        off++;
+    }
+    if (dr[0] && dr[1] && use) {
+        ca[off]   = pack_cand(2, 0, 0, 0, 1);
+        total[pu] = (uint8_t)(off + 1);
+    }
+}
+
+__device__ void cand_general(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint32_t nlist, uint32_t *mv, uint8_t *cand,
+                             uint8_t *total) {
+    const uint8_t pu  = (n > 4) ? z_to_raster_d[n] : (uint8_t)n;
+    uint8_t       off = 0;
+    const int     use = use_me_pu(p, n);
+    uint8_t      *ca  = cand + pu * p.max_cand;
+    uint32_t      drm = 0;  // bit (li*4+ri)
+    const uint32_t prune_th = (uint32_t)p.prune_me_candidates_th;
+    uint32_t       best     = MAX_U32_;
+    for (uint32_t li = 0; li < nlist; li++)
+        for (uint32_t ri = 0; ri < p.num_of_ref_pic_to_search[li]; ri++) {
+            if (!L.st.sr[li][ri].do_ref)
+                continue;
+            drm |= 1u << (li * 4 + ri);
+            best = L.best_sad[li][ri][n] < best ? L.best_sad[li][ri][n] : best;
+        }
+    L.me_dist[pu] = best;
+    for (uint32_t li = 0; li < nlist && (use || off == 0); ++li)
+        for (uint32_t ri = 0; ri < p.num_of_ref_pic_to_search[li] && (use || off == 0); ++ri) {
+            if (!(drm & (1u << (li * 4 + ri))))
+                continue;
+            if (prune_th > 0) {
+                const uint32_t d = (L.best_sad[li][ri][n] - best) * 100u;
+                if (d > (uint32_t)(best * prune_th)) {
+                    drm &= ~(1u << (li * 4 + ri));
+                    continue;
+                }
+            }
+            if (use) {
+                ca[off] = pack_cand(li, ri, ri, li == 0 ? li : 24, li == 1 ? li : 24);
+                mv[pu * p.max_refs + (li ? p.max_l0 : 0) + ri] = L.best_mv[li][ri][n];
+            }
+            off++;
+        }
+    if (nlist == 2 && use) {
+        for (uint32_t a = 0; a < p.num_of_ref_pic_to_search[0]; a++)
+            for (uint32_t b = 0; b < p.num_of_ref_pic_to_search[1]; b++) {
+                if (p.only_l_bwd && (a > 0 || b > 0))
+                    continue;
+                if ((drm & (1u << a)) && (drm & (1u << (4 + b))))
+                    ca[off++] = pack_cand(2, a, b, 0, 1);
+            }
+        if (!p.only_l_bwd) {
+            for (uint32_t a = 1; a < p.num_of_ref_pic_to_search[0]; a++)
+                if ((drm & 1u) && (drm & (1u << a)))
+                    ca[off++] = pack_cand(2, 0, a, 0, 0);
+            if (p.num_of_ref_pic_to_search[1] == 3 && (drm & (1u << 4)) && (drm & (1u << 6)))
+                ca[off++] = pack_cand(2, 0, 2, 1, 1);
+        }
+    }
+    if (use)
+        total[pu] = off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
+    __shared__ MeLds L;
+    const SvtHipMeFrameJob &job = jobs[blockIdx.y];
+    const SvtHipMeParams   &p   = job.prm;
+    const uint32_t          aw = (job.src.full.width + 7u) & ~7u, ah = (job.src.full.height + 7u) & ~7u;
+    const uint32_t          bw64 = (aw + 63) / 64, bh64 = (ah + 63) / 64;
+    const uint32_t          b64 = blockIdx.x;
+    if (b64 >= bw64 * bh64)
+        return;
+    const uint32_t tid = threadIdx.x;
+    B64State      &S   = L.st;
+    const uint32_t org_x = (b64 % bw64) * 64, org_y = (b64 / bw64) * 64;
+    const uint32_t b64_w = (aw - org_x) < 64 ? aw - org_x : 64, b64_h = (ah - org_y) < 64 ? ah - org_y : 64;
+    const bool     hme_sub = p.hme_search_method == 0, me_sub = p.me_search_method == 0;
+    const int      tl      = p.temporal_layer_index;
+
+    // ---- stage the three source blocks (me_process.c:183-214) ----
+    for (uint32_t idx = tid; idx < 64 * 16; idx += WG_THREADS) {
+        const uint32_t r = idx >> 4, i = idx & 15;
+        L.src_full[idx]  = load_u32_unaligned(plane_at(job.src.full, (int)org_x, (int)org_y) + (size_t)r * job.src.full.stride + 4 * i);
+    }
+    for (uint32_t idx = tid; idx < 32 * 8; idx += WG_THREADS) {
+        const uint32_t r = idx >> 3, i = idx & 7;
+        L.src_q[idx] = load_u32_unaligned(plane_at(job.src.quarter, (int)(org_x >> 1), (int)(org_y >> 1)) +
+                                          (size_t)r * job.src.quarter.stride + 4 * i);
+    }
+    for (uint32_t idx = tid; idx < 16 * 4; idx += WG_THREADS) {
+        const uint32_t r = idx >> 2, i = idx & 3;
+        L.src_s[idx] = load_u32_unaligned(plane_at(job.src.sixteenth, (int)(org_x >> 2), (int)(org_y >> 2)) +
+                                          (size_t)r * job.src.sixteenth.stride + 4 * i);
+    }
+    // ---- init_me_hme_data (motion_estimation.c:3080-3140) ----
+    for (uint32_t i = tid; i < NL * NR * 85; i += WG_THREADS) {
+        (&L.best_sad[0][0][0])[i] = 0;
+        (&L.best_mv[0][0][0])[i]  = 0;
+    }
+    if (tid == 0) {
+        S.org_x = org_x, S.org_y = org_y, S.b64_w = b64_w, S.b64_h = b64_h;
+        S.l0_min = p.hme_l0_sa_min, S.l0_max = p.hme_l0_sa_max;
+        for (int i = 0; i < NL; i++)
+            for (int j = 0; j < NR; j++) {
+                S.sr[i][j].hme_sad  = MAX_U32_;
+                S.sr[i][j].hme_sc_x = S.sr[i][j].hme_sc_y = 0;
+                S.sr[i][j].do_ref                         = 1;
+                S.sr[i][j].pad_[0] = S.sr[i][j].pad_[1] = S.sr[i][j].pad_[2] = 0;
+                S.reduce_div[i][j] = 1;
+                S.zz_sad[i][j]     = ~0u;
+                for (int k = 0; k < 2; k++) {
+                    S.ph[i][j][k].valid = 0, S.ph[i][j][k].sad = 0, S.ph[i][j][k].col = S.ph[i][j][k].row = 0;
+                    S.performed_phme[i][j][k] = 0;
+                }
+                set_quadrants(S.l0x[i][j], S.l0y[i][j], S.l0s[i][j], 0, 0, 0);
+                set_quadrants(S.l1x[i][j], S.l1y[i][j], S.l1s[i][j], 0, 0, 0);
+                set_quadrants(S.l2x[i][j], S.l2y[i][j], S.l2s[i][j], 0, 0, 0);
+            }
+    }
+    __syncthreads();
+
+    const int nlists = p.num_of_list_to_search;
+
+    // ---- init_zz_sad (motion_estimation.c:2452-2507) ----
+    if (p.me_early_exit_th || p.me_safe_limit_zz_th) {
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                if (!(tl > 0 || li == 0))
+                    continue;
+                const SvtHipPlane8 &rp = job.ref[li][ri].full;
+                wg_block_sad(L, plane_at(rp, (int16_t)org_x, (int16_t)org_y), rp.stride, b64_w, b64_h >> 1, 2);
+                if (tid == 0) {
+                    uint32_t z = S.wg_sum << 1;
+                    z          = (z * 64 * 64) / (b64_w * b64_h);
+                    S.zz_sad[li][ri] = z;
+                }
+                __syncthreads();
+            }
+        if (tid == 0) {
+            uint32_t best = MAX_U32_;
+            for (int li = 0; li < nlists; ++li)
+                for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
+                    if (tl > 0 || li == 0)
+                        best = MINV(best, S.zz_sad[li][ri]);
+            if (tl > 0 && best < p.zz_sad_th) {
+                for (int li = 0; li < nlists; ++li)
+                    for (int ri = 1; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                        const uint32_t pct = p.zz_sad_pct;
+                        if ((uint32_t)((S.zz_sad[li][ri] - best) * 100u) > (uint32_t)(pct * best))
+                            S.sr[li][ri].do_ref = 0;
+                    }
+            }
+            if (p.me_safe_limit_zz_th) {
+                const int lim = p.hierarchical_levels > 0 && nlists == 2 && tl >= p.hierarchical_levels &&
+                    p.similar_brightness_refs && S.zz_sad[0][0] < p.me_safe_limit_zz_th &&
+                    S.zz_sad[1][0] < p.me_safe_limit_zz_th;
+                if (lim)
+                    for (int li = 0; li < nlists; ++li)
+                        for (int ri = 1; ri < p.num_of_ref_pic_to_search[li]; ++ri) S.sr[li][ri].do_ref = 0;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- prehme_b64 (motion_estimation.c:1792-1866) ----
+    if (p.prehme_enable) {
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                if (tid == 0) {
+                    int go = 0;
+                    if (tl > 0 || li == 0) {
+                        const uint32_t      factor = scaled_dist(pic_dist(p, li, ri));
+                        const SvtHipPlane8 &rp     = job.ref[li][ri].sixteenth;
+                        for (int si = 0; si < 2; si++) {
+                            PreHme     &d  = S.ph[li][ri][si];
+                            SearchDesc &sd = L.sh.desc[si];
+                            sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+                            // check_prehme_early_exit (:1763-1789)
+                            if (p.me_early_exit_th && S.zz_sad[li][ri] < p.me_early_exit_th) {
+                                d.col = d.row = 0, d.sad = 0, d.valid = 1;
+                                continue;
+                            }
+                            if (p.prehme_l1_early_exit) {
+                                const PreHme &o = S.ph[0][ri][si];
+                                if (li == 1 && o.valid &&
+                                    ((o.sad < (32 * 32)) || ((ABSV(o.col) < 16) && (ABSV(o.row) < 16)))) {
+                                    d.col = (int16_t)-o.col, d.row = (int16_t)-o.row, d.sad = o.sad, d.valid = 1;
+                                    continue;
+                                }
+                            }
+                            if (!S.sr[li][ri].do_ref) {
+                                d.col = d.row = 0, d.sad = MAX_U32_;
+                                continue;
+                            }
+                            d.sa_w = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].width * factor), (uint32_t)p.prehme_sa_max[si].width);
+                            d.sa_h = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].height * factor), (uint32_t)p.prehme_sa_max[si].height);
+                            // prehme_core (:1638-1736)
+                            const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
+                            int16_t pad_w = (int16_t)rp.org_x - 1, pad_h = (int16_t)rp.org_y - 1;
+                            int16_t sa_w = (int16_t)d.sa_w, sa_h = (int16_t)d.sa_h;
+                            int16_t ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
+                            const int16_t W = (int16_t)rp.width, H = (int16_t)rp.height;
+                            ox   = ((ox16 + ox) < -pad_w) ? (int16_t)(-pad_w - ox16) : ox;
+                            sa_w = ((ox16 + ox) < -pad_w) ? (int16_t)(sa_w - (-pad_w - (ox16 + ox))) : sa_w;
+                            ox   = ((ox16 + ox) > W - 1) ? (int16_t)(ox - ((ox16 + ox) - (W - 1))) : ox;
+                            sa_w = ((ox16 + ox + sa_w) > W) ? (int16_t)MAXV(1, sa_w - ((ox16 + ox + sa_w) - W)) : sa_w;
+                            oy   = ((oy16 + oy) < -pad_h) ? (int16_t)(-pad_h - oy16) : oy;
+                            sa_h = ((oy16 + oy) < -pad_h) ? (int16_t)(sa_h - (-pad_h - (oy16 + oy))) : sa_h;
+                            oy   = ((oy16 + oy) > H - 1) ? (int16_t)(oy - ((oy16 + oy) - (H - 1))) : oy;
+                            sa_h = ((oy16 + oy + sa_h) > H) ? (int16_t)MAXV(1, sa_h - ((oy16 + oy + sa_h) - H)) : sa_h;
+                            const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
+                            const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
+                            const uint32_t bw = b64_w >> 2, bh = hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2);
+                            set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, p.prehme_skip_search_line && bw == 16 && bh <= 16);
+                            S.q_ox[si] = ox, S.q_oy[si] = oy;
+                            S.performed_phme[li][ri][si] = 1;
+                            go |= 1 << si;
+                        }
+                    } else {
+                        for (int si = 0; si < 2; si++) {
+                            S.ph[1][ri][si].col = (int16_t)-S.ph[0][ri][si].col;
+                            S.ph[1][ri][si].row = (int16_t)-S.ph[0][ri][si].row;
+                            S.ph[1][ri][si].sad = S.ph[0][ri][si].sad;
+                        }
+                    }
+                    S.go = go;
+                }
+                __syncthreads();
+                const int go = S.go;
+                if (go) {
+                    wg_multi_search(L.sh, 2, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2),
+                                    L.win, ME_WIN_DW);
+                    if (tid == 0) {
+                        for (int si = 0; si < 2; si++) {
+                            if (!(go & (1 << si)))
+                                continue;
+                            PreHme &d = S.ph[li][ri][si];
+                            decode_result(L.sh, si, hme_sub, &d.sad, &d.col, &d.row);
+                            d.col = (int16_t)(d.col + S.q_ox[si]);
+                            d.col = (int16_t)(d.col * 4);
+                            d.row = (int16_t)(d.row + S.q_oy[si]);
+                            d.row = (int16_t)(d.row * 4);
+                            d.valid = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        if (tid == 0) {
+            uint32_t best_sad = MAX_U32_;
+            for (int li = 0; li < nlists; ++li)
+                for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
+                    if (tl > 0 || li == 0) {
+                        const uint32_t m = (uint32_t)MINV(S.ph[li][ri][0].sad, S.ph[li][ri][1].sad);
+                        best_sad         = MINV(best_sad, m);
+                    }
+            if (tl > 0 && best_sad < p.phme_sad_th) {
+                for (int li = 0; li < nlists; ++li)
+                    for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                        if (!S.sr[li][ri].do_ref || ri == 0)
+                            continue;
+                        const uint32_t th  = p.phme_sad_pct;
+                        const uint32_t sad = (uint32_t)MINV(S.ph[li][ri][0].sad, S.ph[li][ri][1].sad);
+                        if ((uint32_t)((sad - best_sad) * 100u) > (uint32_t)(th * best_sad))
+                            S.sr[li][ri].do_ref = 0;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- HME level 0 (motion_estimation.c:1976-2106) ----
+    if (p.enable_hme_flag && p.enable_hme_level0_flag) {
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                if (tid == 0) {
+                    int go = 0;
+                    do {
+                        if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
+                            set_quadrants(S.l0x[li][ri], S.l0y[li][ri], S.l0s[li][ri], 0, 0, 0);
+                            break;
+                        }
+                        if (p.prev_me_stage_based_exit_th) {
+                            const int si = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
+                            if (S.performed_phme[li][ri][si] && S.ph[li][ri][si].sad < (p.prev_me_stage_based_exit_th >> 4)) {
+                                set_quadrants(S.l0x[li][ri], S.l0y[li][ri], S.l0s[li][ri], S.ph[li][ri][si].col,
+                                              S.ph[li][ri][si].row, S.ph[li][ri][si].sad);
+                                break;
+                            }
+                        }
+                        if (!S.sr[li][ri].do_ref) {
+                            set_quadrants(S.l0x[li][ri], S.l0y[li][ri], S.l0s[li][ri], 0, 0, MAX_U32_);
+                            break;
+                        }
+                        if (!(tl > 0 || li == 0))
+                            break;
+                        // get_hme_l0_search_area (:1870-1937); hme_l0_sa is restored right after use (:2069-2073)
+                        SvtHipSearchArea mn = S.l0_min, mx = S.l0_max;
+                        if (p.enable_me_sr_adjustment && p.distance_based_hme_resizing) {
+                            uint8_t is_hor = 1, is_ver = 1, is_still = 0;
+                            if (p.reduce_hme_l0_sr_th_min && p.reduce_hme_l0_sr_th_max && (li || ri)) {
+                                const int16_t mvx = S.l0x[0][0][0][0], mvy = S.l0y[0][0][0][0];
+                                is_ver   = (ABSV(mvx) < p.reduce_hme_l0_sr_th_min) && (ABSV(mvy) > p.reduce_hme_l0_sr_th_max);
+                                is_hor   = (ABSV(mvx) > p.reduce_hme_l0_sr_th_max) && (ABSV(mvy) < p.reduce_hme_l0_sr_th_min);
+                                is_still = (ABSV(mvx) < (p.reduce_hme_l0_sr_th_min * 3)) && (ABSV(mvy) < (p.reduce_hme_l0_sr_th_min * 3));
+                            }
+                            uint8_t xo = 1, yo = 1;
+                            if (!is_ver) yo = 2;
+                            if (!is_hor) xo = 2;
+                            if (p.enable_me_sr_adjustment == 2 && is_still) xo = yo = 4;
+                            mn.width  = (uint16_t)(mn.width / (xo + ri));
+                            mn.height = (uint16_t)(mn.height / (yo + ri));
+                            mx.width  = (uint16_t)(mx.width / (xo + ri));
+                            mx.height = (uint16_t)(mx.height / (yo + ri));
+                        }
+                        const int32_t factor = scaled_dist(pic_dist(p, li, ri));
+                        int16_t       w      = (int16_t)(mn.width / p.num_hme_sa_w);
+                        w = (int16_t)MINV((((w * factor) + 15) & ~0x0F), (((mx.width / p.num_hme_sa_w) + 15) & ~0x0F));
+                        int16_t h = (int16_t)(mn.height / p.num_hme_sa_h);
+                        h         = (int16_t)MINV((h * factor), (mx.height / p.num_hme_sa_h));
+                        const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
+                        const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
+                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
+                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
+                                // hme_level_0 (:820-920)
+                                int16_t sa_w = (int16_t)((w + 7) & ~0x07), sa_h = h;
+                                const int16_t xd = (int16_t)(sa_w * sw_), yd = (int16_t)(sa_h * sh_);
+                                int16_t ox = (int16_t)(-(int16_t)((sa_w * p.num_hme_sa_w) >> 1) + xd);
+                                int16_t oy = (int16_t)(-(int16_t)((sa_h * p.num_hme_sa_h) >> 1) + yd);
+                                hme_clamp(ox16, oy16, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width,
+                                          (int16_t)rp.height, &ox, &oy, &sa_w, &sa_h);
+                                const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
+                                const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
+                                const uint32_t qi = sh_ * 2 + sw_;
+                                set_desc(L.sh.desc[qi], p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+                                S.q_ox[qi] = ox, S.q_oy[qi] = oy;
+                            }
+                        go = 1;
+                    } while (0);
+                    S.go = go;
+                }
+                __syncthreads();
+                if (S.go) {
+                    wg_multi_search(L.sh, 4, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2),
+                                    L.win, ME_WIN_DW);
+                    if (tid == 0) {
+                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
+                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
+                                const uint32_t qi = sh_ * 2 + sw_;
+                                int16_t        mx = S.l0x[li][ri][sw_][sh_], my = S.l0y[li][ri][sw_][sh_];
+                                decode_result(L.sh, qi, hme_sub, &S.l0s[li][ri][sw_][sh_], &mx, &my);
+                                mx = (int16_t)(mx + S.q_ox[qi]), mx = (int16_t)(mx * 4);
+                                my = (int16_t)(my + S.q_oy[qi]), my = (int16_t)(my * 4);
+                                S.l0x[li][ri][sw_][sh_] = mx, S.l0y[li][ri][sw_][sh_] = my;
+                            }
+                        if (p.prehme_enable) {
+                            uint8_t  bw_ = 0, bh_ = 0;
+                            uint64_t mx = 0;
+                            if (S.l0s[li][ri][0][0] > mx) mx = S.l0s[li][ri][0][0], bw_ = 0, bh_ = 0;
+                            if (S.l0s[li][ri][1][0] > mx) mx = S.l0s[li][ri][1][0], bw_ = 1, bh_ = 0;
+                            if (S.l0s[li][ri][0][1] > mx) mx = S.l0s[li][ri][0][1], bw_ = 0, bh_ = 1;
+                            if (S.l0s[li][ri][1][1] > mx) bw_ = 1, bh_ = 1;
+                            const int si = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
+                            if (S.ph[li][ri][si].sad < S.l0s[li][ri][bw_][bh_]) {
+                                S.l0s[li][ri][bw_][bh_] = S.ph[li][ri][si].sad;
+                                S.l0x[li][ri][bw_][bh_] = S.ph[li][ri][si].col;
+                                S.l0y[li][ri][bw_][bh_] = S.ph[li][ri][si].row;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+
+    // ---- HME level 1 (motion_estimation.c:2111-2192) ----
+    if (p.enable_hme_flag && p.enable_hme_level1_flag) {
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                if (!(tl > 0 || li == 0))
+                    continue;
+                if (tid == 0) {
+                    int go = 0;
+                    if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
+                        set_quadrants(S.l1x[li][ri], S.l1y[li][ri], S.l1s[li][ri], 0, 0, 0);
+                    } else if (!S.sr[li][ri].do_ref) {
+                        set_quadrants(S.l1x[li][ri], S.l1y[li][ri], S.l1s[li][ri], 0, 0, MAX_U32_);
+                    } else {
+                        const SvtHipPlane8 &rp = job.ref[li][ri].quarter;
+                        const int16_t ox4 = (int16_t)(((int16_t)org_x) >> 1), oy4 = (int16_t)(((int16_t)org_y) >> 1);
+                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
+                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
+                                const uint32_t qi = sh_ * 2 + sw_;
+                                SearchDesc    &sd = L.sh.desc[qi];
+                                sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+                                if (p.prev_me_stage_based_exit_th && S.l0s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 5)) {
+                                    S.l1x[li][ri][sw_][sh_] = S.l0x[li][ri][sw_][sh_];
+                                    S.l1y[li][ri][sw_][sh_] = S.l0y[li][ri][sw_][sh_];
+                                    S.l1s[li][ri][sw_][sh_] = S.l0s[li][ri][sw_][sh_];
+                                    continue;
+                                }
+                                // hme_level_1 (:923-1022)
+                                int16_t sa_w = (int16_t)(((int16_t)p.hme_l1_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l1_sa.height;
+                                int16_t ox = (int16_t)(-(sa_w >> 1) + (int16_t)(S.l0x[li][ri][sw_][sh_] >> 1));
+                                int16_t oy = (int16_t)(-(sa_h >> 1) + (int16_t)(S.l0y[li][ri][sw_][sh_] >> 1));
+                                hme_clamp(ox4, oy4, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width,
+                                          (int16_t)rp.height, &ox, &oy, &sa_w, &sa_h);
+                                const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox4) + ox);
+                                const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy4) + oy);
+                                set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+                                S.q_ox[qi] = ox, S.q_oy[qi] = oy;
+                                go |= 1 << qi;
+                            }
+                    }
+                    S.go = go;
+                }
+                __syncthreads();
+                const int go = S.go;
+                if (go) {
+                    wg_multi_search(L.sh, 4, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1),
+                                    L.win, ME_WIN_DW);
+                    if (tid == 0)
+                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
+                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
+                                const uint32_t qi = sh_ * 2 + sw_;
+                                if (!(go & (1 << qi)))
+                                    continue;
+                                int16_t mx = S.l1x[li][ri][sw_][sh_], my = S.l1y[li][ri][sw_][sh_];
+                                decode_result(L.sh, qi, hme_sub, &S.l1s[li][ri][sw_][sh_], &mx, &my);
+                                mx = (int16_t)(mx + S.q_ox[qi]), mx = (int16_t)(mx * 2);
+                                my = (int16_t)(my + S.q_oy[qi]), my = (int16_t)(my * 2);
+                                S.l1x[li][ri][sw_][sh_] = mx, S.l1y[li][ri][sw_][sh_] = my;
+                            }
+                }
+                __syncthreads();
+            }
+    }
+
+    // ---- HME level 2 (motion_estimation.c:2197-2247) ----
+    if (p.enable_hme_flag && p.enable_hme_level2_flag) {
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                if (!(tl > 0 || li == 0))
+                    continue;
+                if (tid == 0) {
+                    int                 go = 0;
+                    const SvtHipPlane8 &rp = job.ref[li][ri].full;
+                    for (uint32_t sh_ = 0; sh_ < 2; sh_++)
+                        for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
+                            const uint32_t qi = sh_ * 2 + sw_;
+                            SearchDesc    &sd = L.sh.desc[qi];
+                            sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+                            if (p.prev_me_stage_based_exit_th && S.l1s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 2)) {
+                                S.l2x[li][ri][sw_][sh_] = S.l1x[li][ri][sw_][sh_];
+                                S.l2y[li][ri][sw_][sh_] = S.l1y[li][ri][sw_][sh_];
+                                S.l2s[li][ri][sw_][sh_] = S.l1s[li][ri][sw_][sh_];
+                                continue;
+                            }
+                            // hme_level_2 (:1025-1113)
+                            int16_t sa_w = (int16_t)(((int16_t)p.hme_l2_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l2_sa.height;
+                            int16_t ox = (int16_t)(-(sa_w >> 1) + S.l1x[li][ri][sw_][sh_]);
+                            int16_t oy = (int16_t)(-(sa_h >> 1) + S.l1y[li][ri][sw_][sh_]);
+                            hme_clamp((int16_t)org_x, (int16_t)org_y, 63, 63, (int16_t)rp.width, (int16_t)rp.height, &ox, &oy,
+                                      &sa_w, &sa_h);
+                            const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + (int16_t)org_x) + ox);
+                            const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + (int16_t)org_y) + oy);
+                            set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+                            S.q_ox[qi] = ox, S.q_oy[qi] = oy;
+                            go |= 1 << qi;
+                        }
+                    S.go = go;
+                }
+                __syncthreads();
+                const int go = S.go;
+                if (go) {
+                    wg_multi_search(L.sh, 4, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, L.win, ME_WIN_DW);
+                    if (tid == 0)
+                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
+                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
+                                const uint32_t qi = sh_ * 2 + sw_;
+                                if (!(go & (1 << qi)))
+                                    continue;
+                                int16_t mx = S.l2x[li][ri][sw_][sh_], my = S.l2y[li][ri][sw_][sh_];
+                                decode_result(L.sh, qi, hme_sub, &S.l2s[li][ri][sw_][sh_], &mx, &my);
+                                S.l2x[li][ri][sw_][sh_] = (int16_t)(mx + S.q_ox[qi]);
+                                S.l2y[li][ri][sw_][sh_] = (int16_t)(my + S.q_oy[qi]);
+                            }
+                }
+                __syncthreads();
+            }
+    }
+
+    // ---- set_final_seach_centre_sb (:2252-2450) + hme_prune_ref_and_adjust_sr (:2547-2588) ----
+    if (tid == 0) {
+        int16_t  hx = 0, hy = 0, xc = 0, yc = 0;
+        uint64_t hsad = 0;
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                if (tl > 0 || li == 0) {
+                    if (p.enable_hme_flag) {
+                        if (p.enable_hme_level0_flag && !p.enable_hme_level1_flag && !p.enable_hme_level2_flag)
+                            best_quadrant(S.l0x[li][ri], S.l0y[li][ri], S.l0s[li][ri], &hx, &hy, &hsad);
+                        if (p.enable_hme_level1_flag && !p.enable_hme_level2_flag)
+                            best_quadrant(S.l1x[li][ri], S.l1y[li][ri], S.l1s[li][ri], &hx, &hy, &hsad);
+                        if (p.enable_hme_level2_flag)
+                            best_quadrant(S.l2x[li][ri], S.l2y[li][ri], S.l2s[li][ri], &hx, &hy, &hsad);
+                        xc = hx, yc = hy;
+                    }
+                } else {
+                    xc = 0, yc = 0;
+                }
+                S.sr[li][ri].hme_sc_x = xc, S.sr[li][ri].hme_sc_y = yc, S.sr[li][ri].hme_sad = hsad;
+            }
+        if (p.enable_hme_flag) {  // prune_ref = enable_hme_flag && me_type != ME_MCTF
+            const uint16_t th = p.prune_ref_if_hme_sad_dev_bigger_than_th;
+            if (p.enable_me_hme_ref_pruning && th != (uint16_t)~0) {
+                uint64_t best = ~(uint64_t)0;
+                for (int i = 0; i < NL; i++)
+                    for (int j = 0; j < NR; j++)
+                        if (S.sr[i][j].hme_sad < best) best = S.sr[i][j].hme_sad;
+                for (int i = 0; i < NL; i++)
+                    for (int j = 1; j < NR; j++)
+                        if ((S.sr[i][j].hme_sad - best) * 100 > (th * best)) S.sr[i][j].do_ref = 0;
+            }
+            if (p.enable_me_sr_adjustment) {
+                for (int i = 0; i < NL; i++)
+                    for (int j = 0; j < NR; j++) {
+                        if (ABSV(S.sr[i][j].hme_sc_x) <= p.reduce_me_sr_based_on_mv_length_th &&
+                            ABSV(S.sr[i][j].hme_sc_y) <= p.reduce_me_sr_based_on_mv_length_th &&
+                            S.sr[i][j].hme_sad < p.stationary_hme_sad_abs_th)
+                            S.reduce_div[i][j] = p.stationary_me_sr_divisor;
+                        else if (S.sr[i][j].hme_sad < p.reduce_me_sr_based_on_hme_sad_abs_th)
+                            S.reduce_div[i][j] = p.me_sr_divisor_for_low_hme_sad;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- integer_search_b64 (motion_estimation.c:1249-1586) ----
+    {
+        const int16_t W = (int16_t)aw, H = (int16_t)ah, pad = 63;
+        const int16_t ox_b = (int16_t)org_x, oy_b = (int16_t)org_y;
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                if (S.sr[li][ri].do_ref == 0)  // uniform: LDS value written before the last barrier
+                    continue;
+                const SvtHipPlane8 &rp = job.ref[li][ri].full;
+                // part 1: search area from settings + HME results
+                if (tid == 0) {
+                    uint16_t dist = pic_dist(p, li, ri);
+                    int16_t  xc = S.sr[li][ri].hme_sc_x, yc = S.sr[li][ri].hme_sc_y;
+                    int16_t  sw = (int16_t)p.me_sa_min.width, sh_ = (int16_t)p.me_sa_min.height;
+                    dist        = scaled_dist(dist);
+                    sw          = (int16_t)MINV((sw * dist), p.me_sa_max.width);
+                    sh_         = (int16_t)MINV((sh_ * dist), p.me_sa_max.height);
+                    if (p.mv_sa_adj_enabled && (!p.mv_sa_adj_nearest_ref_only || ri == 0)) {
+                        if (ABSV(xc) > p.mv_sa_adj_mv_size_th) sw = (int16_t)(sw * p.mv_sa_adj_sa_multiplier);
+                        if (ABSV(yc) > p.mv_sa_adj_mv_size_th) sh_ = (int16_t)(sh_ * p.mv_sa_adj_sa_multiplier);
+                    }
+                    sw  = (int16_t)((MAXV(1u, ((uint32_t)sw / S.reduce_div[li][ri])) + 7) & ~0x07u);
+                    sh_ = (int16_t)MAXV(3u, ((uint32_t)sh_ / S.reduce_div[li][ri]));
+                    S.xc = xc, S.yc = yc, S.sw = sw, S.sh = sh_;
+                    S.need_zero_sad = 0, S.need_hme_sad = 0;
+                    if (p.me_early_exit_th) {
+                        if (S.zz_sad[li][ri] < (p.me_early_exit_th / 6))
+                            S.sw = S.sh = 1;
+                    } else if ((xc != 0 || yc != 0) && p.is_ref) {
+                        // check_00_center needs two 64x(h/2) SADs (:1139-1206)
+                        S.need_zero_sad = 1;  // me_early_exit_th == 0 here, so zz_sad is not available
+                        S.need_hme_sad  = 1;
+                        int16_t cx = xc, cy = yc;
+                        const int16_t RW = (int16_t)rp.width, RH = (int16_t)rp.height;
+                        cx = ((ox_b + cx) < -pad) ? (int16_t)(-pad - ox_b) : cx;
+                        cx = ((ox_b + cx) > RW - 1) ? (int16_t)(cx - ((ox_b + cx) - (RW - 1))) : cx;
+                        cy = ((oy_b + cy) < -pad) ? (int16_t)(-pad - oy_b) : cy;
+                        cy = ((oy_b + cy) > RH - 1) ? (int16_t)(cy - ((oy_b + cy) - (RH - 1))) : cy;
+                        S.xc = cx, S.yc = cy;
+                    }
+                }
+                __syncthreads();
+                if (S.need_zero_sad) {
+                    wg_block_sad(L, plane_at(rp, ox_b, oy_b), rp.stride, b64_w, b64_h >> 1, 2);
+                    if (tid == 0)
+                        S.zero_sad = S.wg_sum;
+                    __syncthreads();
+                    wg_block_sad(L, plane_at(rp, ox_b + S.xc, oy_b + S.yc), rp.stride, b64_w, b64_h >> 1, 2);
+                    if (tid == 0)
+                        S.hme_mv_sad = S.wg_sum;
+                    __syncthreads();
+                }
+                // part 2: finish check_00_center, SR adjustment, decide on the centre probe
+                if (tid == 0) {
+                    int16_t       sw = S.sw, sh_ = S.sh;
+                    const int16_t sw0 = sw, sh0 = sh_;
+                    if (!p.me_early_exit_th) {
+                        uint8_t  accurate     = 1;
+                        uint64_t best_hme_sad = ~(uint64_t)0;
+                        if (S.need_zero_sad) {
+                            const uint32_t zero_sad = S.zero_sad << 1;
+                            const uint32_t hme_sad  = S.hme_mv_sad << 1;
+                            const uint64_t zc = (uint64_t)(zero_sad << 8), hc = (uint64_t)(hme_sad << 8);
+                            const uint64_t cost = MINV(zc, hc);
+                            if (cost == zc)
+                                S.xc = 0, S.yc = 0;
+                            best_hme_sad = hme_sad;
+                            if (S.xc == 0 && S.yc == 0)
+                                accurate = 0;
+                        }
+                        if (p.enable_me_sr_adjustment == 2) {
+                            if ((accurate && (best_hme_sad < (24 * 24))) || (p.is_ref && S.sr[li][ri].hme_sad < (24 * 24)))
+                                sh_ = (int16_t)(sh_ / 2);
+                            if ((li || ri) && L.best_sad[0][0][0] < 5000 && sh_ == sh0 && sw == sw0) {
+                                sh_ = (int16_t)(sh_ >> 1);
+                                sw  = (int16_t)(sw >> 1);
+                            }
+                        }
+                    }
+                    S.sw = sw, S.sh = sh_;
+                    S.do_centre = p.me_8x8_var_enabled && (sw * sh_ > 24);
+                }
+                if (tid < 85)
+                    L.bestkey[tid] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
+                __syncthreads();
+                if (S.do_centre) {
+                    fullpel_tile(L, plane_at(rp, ox_b + S.xc, oy_b + S.yc), rp.stride, 1, 1, 0, 1, me_sub);
+                    if (tid == 0) {
+                        int16_t        sw = S.sw, sh_ = S.sh;
+                        const uint32_t mean = (uint32_t)(L.bestkey[0] >> 32) / 64;
+                        uint32_t       ssq  = 0;
+                        for (int i = 0; i < 64; i++) {
+                            const int32_t d = (int32_t)(uint32_t)(L.bestkey[21 + i] >> 32) - (int32_t)mean;
+                            ssq += (uint32_t)(d * d);
+                        }
+                        const uint32_t var = ssq / 64;
+                        if (var > p.me_sr_mult2_th) {
+                            sw  = (int16_t)((MAXV(1, sw * 3 / 2) + 7) & ~0x7);
+                            sh_ = (int16_t)MAXV(1, sh_ * 3 / 2);
+                        }
+                        if (var < p.me_sr_div4_th) {
+                            sw  = (int16_t)((MAXV(1, sw >> 2) + 7) & ~0x7);
+                            sh_ = (int16_t)MAXV(1, sh_ >> 2);
+                            sh_ = (int16_t)MAXV(3, sh_);
+                        } else if (var < p.me_sr_div2_th) {
+                            sw  = (int16_t)((MINV(sw, sw >> 1) + 7) & ~0x7);
+                            sh_ = (int16_t)MINV(sh_, sh_ >> 1);
+                            sh_ = (int16_t)MAXV(3, sh_);
+                        }
+                        S.sw = sw, S.sh = sh_;
+                    }
+                    __syncthreads();
+                }
+                // part 3: final window (:1442-1561)
+                if (tid == 0) {
+                    int16_t sw = S.sw, sh_ = S.sh;
+                    int16_t ox = (int16_t)(S.xc - (sw >> 1)), oy = (int16_t)(S.yc - (sh_ >> 1));
+                    ox  = ((ox_b + ox) < -pad) ? (int16_t)(-pad - ox_b) : ox;
+                    sw  = ((ox_b + ox) < -pad) ? (int16_t)(sw - (-pad - (ox_b + ox))) : sw;
+                    ox  = ((ox_b + ox) > W - 1) ? (int16_t)(ox - ((ox_b + ox) - (W - 1))) : ox;
+                    sw  = ((ox_b + ox + sw) > W) ? (int16_t)MAXV(1, sw - ((ox_b + ox + sw) - W)) : sw;
+                    sw  = (sw < 8) ? sw : (int16_t)(sw & ~0x07);
+                    oy  = ((oy_b + oy) < -pad) ? (int16_t)(-pad - oy_b) : oy;
+                    sh_ = ((oy_b + oy) < -pad) ? (int16_t)(sh_ - (-pad - (oy_b + oy))) : sh_;
+                    oy  = ((oy_b + oy) > H - 1) ? (int16_t)(oy - ((oy_b + oy) - (H - 1))) : oy;
+                    sh_ = ((oy_b + oy + sh_) > H) ? (int16_t)MAXV(1, sh_ - ((oy_b + oy + sh_) - H)) : sh_;
+                    S.sw = sw, S.sh = sh_, S.ox = ox, S.oy = oy;
+                }
+                __syncthreads();
+                {
+                    const int      ox = S.ox, oy = S.oy;
+                    const uint32_t sw = (uint32_t)(S.sw > 0 ? S.sw : 0), sh_ = (uint32_t)(S.sh > 0 ? S.sh : 0);
+                    const uint32_t tw = sw < 32 ? sw : 32;
+                    const uint32_t th = tw ? MINV(sh_, MAXV(1u, TILE_MAXPOS / tw)) : 0;
+                    for (uint32_t ty = 0; th && ty < sh_; ty += th)
+                        for (uint32_t tx = 0; tx < sw; tx += tw) {
+                            const uint32_t cw = MINV(tw, sw - tx), ch = MINV(th, sh_ - ty);
+                            fullpel_tile(L, plane_at(rp, ox_b + ox + (int)tx, oy_b + oy + (int)ty), rp.stride, cw, ch,
+                                         1 + ty * sw + tx, sw, me_sub);
+                        }
+                    // keys -> p_sb_best_sad / p_sb_best_mv of this reference
+                    if (tid < 85) {
+                        const uint64_t key = L.bestkey[tid];
+                        const uint32_t ord = (uint32_t)key;
+                        L.best_sad[li][ri][tid] = (uint32_t)(key >> 32);
+                        if (ord != 0xffffffffu) {
+                            int16_t mx, my;
+                            if (ord == 0) {
+                                mx = S.xc, my = S.yc;
+                            } else {
+                                const uint32_t pos = ord - 1;
+                                mx = (int16_t)((int)(pos % sw) + ox), my = (int16_t)((int)(pos / sw) + oy);
+                            }
+                            L.best_mv[li][ri][tid] = ((uint32_t)(uint16_t)my << 16) | (uint16_t)mx;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+
+    // ---- me_prune_ref (motion_estimation.c:1592-1635) ----
+    if (p.enable_hme_flag && p.enable_me_hme_ref_pruning) {
+        if (tid == 0) {
+            for (int li = 0; li < nlists; ++li)
+                for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                    S.sr[li][ri].hme_sad = 0;
+                    if (S.sr[li][ri].do_ref == 0) {
+                        S.sr[li][ri].hme_sad = (uint64_t)(MAX_SAD_VALUE_ * 64);
+                        continue;
+                    }
+                    uint64_t t = 0;
+                    for (int k = 0; k < 64; k++) t += L.best_sad[li][ri][21 + tab8x8_d[k]];
+                    S.sr[li][ri].hme_sad = t;
+                }
+            const uint16_t th = p.prune_ref_if_me_sad_dev_bigger_than_th;
+            if (th != (uint16_t)~0) {
+                uint64_t best = ~(uint64_t)0;
+                for (int i = 0; i < NL; i++)
+                    for (int j = 0; j < NR; j++)
+                        if (S.sr[i][j].hme_sad < best) best = S.sr[i][j].hme_sad;
+                for (int i = 0; i < NL; i++)
+                    for (int j = 1; j < NR; j++)
+                        if ((S.sr[i][j].hme_sad - best) * 100 > (th * best)) S.sr[i][j].do_ref = 0;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- candidates (motion_estimation.c:3196-3211) ----
+    const SvtHipMeFrameOut &out    = job.out;
+    const uint32_t          stored = p.enable_me_16x16 ? (p.enable_me_8x8 ? 85u : 21u) : 5u;
+    uint32_t               *o_mv   = out.me_mv_array + (size_t)b64 * stored * p.max_refs;
+    uint8_t                *o_cand = out.me_candidate_array + (size_t)b64 * stored * p.max_cand;
+    uint8_t                *o_tot  = out.total_me_candidate_index + (size_t)b64 * stored;
+    const bool single = p.num_of_ref_pic_to_search[0] == 1 && p.num_of_ref_pic_to_search[1] == 0;
+    const bool mrpoff = p.num_of_ref_pic_to_search[0] == 1 && p.num_of_ref_pic_to_search[1] == 1;
+    if ((single || mrpoff) && tid < stored)
+        o_tot[tid] = 1;
+    __syncthreads();
+    if (tid < p.max_number_of_pus_per_sb && tid < 85) {
+        if (single)
+            cand_single_ref(L, p, tid, o_mv, o_cand);
+        else if (mrpoff)
+            cand_mrp_off(L, p, tid, (uint32_t)nlists, o_mv, o_cand, o_tot);
+        else
+            cand_general(L, p, tid, (uint32_t)nlists, o_mv, o_cand, o_tot);
+    }
+    __syncthreads();
+
+    // ---- compute_distortion (motion_estimation.c:3034-3077) + result write-back ----
+    if (tid == 0) {
+        uint32_t d64 = L.me_dist[0], d32 = 0, d16 = 0, d8 = 0;
+        for (int i = 0; i < 4; i++) d32 += L.me_dist[1 + i];
+        for (int i = 0; i < 16; i++) d16 += L.me_dist[5 + i];
+        for (int i = 0; i < 64; i++) d8 += L.me_dist[21 + i];
+        const uint64_t mean = d8 / 64;
+        uint64_t       ssq  = 0;
+        for (int i = 0; i < 64; i++) {
+            const int64_t d = (int64_t)L.me_dist[21 + i] - (int64_t)mean;
+            ssq += (uint64_t)(d * d);
+        }
+        const uint32_t pix = b64_w * b64_h;
+        out.me_8x8_cost_variance[b64] = (uint32_t)(ssq / 64);
+        out.rc_me_distortion[b64]     = p.input_resolution_le_480p ? d8 : d16;
+        out.me_64x64_distortion[b64]  = (d64 * 4096u) / pix;
+        out.me_32x32_distortion[b64]  = (d32 * 4096u) / pix;
+        out.me_16x16_distortion[b64]  = (d16 * 4096u) / pix;
+        out.me_8x8_distortion[b64]    = (d8 * 4096u) / pix;
+    }
+    for (uint32_t i = tid; i < NL * NR * 85; i += WG_THREADS) {
+        out.best_sad[(size_t)b64 * NL * NR * 85 + i] = (&L.best_sad[0][0][0])[i];
+        out.best_mv[(size_t)b64 * NL * NR * 85 + i]  = (&L.best_mv[0][0][0])[i];
+    }
+    if (tid < NL * NR)
+        out.search_results[(size_t)b64 * NL * NR + tid] = (&S.sr[0][0])[tid];
+}
+
+}  // namespace
+
+extern "C" uint32_t svt_hip_me_b64_count(uint32_t width, uint32_t height) {
+    const uint32_t aw = (width + 7u) & ~7u, ah = (height + 7u) & ~7u;
+    return ((aw + 63) / 64) * ((ah + 63) / 64);
+}
+
+static int32_t validate_job(const SvtHipMeFrameJob &j, uint32_t idx) {
+    const SvtHipMeParams &p = j.prm;
+    auto bad = [&](const char *what) {
+        set_error("svt_hip_me_frames: job %u: %s", idx, what);
+        return (int32_t)SVT_HIP_ERR_BAD_PARAMETER;
+    };
+    if (p.num_hme_sa_w != 2 || p.num_hme_sa_h != 2)
+        return bad("num_hme_sa_w/h must be 2 (as in the reference, motion_estimation.c:1945)");
+    if (p.num_of_list_to_search < 1 || p.num_of_list_to_search > 2)
+        return bad("num_of_list_to_search must be 1 or 2");
+    for (int l = 0; l < 2; l++)
+        if (p.num_of_ref_pic_to_search[l] > SVT_HIP_ME_MAX_REF)
+            return bad("too many reference pictures");
+    if (p.num_of_ref_pic_to_search[0] < 1)
+        return bad("list 0 needs at least one reference");
+    if (p.max_number_of_pus_per_sb != 85)
+        return bad("max_number_of_pus_per_sb must be 85 (SQUARE_PU_COUNT)");
+    if (p.max_refs == 0 || p.max_cand == 0)
+        return bad("max_refs / max_cand not set");
+    if (!j.src.full.buf || !j.src.quarter.buf || !j.src.sixteenth.buf)
+        return bad("source pyramid incomplete");
+    if (j.src.full.width < 64 || j.src.full.height < 64 || j.src.full.width > 16384 || j.src.full.height > 8704)
+        return bad("unsupported picture size");
+    if (j.src.full.org_x < 64 || j.src.full.org_y < 64)
+        return bad("full-resolution planes need >= 64 samples of padding");
+    for (int l = 0; l < p.num_of_list_to_search; l++)
+        for (int r = 0; r < p.num_of_ref_pic_to_search[l]; r++) {
+            const SvtHipPyramid8 &y = j.ref[l][r];
+            if (!y.full.buf || !y.quarter.buf || !y.sixteenth.buf)
+                return bad("reference pyramid incomplete");
+            if (y.full.width != j.src.full.width || y.full.height != j.src.full.height)
+                return bad("reference size differs from the source (scaled references are not supported)");
+            if (y.full.org_x < 64 || y.full.org_y < 64)
+                return bad("reference planes need >= 64 samples of padding");
+        }
+    const void *outs[] = {j.out.best_sad, j.out.best_mv, j.out.search_results, j.out.me_mv_array, j.out.me_candidate_array,
+                          j.out.total_me_candidate_index, j.out.me_64x64_distortion, j.out.me_32x32_distortion,
+                          j.out.me_16x16_distortion, j.out.me_8x8_distortion, j.out.me_8x8_cost_variance,
+                          j.out.rc_me_distortion};
+    for (const void *o : outs)
+        if (!o)
+            return bad("NULL output array");
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jobs, void *stream) {
+    if (!jobs || n_jobs == 0) {
+        set_error("svt_hip_me_frames: no jobs");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    uint32_t max_b64 = 0;
+    for (uint32_t i = 0; i < n_jobs; i++) {
+        const int32_t rc = validate_job(jobs[i], i);
+        if (rc != SVT_HIP_OK)
+            return rc;
+        const uint32_t nb = svt_hip_me_b64_count(jobs[i].src.full.width, jobs[i].src.full.height);
+        max_b64           = nb > max_b64 ? nb : max_b64;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    hipStream_t st = resolve_stream(stream);
+    // Job descriptors travel through a stream-ordered device buffer (freed stream-ordered as well), so the
+    // call stays asynchronous and re-entrant.
+    SvtHipMeFrameJob *d_jobs = nullptr;
+    const size_t      bytes  = sizeof(SvtHipMeFrameJob) * n_jobs;
+    SVT_HIP_CHECK(hipMallocAsync((void **)&d_jobs, bytes, st));
+    SVT_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs, bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(me_b64_kernel, dim3(max_b64, n_jobs), dim3(WG_THREADS), 0, st, (const SvtHipMeFrameJob *)d_jobs);
+    SVT_HIP_CHECK(hipGetLastError());
+    SVT_HIP_CHECK(hipFreeAsync(d_jobs, st));
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_install_rtcd_me(void **table, uint32_t n_slots) {
+    if (!table || n_slots < SVT_HIP_SLOT_ME_COUNT) {
+        set_error("svt_hip_install_rtcd_me: table too small");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;  // caller keeps its CPU pointers
+    void *fn[SVT_HIP_SLOT_ME_COUNT] = {
+        (void *)svt_sad_loop_kernel_hip,
+        (void *)svt_nxm_sad_kernel_hip,
+        (void *)svt_ext_all_sad_calculation_8x8_16x16_hip,
+        (void *)svt_ext_eight_sad_calculation_32x32_64x64_hip,
+        (void *)svt_ext_sad_calculation_8x8_16x16_hip,
+        (void *)svt_ext_sad_calculation_32x32_64x64_hip,
+        (void *)svt_aom_downsample_2d_hip,
+        (void *)svt_compute_interm_var_four8x8_hip,
+        (void *)svt_compute_sub_mean_8x8_hip,
+        (void *)svt_compute_mean_8x8_hip,
+        (void *)svt_compute_mean_square_values_8x8_hip,
+    };
+    for (uint32_t i = 0; i < SVT_HIP_SLOT_ME_COUNT; i++)
+        if (table[i])
+            *(void **)table[i] = fn[i];
+    return SVT_HIP_OK;
+}

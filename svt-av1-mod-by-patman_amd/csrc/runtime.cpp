@@ -1,0 +1,184 @@
+// runtime.cpp — device life-cycle, streams, memory and error plumbing of libsvtav1_hip.
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "common.hpp"
+
+namespace svthip {
+
+static thread_local char tls_err[512] = "";
+static std::atomic<int>  g_device{-1};
+static std::mutex        g_mutex;
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tls_err, sizeof(tls_err), fmt, ap);
+    va_end(ap);
+}
+
+bool ensure_init() {
+    if (g_device.load() >= 0) {
+        // each host thread must select the device once
+        static thread_local bool bound = false;
+        if (!bound) {
+            if (hipSetDevice(g_device.load()) != hipSuccess)
+                return false;
+            bound = true;
+        }
+        return true;
+    }
+    return svt_hip_init(0) == SVT_HIP_OK;
+}
+
+struct TlsStream {
+    hipStream_t s = nullptr;
+    ~TlsStream() {
+        if (s)
+            (void)hipStreamDestroy(s);
+    }
+};
+
+hipStream_t resolve_stream(void *stream) {
+    if (stream)
+        return (hipStream_t)stream;
+    static thread_local TlsStream t;
+    if (!t.s) {
+        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) {
+            fprintf(stderr, "libsvtav1_hip fatal: cannot create a stream\n");
+            abort();
+        }
+    }
+    return t.s;
+}
+
+uint8_t *Scratch::device(size_t bytes) {
+    if (bytes > dev_cap) {
+        if (dev)
+            (void)hipFree(dev);
+        size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
+        if (hipMalloc((void **)&dev, cap + 256) != hipSuccess) {
+            fprintf(stderr, "libsvtav1_hip fatal: hipMalloc(%zu) failed\n", cap);
+            abort();
+        }
+        dev_cap = cap;
+    }
+    return dev;
+}
+uint8_t *Scratch::host(size_t bytes) {
+    if (bytes > pinned_cap) {
+        if (pinned)
+            (void)hipHostFree(pinned);
+        size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
+        if (hipHostMalloc((void **)&pinned, cap + 256, hipHostMallocDefault) != hipSuccess) {
+            fprintf(stderr, "libsvtav1_hip fatal: hipHostMalloc(%zu) failed\n", cap);
+            abort();
+        }
+        pinned_cap = cap;
+    }
+    return pinned;
+}
+Scratch &tls_scratch() {
+    static thread_local Scratch s;
+    return s;
+}
+
+}  // namespace svthip
+
+using namespace svthip;
+
+extern "C" {
+
+int32_t svt_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int32_t svt_hip_init(int32_t device_ordinal) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    int                         n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible");
+        return SVT_HIP_ERR_NO_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        set_error("device ordinal %d out of range (%d devices)", device_ordinal, n);
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    SVT_HIP_CHECK(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    SVT_HIP_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device_ordinal,
+                  prop.gcnArchName);
+        return SVT_HIP_ERR_NO_DEVICE;
+    }
+    g_device.store(device_ordinal);
+    return SVT_HIP_OK;
+}
+
+void svt_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    g_device.store(-1);
+}
+
+const char *svt_hip_last_error(void) { return tls_err; }
+const char *svt_hip_version(void) { return "svtav1-hip 0.1 (gfx950)"; }
+
+int32_t svt_hip_malloc(void **dptr, size_t bytes) {
+    if (!dptr)
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    // +256 B of slack: the window stagers read whole aligned dwords around unaligned rows.
+    SVT_HIP_CHECK(hipMalloc(dptr, bytes + 256));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_free(void *dptr) {
+    SVT_HIP_CHECK(hipFree(dptr));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_memset(void *dptr, int value, size_t bytes, void *stream) {
+    SVT_HIP_CHECK(hipMemsetAsync(dptr, value, bytes, resolve_stream(stream)));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_upload(void *dptr, const void *hptr, size_t bytes, void *stream) {
+    SVT_HIP_CHECK(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, resolve_stream(stream)));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_download(void *hptr, const void *dptr, size_t bytes, void *stream) {
+    SVT_HIP_CHECK(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, resolve_stream(stream)));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_upload_2d(void *dptr, size_t dpitch, const void *hptr, size_t hpitch, size_t width_bytes,
+                          size_t height, void *stream) {
+    SVT_HIP_CHECK(hipMemcpy2DAsync(dptr, dpitch, hptr, hpitch, width_bytes, height, hipMemcpyHostToDevice,
+                                   resolve_stream(stream)));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_stream_create(void **stream) {
+    if (!stream)
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    hipStream_t s;
+    SVT_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_stream_destroy(void *stream) {
+    SVT_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_stream_sync(void *stream) {
+    SVT_HIP_CHECK(hipStreamSynchronize(resolve_stream(stream)));
+    return SVT_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// sad_device.hpp — workgroup-level exhaustive SAD search for gfx950 (wave64, LDS-staged windows).
+//
+// Replaces the triple loop of svt_sad_loop_kernel (Source/Lib/C_DEFAULT/compute_sad_c.c:58-101 of the
+// reference) by:
+//   * staging the search window(s) once into LDS with coalesced, dword-aligned global loads
+//     (unaligned window origins are re-aligned with v_alignbyte_b32 while staging),
+//   * one lane per QUAD of 4 horizontally adjacent search positions, using v_qsad_pk_u16_u8
+//     (4 positions x 4 pixels per instruction) on dwords read from LDS,
+//   * a 64-bit key (sad << 32 | raster index) reduced with ds_min_u64, which reproduces the
+//     reference's "first minimum in raster order, strict <" tie-breaking exactly.
+// Several independent searches that share one source block (the 4 HME quadrants, both pre-HME
+// regions ...) are processed in one pass so that all 256 lanes have work.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svthip {
+namespace dev {
+
+constexpr int      WG_THREADS = 256;
+constexpr int      MAX_SEARCH = 16;
+constexpr uint64_t KEY_NONE   = ((uint64_t)0xffffffu << 32) | 0xffffffffu;  // best starts at 0xffffff
+
+struct SearchDesc {
+    const uint8_t *ref;         // global: window origin (search position (0,0), block row 0)
+    uint32_t       ref_stride;  // bytes between consecutive block rows
+    uint32_t       raw_stride;  // bytes between consecutive search rows (src_stride_raw of the reference)
+    int32_t        sa_w, sa_h;
+    uint32_t       skip;  // search only odd rows (skip_search_line && bw==16 && bh<=16)
+    // --- plan (filled by search_plan) ---
+    uint32_t k;         // ref_stride / raw_stride
+    uint32_t fast;      // LDS fast path usable
+    uint32_t nq;        // quads per search row
+    uint32_t n_srows;   // searched rows
+    uint32_t pitch_dw;  // LDS row pitch of the staged window (dwords)
+    uint32_t rows_per_pos;  // raw rows spanned by one search position: (bh-1)*k + 1
+};
+
+struct SearchSeg {
+    uint32_t d;          // descriptor
+    uint32_t j0, nj;     // searched-row range [j0, j0+nj)
+    uint32_t lds_dw;     // window offset in the LDS window buffer
+    uint32_t nstage;     // raw rows staged
+    uint32_t item_base;  // first work item of this segment
+};
+
+struct SearchShared {
+    SearchDesc desc[MAX_SEARCH];
+    SearchSeg  seg[MAX_SEARCH];
+    uint64_t   best[MAX_SEARCH];
+    uint32_t   nseg, nitems;
+    uint32_t   next_d, next_j;  // continuation point of the planner
+    uint32_t   slow_mask;       // descriptors that must take the slow (global memory) path
+};
+
+__device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// SAD of 4 adjacent positions (window dword `w` onwards) against one block.  src rows are dwords in LDS.
+__device__ __forceinline__ void quad_sad(const uint32_t *__restrict__ w, uint32_t w_row_dw,
+                                         const uint32_t *__restrict__ s, uint32_t s_row_dw, uint32_t bw, uint32_t bh,
+                                         uint32_t out[4]) {
+    const uint32_t nfull = bw >> 2, tail = bw & 3;
+    const uint32_t rows_per_flush = nfull ? (64u / nfull ? 64u / nfull : 1u) : 64u;
+    const uint32_t tmask          = tail ? ((1u << (8 * tail)) - 1u) : 0u;
+    uint32_t       a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint64_t       acc = 0;
+    uint32_t       since = 0;
+    for (uint32_t r = 0; r < bh; r++) {
+        const uint32_t *wr = w + r * w_row_dw;
+        const uint32_t *sr = s + r * s_row_dw;
+        uint32_t        lo = wr[0];
+        for (uint32_t i = 0; i < nfull; i++) {
+            const uint32_t hi = wr[i + 1];
+#ifdef SVT_HIP_NO_QSAD  // diagnostic build: same arithmetic with v_sad_u8 only
+            a0 = __builtin_amdgcn_sad_u8(lo, sr[i], a0);
+            a1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 1u), sr[i], a1);
+            a2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 2u), sr[i], a2);
+            a3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 3u), sr[i], a3);
+#else
+            acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(lo, hi), sr[i], acc);
+#endif
+            lo = hi;
+        }
+        if (tail) {
+            const uint32_t hi = wr[nfull + 1];
+            const uint32_t sv = sr[nfull] & tmask;
+            a0 = __builtin_amdgcn_sad_u8(lo & tmask, sv, a0);
+            a1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 1u) & tmask, sv, a1);
+            a2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 2u) & tmask, sv, a2);
+            a3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 3u) & tmask, sv, a3);
+        }
+        if (++since == rows_per_flush) {
+            a0 += (uint32_t)(acc & 0xffff), a1 += (uint32_t)((acc >> 16) & 0xffff);
+            a2 += (uint32_t)((acc >> 32) & 0xffff), a3 += (uint32_t)(acc >> 48);
+            acc = 0, since = 0;
+        }
+    }
+    a0 += (uint32_t)(acc & 0xffff), a1 += (uint32_t)((acc >> 16) & 0xffff);
+    a2 += (uint32_t)((acc >> 32) & 0xffff), a3 += (uint32_t)(acc >> 48);
+    out[0] = a0, out[1] = a1, out[2] = a2, out[3] = a3;
+}
+
+__device__ __forceinline__ void search_plan_desc(SearchDesc &d, uint32_t bw, uint32_t bh, uint32_t win_cap_dw) {
+    d.fast = 0;
+    d.k    = 0;
+    if (d.sa_w <= 0 || d.sa_h <= 0) {
+        d.n_srows = 0, d.nq = 0;
+        return;
+    }
+    d.n_srows = d.skip ? (uint32_t)d.sa_h / 2u : (uint32_t)d.sa_h;
+    d.nq      = ((uint32_t)d.sa_w + 3u) >> 2;
+    if (d.raw_stride != 0 && d.ref_stride % d.raw_stride == 0 && bw <= 256) {
+        d.k            = d.ref_stride / d.raw_stride;
+        d.rows_per_pos = (bh - 1) * d.k + 1;
+        d.pitch_dw     = (d.nq + ((bw + 3) >> 2) + 1) | 1u;  // odd pitch: rows land on different banks
+        d.fast         = (uint64_t)d.pitch_dw * d.rows_per_pos <= win_cap_dw;
+    }
+}
+
+// Exhaustive search of n descriptors (same bw x bh block, `src` = block rows as dwords in LDS).
+// On return sh.best[i] holds the winning key of descriptor i (KEY_NONE if nothing was searched).
+// Must be called by all WG_THREADS threads of the workgroup; contains barriers.
+__device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint32_t *__restrict__ src,
+                                       uint32_t src_row_dw, uint32_t bw, uint32_t bh, uint32_t *__restrict__ win,
+                                       uint32_t win_cap_dw) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < n) {
+        search_plan_desc(sh.desc[tid], bw, bh, win_cap_dw);
+        sh.best[tid] = KEY_NONE;
+    }
+    if (tid == 0) {
+        sh.next_d = 0, sh.next_j = 0;
+    }
+    __syncthreads();
+
+    // ---- fast path: passes of (stage -> search) until every descriptor row has been searched ----
+    for (;;) {
+        if (tid == 0) {
+            uint32_t nseg = 0, used = 0, items = 0, d = sh.next_d, j = sh.next_j;
+            while (d < n && nseg < MAX_SEARCH) {
+                const SearchDesc &ds = sh.desc[d];
+                if (!ds.fast || j >= ds.n_srows) {
+                    d++, j = 0;
+                    continue;
+                }
+                const uint32_t step    = ds.skip ? 2u : 1u;
+                const uint32_t free_dw = win_cap_dw - used;
+                // rows staged for nj searched rows: (nj-1)*step + rows_per_pos
+                if ((uint64_t)ds.pitch_dw * ds.rows_per_pos > free_dw)
+                    break;
+                uint32_t max_rows = free_dw / ds.pitch_dw;
+                uint32_t nj       = (max_rows - ds.rows_per_pos) / step + 1;
+                if (nj > ds.n_srows - j)
+                    nj = ds.n_srows - j;
+                SearchSeg &sg = sh.seg[nseg++];
+                sg.d = d, sg.j0 = j, sg.nj = nj, sg.lds_dw = used;
+                sg.nstage    = (nj - 1) * step + ds.rows_per_pos;
+                sg.item_base = items;
+                used += sg.nstage * ds.pitch_dw;
+                items += nj * ds.nq;
+                j += nj;
+            }
+            sh.nseg = nseg, sh.nitems = items, sh.next_d = d, sh.next_j = j;
+        }
+        __syncthreads();
+        const uint32_t nseg = sh.nseg;
+        if (nseg == 0)
+            break;
+        // stage
+        for (uint32_t s = 0; s < nseg; s++) {
+            const SearchSeg  sg = sh.seg[s];
+            const SearchDesc ds = sh.desc[sg.d];
+            const uint32_t   sy0   = ds.skip ? 2 * sg.j0 + 1 : sg.j0;
+            const uint32_t   total = sg.nstage * ds.pitch_dw;
+            for (uint32_t idx = tid; idx < total; idx += WG_THREADS) {
+                const uint32_t  row = idx / ds.pitch_dw, i = idx - row * ds.pitch_dw;
+                const uint8_t  *g   = ds.ref + (size_t)(sy0 + row) * ds.raw_stride;
+                const uint32_t  a   = (uint32_t)((uintptr_t)g & 3u);
+                const uint32_t *gb  = (const uint32_t *)(g - a) + i;
+                const uint32_t  lo  = gb[0];
+                const uint32_t  hi  = a ? gb[1] : 0u;
+                win[sg.lds_dw + idx] = __builtin_amdgcn_alignbyte(hi, lo, a);
+            }
+        }
+        __syncthreads();
+        // search
+        const uint32_t nitems = sh.nitems;
+        for (uint32_t item = tid; item < nitems; item += WG_THREADS) {
+            uint32_t s = 0;
+            while (s + 1 < nseg && item >= sh.seg[s + 1].item_base) s++;
+            const SearchSeg  sg = sh.seg[s];
+            const SearchDesc ds = sh.desc[sg.d];
+            const uint32_t   li = item - sg.item_base;
+            const uint32_t   jl = li / ds.nq, q = li - jl * ds.nq;
+            const uint32_t   step = ds.skip ? 2u : 1u;
+            const uint32_t  *w    = win + sg.lds_dw + (jl * step) * ds.pitch_dw + q;
+            uint32_t         sad[4];
+            quad_sad(w, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad);
+            const uint32_t sy = ds.skip ? 2 * (sg.j0 + jl) + 1 : (sg.j0 + jl);
+            uint64_t       key = KEY_NONE;
+#pragma unroll
+            for (uint32_t p = 0; p < 4; p++) {
+                const uint32_t sx = 4 * q + p;
+                if (sx < (uint32_t)ds.sa_w) {
+                    const uint64_t kk = ((uint64_t)sad[p] << 32) | (sy * (uint32_t)ds.sa_w + sx);
+                    key               = kk < key ? kk : key;
+                }
+            }
+            if (key < KEY_NONE)
+                atomicMin((unsigned long long *)&sh.best[sg.d], (unsigned long long)key);
+        }
+        __syncthreads();
+    }
+
+    // ---- slow path (window does not fit LDS, or strides are unrelated): straight from global memory ----
+    for (uint32_t d = 0; d < n; d++) {
+        const SearchDesc ds = sh.desc[d];
+        if (ds.fast || ds.n_srows == 0)
+            continue;
+        const uint32_t npos = ds.n_srows * (uint32_t)ds.sa_w;
+        const uint8_t *sb   = (const uint8_t *)src;
+        uint64_t       key  = KEY_NONE;
+        for (uint32_t p = tid; p < npos; p += WG_THREADS) {
+            const uint32_t j = p / (uint32_t)ds.sa_w, sx = p - j * (uint32_t)ds.sa_w;
+            const uint32_t sy = ds.skip ? 2 * j + 1 : j;
+            const uint8_t *g  = ds.ref + (size_t)sy * ds.raw_stride + sx;
+            uint32_t       sad = 0;
+            for (uint32_t r = 0; r < bh; r++)
+                for (uint32_t c = 0; c < bw; c++) {
+                    const int dv = (int)sb[r * src_row_dw * 4 + c] - (int)g[(size_t)r * ds.ref_stride + c];
+                    sad += (uint32_t)(dv < 0 ? -dv : dv);
+                }
+            const uint64_t kk = ((uint64_t)sad << 32) | (sy * (uint32_t)ds.sa_w + sx);
+            key               = kk < key ? kk : key;
+        }
+        if (key < KEY_NONE)
+            atomicMin((unsigned long long *)&sh.best[d], (unsigned long long)key);
+    }
+    __syncthreads();
+}
+
+// Stage a bw x bh block (bytes) from global into LDS as rows of `row_dw` dwords (zero padded tail).
+__device__ __forceinline__ void wg_stage_block(uint32_t *__restrict__ dst, uint32_t row_dw, const uint8_t *__restrict__ g,
+                                               uint32_t stride, uint32_t bw, uint32_t bh) {
+    const uint32_t total = row_dw * bh;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += WG_THREADS) {
+        const uint32_t r = idx / row_dw, i = idx - r * row_dw;
+        const uint8_t *p = g + (size_t)r * stride + 4 * i;
+        uint32_t       v = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++)
+            if (4 * i + b < bw)
+                v |= (uint32_t)p[b] << (8 * b);
+        dst[idx] = v;
+    }
+}
+
+// Wave64 sum reduction (all lanes get nothing in particular; lane 0 holds the total).
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+}  // namespace dev
+}  // namespace svthip
