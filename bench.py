@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py — hot-path throughput of libsvtav1_hip on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], "1080p 8-bit preset 8 — SAD/variance ME kernels on HIP"): one STEP is one
+pass of the open-loop analysis hot path over a batch of F synthetic 1080p luma pictures that are already
+resident in HBM: 1/4 + 1/16 pyramid (with padding), 64x64 block variances, and the complete per-64x64 open-loop
+motion estimation (zero-MV SADs, pre-HME, HME L0/L1, search-centre selection, reference pruning, full-pel
+85-PU search, candidate lists) against 2+2 reference pictures with the reference's preset-8 parameters
+(tests/golden/me_params.json, derived by the reference's own svt_aom_sig_deriv_me).
+
+`value` = pictures/s over all ranks (weak scaling: every rank owns its own pictures; frames of a GOP shard across
+GPUs with no data-path collective because open-loop ME only reads SOURCE pictures).  It is the fps of
+this hot-path stage, NOT of a whole encode (the serial mode-decision / entropy stages stay on the host).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "svt-av1-mod-by-patman_amd"))
+
+import torch  # noqa: E402  (device memory, streams/events, torch.distributed: plumbing only)
+import torch.distributed as dist  # noqa: E402
+
+from svtav1_hip import abi, frames  # noqa: E402
+
+WIDTH, HEIGHT = 1920, 1080
+L0_OFFS, L1_OFFS = (-1, -2), (1, 2)     # references of picture i: i-1, i-2 (list 0), i+1, i+2 (list 1)
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes_me(width, height, n_refs):
+    """(1 + 1/4 + 1/16)*P*(1+R) + B*R*85*8 bytes per picture."""
+    p = width * height
+    b = frames.b64_count(width, height)
+    return 1.3125 * p * (1 + n_refs) + b * n_refs * 85 * 8
+
+
+class TorchPlane:
+    """Padded u8 plane in a torch CUDA tensor (+256 B slack: window stagers read whole aligned dwords)."""
+
+    def __init__(self, host_plane, dev):
+        self.h = host_plane
+        self.t = torch.zeros(host_plane.nbytes + 256, dtype=torch.uint8, device=dev)
+        self.t[:host_plane.nbytes].copy_(torch.from_numpy(host_plane.buf.reshape(-1)))
+
+    def desc(self):
+        return self.h.desc(self.t.data_ptr())
+
+
+class TorchPyramid:
+    def __init__(self, host_pyr, dev):
+        self.full, self.quarter, self.sixteenth = (TorchPlane(p, dev) for p in host_pyr.planes())
+
+    def desc(self):
+        return abi.Pyramid8(self.full.desc(), self.quarter.desc(), self.sixteenth.desc())
+
+
+def load_params(key):
+    with open(os.path.join(ROOT, "tests", "golden", "me_params.json")) as f:
+        return abi.MeParams.from_dict(json.load(f)[key])
+
+
+def cpu_baseline(clip_host, prm_for, n_frames_cap=24, budget_s=20.0):
+    """The reference's own C path (oracle/_ref, kind "reference") when its build travelled with the repo, else
+    our C restatement (kind "port"): pyramid + variance + open-loop ME of the same pictures on the host cores,
+    one picture per thread, bounded to ~20 s."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyorc
+    use_ref = pyorc.have_ref()
+    lib = pyorc.ref() if use_ref else pyorc.oracle()
+    pyr_fn = lib.ref_pyramid_frame if use_ref else lib.orc_pyramid_frame
+    me_fn = lib.ref_me_frame if use_ref else lib.orc_me_frame_range
+    cores = min(16, os.cpu_count() or 1)
+    n = len(clip_host)
+    pyrs = [frames.HostPyramid(f) for f in clip_host]
+    nb = frames.b64_count(WIDTH, HEIGHT)
+
+    def analyse(i):
+        d = pyrs[i].desc()
+        pyr_fn(C.byref(d.full), C.byref(d.quarter), C.byref(d.sixteenth), 1)
+        var = np.zeros((nb, 85), np.uint16)
+        if use_ref:
+            lib.ref_variance_frame(C.byref(d.full), var.ctypes.data_as(C.c_void_p), 0)
+        else:
+            lib.orc_variance_frame(C.byref(d.full), var.ctypes.data_as(C.c_void_p), None, 0)
+
+    def me(i):
+        prm, l0, l1 = prm_for(i)
+        arrs, out = frames.alloc_me_out_host(prm, nb)
+        job = abi.MeFrameJob()
+        job.prm, job.src, job.out = prm, pyrs[i].desc(), out
+        for r, poc in enumerate(l0):
+            job.ref[0][r] = pyrs[poc].desc()
+        for r, poc in enumerate(l1):
+            job.ref[1][r] = pyrs[poc].desc()
+        assert me_fn(C.byref(job), 0, nb) == 0
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(analyse, range(n)))          # every picture needs its pyramid before it can be a reference
+    t_pyr = time.perf_counter() - t0
+    todo = list(range(2, min(n - 2, 2 + n_frames_cap)))
+    t0 = time.perf_counter()
+    done = 0
+    with ThreadPoolExecutor(cores) as ex:
+        for chunk in range(0, len(todo), cores):
+            list(ex.map(me, todo[chunk:chunk + cores]))
+            done += len(todo[chunk:chunk + cores])
+            if time.perf_counter() - t0 > budget_s:
+                break
+    t_me = time.perf_counter() - t0
+    per_frame = t_pyr / n + t_me / done
+    return {"value": round(1.0 / per_frame, 3), "unit": "fps", "cores": cores,
+            "kind": "reference" if use_ref else "port",
+            "sample": f"{done} of the same synthetic 1080p pictures: pyramid+variance+open-loop ME (M8 params, 2+2 refs), "
+                      f"{'reference C functions (svt_aom_motion_estimation_b64 etc., gcc -O2)' if use_ref else 'oracle C restatement'}, "
+                      f"one picture per thread on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16, help="pictures per step and rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl")   # RCCL on ROCm; used for the barrier / max-time reduction only
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    lib = abi.load()                               # raises if the HIP extension is missing: no CPU fallback
+    rc = lib.svt_hip_init(local_rank)
+    assert rc == 0, lib.svt_hip_last_error().decode()
+
+    F = args.frames
+    n_clip = F + 4
+    clip = frames.synthetic_clip(WIDTH, HEIGHT, n_clip, seed=7 + rank)
+    nb = frames.b64_count(WIDTH, HEIGHT)
+    base_prm = load_params("m8_1080p_tl2")
+
+    def prm_for(i):
+        l0 = [i + o for o in L0_OFFS]
+        l1 = [i + o for o in L1_OFFS]
+        prm = abi.MeParams.from_buffer_copy(base_prm)
+        frames.set_refs(prm, i, l0, l1)
+        prm.is_ref = 1
+        return prm, l0, l1
+
+    # ---- device-resident inputs: full-resolution padded pictures (decimated planes are produced on the GPU)
+    host_pyrs = [frames.HostPyramid(f) for f in clip]
+    dpyr = [TorchPyramid(p, dev) for p in host_pyrs]
+    var_out = torch.zeros((n_clip, nb * 85 * 2), dtype=torch.uint8, device=dev)    # uint16 [nb][85] per picture
+    mean_out = torch.zeros((n_clip, nb * 85 * 8), dtype=torch.uint8, device=dev)   # uint64 [nb][85] per picture
+    shapes = frames.me_out_shapes(base_prm_with_refs(prm_for(2)[0]), nb)
+    outs, jobs = [], []
+    for i in range(2, 2 + F):
+        prm, l0, l1 = prm_for(i)
+        o = {k: torch.zeros(int(np.prod(s)) * np.dtype(dt).itemsize, dtype=torch.uint8, device=dev) for k, (dt, s) in shapes.items()}
+        job = abi.MeFrameJob()
+        job.prm, job.src = prm, dpyr[i].desc()
+        for r, poc in enumerate(l0):
+            job.ref[0][r] = dpyr[poc].desc()
+        for r, poc in enumerate(l1):
+            job.ref[1][r] = dpyr[poc].desc()
+        job.out = abi.MeFrameOut(**{k: v.data_ptr() for k, v in o.items()})
+        outs.append(o)
+        jobs.append(job)
+    jarr = (abi.MeFrameJob * F)(*jobs)
+    max_b64 = C.c_uint32(0)
+    rc = lib.svt_hip_me_validate_jobs(jarr, C.c_uint32(F), C.byref(max_b64))
+    assert rc == 0, lib.svt_hip_last_error().decode()
+    d_jobs = torch.from_numpy(np.frombuffer(jarr, dtype=np.uint8).copy()).to(dev)
+
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    pyr_descs = [p.desc() for p in dpyr]
+    ev_me = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(k=None):
+        # pyramid + variance of the F pictures of this step (+ the 4 boundary pictures they reference)
+        for i in range(n_clip):
+            d = pyr_descs[i]
+            rc = lib.svt_hip_pyramid_frame(C.byref(d.full), C.byref(d.quarter), C.byref(d.sixteenth), 1, sp)
+            assert rc == 0, lib.svt_hip_last_error().decode()
+            rc = lib.svt_hip_variance_frame(C.byref(d.full), C.c_void_p(var_out[i].data_ptr()), C.c_void_p(mean_out[i].data_ptr()), 0, sp)
+            assert rc == 0, lib.svt_hip_last_error().decode()
+        if k is not None:
+            ev_me[k][0].record(stream)
+        rc = lib.svt_hip_me_frames_dev(C.c_void_p(d_jobs.data_ptr()), C.c_uint32(F), max_b64, sp)
+        assert rc == 0, lib.svt_hip_last_error().decode()
+        if k is not None:
+            ev_me[k][1].record(stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    me_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_me]))
+    n_refs = len(L0_OFFS) + len(L1_OFFS)
+    alg_bytes = algorithmic_bytes_me(WIDTH, HEIGHT, n_refs) * F       # per launch (one launch = F pictures)
+    achieved = alg_bytes / (me_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_me_b64_kernel.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("frames_per_launch") == F and tj.get("width") == WIDTH:
+                traffic = tj.get("hbm_bytes_per_launch")
+        line = {
+            "metric": "encoded fps (4K 10-bit preset 8) + ME+txfm HBM GB/s vs roofline, 1/2/4/8 GPU",
+            "value": round(F * world * args.steps / elapsed, 2),
+            "unit": "fps",
+            "value_scope": "fps of the open-loop analysis hot path (pyramid + variance + full per-b64 ME), not of a whole encode",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1080p 8-bit preset 8 open-loop ME (BASELINE.json configs[1]): pyramid+variance+HME+full-pel, "
+                                   "2+2 refs, M8 parameters from the reference's svt_aom_sig_deriv_me",
+                       "width": WIDTH, "height": HEIGHT, "pictures_per_step_per_gpu": F, "refs": n_refs,
+                       "parallelism": f"frame-shard x{world} (no data-path collective)"},
+            "roofline": {"bound": "hbm", "kernel": "me_b64_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(me_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(clip, prm_for)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def base_prm_with_refs(prm):
+    return prm
+
+
+if __name__ == "__main__":
+    main()

@@ -227,6 +227,14 @@ SVT_HIP_API uint32_t svt_hip_me_b64_count(uint32_t width, uint32_t height);
  * to the device on `stream`); all planes/outputs inside are device pointers.  Asynchronous. */
 SVT_HIP_API int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jobs, void *stream);
 
+/* Same, with the job array already resident on the device (`d_jobs`): exactly one kernel launch, nothing
+ * else is enqueued — the form to capture in a hipGraph or to bracket with events.  `max_b64` = largest
+ * svt_hip_me_b64_count() over the jobs.  The jobs must have been validated once through
+ * svt_hip_me_validate_jobs (host copy). */
+SVT_HIP_API int32_t svt_hip_me_validate_jobs(const SvtHipMeFrameJob *jobs, uint32_t n_jobs, uint32_t *max_b64);
+SVT_HIP_API int32_t svt_hip_me_frames_dev(const SvtHipMeFrameJob *d_jobs, uint32_t n_jobs, uint32_t max_b64,
+                                          void *stream);
+
 /* Installs the Tier A functions into a table of the reference's RTCD pointers.  `table` holds the
  * ADDRESSES of the encoder's pointers (e.g. &svt_sad_loop_kernel) in the order of
  * SvtHipRtcdSlot; NULL entries are skipped.  See INTEGRATION.md. */

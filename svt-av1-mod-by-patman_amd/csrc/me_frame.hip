@@ -1163,9 +1163,9 @@ static int32_t validate_job(const SvtHipMeFrameJob &j, uint32_t idx) {
     return SVT_HIP_OK;
 }
 
-extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jobs, void *stream) {
-    if (!jobs || n_jobs == 0) {
-        set_error("svt_hip_me_frames: no jobs");
+extern "C" int32_t svt_hip_me_validate_jobs(const SvtHipMeFrameJob *jobs, uint32_t n_jobs, uint32_t *max_b64_out) {
+    if (!jobs || n_jobs == 0 || n_jobs > 65535) {
+        set_error("svt_hip_me_frames: bad job count");
         return SVT_HIP_ERR_BAD_PARAMETER;
     }
     uint32_t max_b64 = 0;
@@ -1176,6 +1176,28 @@ extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jo
         const uint32_t nb = svt_hip_me_b64_count(jobs[i].src.full.width, jobs[i].src.full.height);
         max_b64           = nb > max_b64 ? nb : max_b64;
     }
+    if (max_b64_out)
+        *max_b64_out = max_b64;
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_me_frames_dev(const SvtHipMeFrameJob *d_jobs, uint32_t n_jobs, uint32_t max_b64, void *stream) {
+    if (!d_jobs || n_jobs == 0 || n_jobs > 65535 || max_b64 == 0) {
+        set_error("svt_hip_me_frames_dev: bad argument");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(me_b64_kernel, dim3(max_b64, n_jobs), dim3(WG_THREADS), 0, resolve_stream(stream), d_jobs);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jobs, void *stream) {
+    uint32_t      max_b64 = 0;
+    const int32_t vrc     = svt_hip_me_validate_jobs(jobs, n_jobs, &max_b64);
+    if (vrc != SVT_HIP_OK)
+        return vrc;
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
     hipStream_t st = resolve_stream(stream);

@@ -17,7 +17,7 @@ u32p = C.POINTER(C.c_uint32)
 
 
 def P(a, off=0):
-    return C.cast(a.ctypes.data + off, u8p)
+    return C.cast(int(a.ctypes.data) + int(off), u8p)
 
 
 # ----------------------------------------------------------------------------- Tier A (per-call, host pointers)
