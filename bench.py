@@ -190,7 +190,10 @@ def main():
     assert rc == 0, lib.svt_hip_last_error().decode()
     d_jobs = torch.from_numpy(np.frombuffer(jarr, dtype=np.uint8).copy()).to(dev)
 
-    stream = torch.cuda.current_stream()
+    # A dedicated (non-default) stream: its handle goes to the library, and the events that time the dominant
+    # kernel are recorded on the very same stream.
+    stream = torch.cuda.Stream(device=dev)
+    assert stream.cuda_stream != 0
     sp = C.c_void_p(stream.cuda_stream)
     pyr_descs = [p.desc() for p in dpyr]
     ev_me = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

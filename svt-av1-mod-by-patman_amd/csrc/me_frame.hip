@@ -31,8 +31,8 @@ namespace {
 #define MAX_SAD_VALUE_ (128 * 128 * 255) /* motion_estimation.h:85 */
 #define MAX_U32_ 0xFFFFFFFFu
 
-constexpr uint32_t ME_WIN_DW   = 4096;  // 16 KiB LDS window buffer
-constexpr uint32_t TILE_MAXPOS = 128;   // full-pel positions per tile
+constexpr uint32_t ME_WIN_DW   = 2048;  // 8 KiB LDS window buffer (bigger windows are searched in several passes)
+constexpr uint32_t TILE_MAXPOS = 64;    // full-pel positions per tile
 
 struct PreHme {
     uint64_t sad;
@@ -60,6 +60,8 @@ struct B64State {
     int16_t  xc, yc, sw, sh, ox, oy;
     int32_t  do_centre, need_zero_sad, need_hme_sad;
     uint32_t zero_sad, hme_mv_sad;
+    uint32_t first_ref_sad64;        // p_sb_best_sad[0][0][0] (read by later references, :1359)
+    uint64_t me_sad_sum[NL][NR];     // sum of the 64 best 8x8 SADs per reference (me_prune_ref, :1605-1611)
 };
 
 struct MeLds {
@@ -71,7 +73,6 @@ struct MeLds {
     uint32_t     src_s[16 * 4];
     uint16_t     sad8[TILE_MAXPOS][64];
     uint64_t     bestkey[85];
-    uint32_t     best_sad[NL][NR][85], best_mv[NL][NR][85];
     uint32_t     me_dist[85];
 };
 
@@ -272,11 +273,6 @@ __device__ const uint8_t z_to_raster_d[85] = {
     0,  1,  2,  3,  4,  5,  6,  9,  10, 7,  8,  11, 12, 13, 14, 17, 18, 15, 16, 19, 20, 21, 22, 29, 30, 23, 24, 31, 32,
     37, 38, 45, 46, 39, 40, 47, 48, 25, 26, 33, 34, 27, 28, 35, 36, 41, 42, 49, 50, 43, 44, 51, 52, 53, 54, 61, 62, 55,
     56, 63, 64, 69, 70, 77, 78, 71, 72, 79, 80, 57, 58, 65, 66, 59, 60, 67, 68, 73, 74, 81, 82, 75, 76, 83, 84};
-__device__ const uint8_t tab8x8_d[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,  18, 19, 22, 23,
-                                         8,  9,  12, 13, 24, 25, 28, 29, 10, 11, 14, 15, 26, 27, 30, 31,
-                                         32, 33, 36, 37, 48, 49, 52, 53, 34, 35, 38, 39, 50, 51, 54, 55,
-                                         40, 41, 44, 45, 56, 57, 60, 61, 42, 43, 46, 47, 58, 59, 62, 63};
-
 __device__ __forceinline__ uint8_t pack_cand(uint32_t direction, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1) {
     return (uint8_t)((direction & 3) | ((l0 & 3) << 2) | ((l1 & 3) << 4) | ((r0 & 1) << 6) | ((r1 & 1) << 7));
 }
@@ -284,19 +280,23 @@ __device__ __forceinline__ int use_me_pu(const SvtHipMeParams &p, uint32_t n) {
     return p.enable_me_16x16 ? (p.enable_me_8x8 || n < 21) : (n < 5);
 }
 
-__device__ void cand_single_ref(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint32_t *mv, uint8_t *cand) {
+#define GS(li, ri, n) gs[((li) * NR + (ri)) * 85 + (n)]
+#define GM(li, ri, n) gm[((li) * NR + (ri)) * 85 + (n)]
+
+__device__ void cand_single_ref(MeLds &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+                                uint32_t *mv, uint8_t *cand) {
     const uint8_t pu = z_to_raster_d[n];
-    L.me_dist[pu]    = L.best_sad[0][0][n];
+    L.me_dist[pu]    = GS(0, 0, n);
     if (!L.st.sr[0][0].do_ref)
         return;
     if (use_me_pu(p, n)) {
         cand[pu * p.max_cand] = pack_cand(0, 0, 0, 0, 0);
-        mv[pu * p.max_refs]   = L.best_mv[0][0][n];
+        mv[pu * p.max_refs]   = GM(0, 0, n);
     }
 }
 
-__device__ void cand_mrp_off(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint32_t nlist, uint32_t *mv, uint8_t *cand,
-                             uint8_t *total) {
+__device__ void cand_mrp_off(MeLds &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+                             uint32_t nlist, uint32_t *mv, uint8_t *cand, uint8_t *total) {
     const uint8_t org0 = L.st.sr[0][0].do_ref, org1 = (uint8_t)((nlist == 1) ? 0 : L.st.sr[1][0].do_ref);
     if (nlist < 2 || !L.st.sr[1][0].do_ref)
         nlist = 1;
@@ -306,7 +306,7 @@ __device__ void cand_mrp_off(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint
     const int      use = use_me_pu(p, n);
     uint8_t       *ca  = cand + pu * p.max_cand;
     uint8_t        dr[2] = {org0, org1};
-    const uint32_t s0 = L.best_sad[0][0][n], s1 = L.best_sad[1][0][n];
+    const uint32_t s0 = GS(0, 0, n), s1 = GS(1, 0, n);
     const uint32_t best = (org0 && org1) ? MINV(s0, s1) : org0 ? s0 : s1;
     L.me_dist[pu]       = best;
     int min_list        = -1;
@@ -325,12 +325,12 @@ __device__ void cand_mrp_off(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint
         }
         if (min_list != -1 && min_list != (int)li) {
             if (use)
-                mv[pu * p.max_refs + (li ? p.max_l0 : 0)] = L.best_mv[li][0][n];
+                mv[pu * p.max_refs + (li ? p.max_l0 : 0)] = GM(li, 0, n);
             continue;
         }
         if (use) {
             ca[off] = pack_cand(li, 0, 0, li == 0 ? li : 24, li == 1 ? li : 24);
-            mv[pu * p.max_refs + (li ? p.max_l0 : 0)] = L.best_mv[li][0][n];
+            mv[pu * p.max_refs + (li ? p.max_l0 : 0)] = GM(li, 0, n);
         }
         off++;
     }
@@ -340,8 +340,8 @@ __device__ void cand_mrp_off(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint
     }
 }
 
-__device__ void cand_general(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint32_t nlist, uint32_t *mv, uint8_t *cand,
-                             uint8_t *total) {
+__device__ void cand_general(MeLds &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+                             uint32_t nlist, uint32_t *mv, uint8_t *cand, uint8_t *total) {
     const uint8_t pu  = (n > 4) ? z_to_raster_d[n] : (uint8_t)n;
     uint8_t       off = 0;
     const int     use = use_me_pu(p, n);
@@ -354,7 +354,7 @@ __device__ void cand_general(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint
             if (!L.st.sr[li][ri].do_ref)
                 continue;
             drm |= 1u << (li * 4 + ri);
-            best = L.best_sad[li][ri][n] < best ? L.best_sad[li][ri][n] : best;
+            best = GS(li, ri, n) < best ? GS(li, ri, n) : best;
         }
     L.me_dist[pu] = best;
     for (uint32_t li = 0; li < nlist && (use || off == 0); ++li)
@@ -362,7 +362,7 @@ __device__ void cand_general(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint
             if (!(drm & (1u << (li * 4 + ri))))
                 continue;
             if (prune_th > 0) {
-                const uint32_t d = (L.best_sad[li][ri][n] - best) * 100u;
+                const uint32_t d = (GS(li, ri, n) - best) * 100u;
                 if (d > (uint32_t)(best * prune_th)) {
                     drm &= ~(1u << (li * 4 + ri));
                     continue;
@@ -370,7 +370,7 @@ __device__ void cand_general(MeLds &L, const SvtHipMeParams &p, uint32_t n, uint
             }
             if (use) {
                 ca[off] = pack_cand(li, ri, ri, li == 0 ? li : 24, li == 1 ? li : 24);
-                mv[pu * p.max_refs + (li ? p.max_l0 : 0) + ri] = L.best_mv[li][ri][n];
+                mv[pu * p.max_refs + (li ? p.max_l0 : 0) + ri] = GM(li, ri, n);
             }
             off++;
         }
@@ -429,11 +429,13 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                                           (size_t)r * job.src.sixteenth.stride + 4 * i);
     }
     // ---- init_me_hme_data (motion_estimation.c:3080-3140) ----
-    for (uint32_t i = tid; i < NL * NR * 85; i += WG_THREADS) {
-        (&L.best_sad[0][0][0])[i] = 0;
-        (&L.best_mv[0][0][0])[i]  = 0;
-    }
+    uint32_t *const gs = job.out.best_sad + (size_t)b64 * NL * NR * 85;  // p_sb_best_sad / p_sb_best_mv of this b64
+    uint32_t *const gm = job.out.best_mv + (size_t)b64 * NL * NR * 85;   // live in the (L2-resident) output arrays
+    for (uint32_t i = tid; i < NL * NR * 85; i += WG_THREADS) gs[i] = 0, gm[i] = 0;
     if (tid == 0) {
+        S.first_ref_sad64 = 0;
+        for (int i = 0; i < NL; i++)
+            for (int j = 0; j < NR; j++) S.me_sad_sum[i][j] = 0;
         S.org_x = org_x, S.org_y = org_y, S.b64_w = b64_w, S.b64_h = b64_h;
         S.l0_min = p.hme_l0_sa_min, S.l0_max = p.hme_l0_sa_max;
         for (int i = 0; i < NL; i++)
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                         if (p.enable_me_sr_adjustment == 2) {
                             if ((accurate && (best_hme_sad < (24 * 24))) || (p.is_ref && S.sr[li][ri].hme_sad < (24 * 24)))
                                 sh_ = (int16_t)(sh_ / 2);
-                            if ((li || ri) && L.best_sad[0][0][0] < 5000 && sh_ == sh0 && sw == sw0) {
+                            if ((li || ri) && S.first_ref_sad64 < 5000 && sh_ == sh0 && sw == sw0) {
                                 sh_ = (int16_t)(sh_ >> 1);
                                 sw  = (int16_t)(sw >> 1);
                             }
@@ -1006,7 +1008,11 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                     const int      ox = S.ox, oy = S.oy;
                     const uint32_t sw = (uint32_t)(S.sw > 0 ? S.sw : 0), sh_ = (uint32_t)(S.sh > 0 ? S.sh : 0);
                     const uint32_t tw = sw < 32 ? sw : 32;
-                    const uint32_t th = tw ? MINV(sh_, MAXV(1u, TILE_MAXPOS / tw)) : 0;
+                    // tile height: at most TILE_MAXPOS positions and a window that fits the LDS buffer
+                    const uint32_t pitch_t = (((tw + 3) >> 2) + 17) | 1u;
+                    uint32_t       th      = tw ? MINV(sh_, MAXV(1u, TILE_MAXPOS / tw)) : 0;
+                    if (th && (th + 63) * pitch_t > ME_WIN_DW)
+                        th = ME_WIN_DW / pitch_t - 63;
                     for (uint32_t ty = 0; th && ty < sh_; ty += th)
                         for (uint32_t tx = 0; tx < sw; tx += tw) {
                             const uint32_t cw = MINV(tw, sw - tx), ch = MINV(th, sh_ - ty);
@@ -1014,10 +1020,14 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                                          1 + ty * sw + tx, sw, me_sub);
                         }
                     // keys -> p_sb_best_sad / p_sb_best_mv of this reference
+                    uint32_t my_sad = 0;
                     if (tid < 85) {
                         const uint64_t key = L.bestkey[tid];
                         const uint32_t ord = (uint32_t)key;
-                        L.best_sad[li][ri][tid] = (uint32_t)(key >> 32);
+                        my_sad             = (uint32_t)(key >> 32);
+                        gs[(li * NR + ri) * 85 + tid] = my_sad;
+                        if (li == 0 && ri == 0 && tid == 0)
+                            S.first_ref_sad64 = my_sad;
                         if (ord != 0xffffffffu) {
                             int16_t mx, my;
                             if (ord == 0) {
@@ -1026,8 +1036,14 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                                 const uint32_t pos = ord - 1;
                                 mx = (int16_t)((int)(pos % sw) + ox), my = (int16_t)((int)(pos / sw) + oy);
                             }
-                            L.best_mv[li][ri][tid] = ((uint32_t)(uint16_t)my << 16) | (uint16_t)mx;
+                            gm[(li * NR + ri) * 85 + tid] = ((uint32_t)(uint16_t)my << 16) | (uint16_t)mx;
                         }
+                    }
+                    // sum of the 64 8x8 SADs (tab8x8 is a permutation, so the plain sum equals :1608-1611)
+                    if (tid < 128) {
+                        const uint32_t part = wave_sum((tid >= 21 && tid < 85) ? my_sad : 0u);
+                        if ((tid & 63) == 0)
+                            atomicAdd((unsigned long long *)&S.me_sad_sum[li][ri], (unsigned long long)part);
                     }
                 }
                 __syncthreads();
@@ -1044,9 +1060,7 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                         S.sr[li][ri].hme_sad = (uint64_t)(MAX_SAD_VALUE_ * 64);
                         continue;
                     }
-                    uint64_t t = 0;
-                    for (int k = 0; k < 64; k++) t += L.best_sad[li][ri][21 + tab8x8_d[k]];
-                    S.sr[li][ri].hme_sad = t;
+                    S.sr[li][ri].hme_sad = S.me_sad_sum[li][ri];
                 }
             const uint16_t th = p.prune_ref_if_me_sad_dev_bigger_than_th;
             if (th != (uint16_t)~0) {
@@ -1075,11 +1089,11 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
     __syncthreads();
     if (tid < p.max_number_of_pus_per_sb && tid < 85) {
         if (single)
-            cand_single_ref(L, p, tid, o_mv, o_cand);
+            cand_single_ref(L, p, gs, gm, tid, o_mv, o_cand);
         else if (mrpoff)
-            cand_mrp_off(L, p, tid, (uint32_t)nlists, o_mv, o_cand, o_tot);
+            cand_mrp_off(L, p, gs, gm, tid, (uint32_t)nlists, o_mv, o_cand, o_tot);
         else
-            cand_general(L, p, tid, (uint32_t)nlists, o_mv, o_cand, o_tot);
+            cand_general(L, p, gs, gm, tid, (uint32_t)nlists, o_mv, o_cand, o_tot);
     }
     __syncthreads();
 
@@ -1102,10 +1116,6 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
         out.me_32x32_distortion[b64]  = (d32 * 4096u) / pix;
         out.me_16x16_distortion[b64]  = (d16 * 4096u) / pix;
         out.me_8x8_distortion[b64]    = (d8 * 4096u) / pix;
-    }
-    for (uint32_t i = tid; i < NL * NR * 85; i += WG_THREADS) {
-        out.best_sad[(size_t)b64 * NL * NR * 85 + i] = (&L.best_sad[0][0][0])[i];
-        out.best_mv[(size_t)b64 * NL * NR * 85 + i]  = (&L.best_mv[0][0][0])[i];
     }
     if (tid < NL * NR)
         out.search_results[(size_t)b64 * NL * NR + tid] = (&S.sr[0][0])[tid];
