@@ -1,0 +1,141 @@
+/*
+ * svt_hip_txfm.h — C-ABI for forward / inverse 2-D transforms and quantisation (SURVEY.md §8 rows a6–a8).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   Source/Lib/Codec/aom_dsp_rtcd.h:85-205     svt_av1_fwd_txfm2d_{WxH}[_N2|_N4]           (57 pointers)
+ *   Source/Lib/Codec/aom_dsp_rtcd.h:214-237    svt_handle_transform{16x64,32x64,64x16,64x32,64x64}[_N2_N4]
+ *   Source/Lib/Codec/aom_dsp_rtcd.h:244-260    svt_aom_quantize_b, svt_aom_highbd_quantize_b, svt_av1_quantize_b_qm,
+ *                                              svt_av1_highbd_quantize_b_qm, svt_av1_quantize_fp[_32x32|_64x64|_qm],
+ *                                              svt_av1_highbd_quantize_fp[_qm]
+ *   Source/Lib/Codec/common_dsp_rtcd.c:482-500 svt_av1_inv_txfm2d_add_{WxH}                 (19 pointers)
+ *   Source/Lib/Codec/full_loop.c:1462-1686     svt_aom_quantize_inv_quantize (the per-TB driver: Tier B batch)
+ *   Source/Lib/Codec/transforms.c:3100-3154    svt_aom_estimate_transform     (the per-TB driver: Tier B batch)
+ *
+ * TxType is the reference's enum (definitions.h:981-998, 0 = DCT_DCT ... 15 = H_FLIPADST); TranLow is int32_t;
+ * QmVal is uint8_t.
+ */
+#ifndef SVT_HIP_TXFM_H
+#define SVT_HIP_TXFM_H
+
+#include "svt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Tier A — ABI-identical per-call entry points (host pointers).
+ * ------------------------------------------------------------------------------------------- */
+#define SVT_HIP_FWD_DECL(W, H)                                                                                     \
+    SVT_HIP_API void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *input, int32_t *output, uint32_t input_stride,    \
+                                                        int32_t transform_type, uint8_t bit_depth);               \
+    SVT_HIP_API void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *input, int32_t *output, uint32_t input_stride, \
+                                                           int32_t transform_type, uint8_t bit_depth);            \
+    SVT_HIP_API void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *input, int32_t *output, uint32_t input_stride, \
+                                                           int32_t transform_type, uint8_t bit_depth);
+SVT_HIP_FWD_DECL(4, 4) SVT_HIP_FWD_DECL(8, 8) SVT_HIP_FWD_DECL(16, 16) SVT_HIP_FWD_DECL(32, 32) SVT_HIP_FWD_DECL(64, 64)
+SVT_HIP_FWD_DECL(4, 8) SVT_HIP_FWD_DECL(8, 4) SVT_HIP_FWD_DECL(8, 16) SVT_HIP_FWD_DECL(16, 8) SVT_HIP_FWD_DECL(16, 32)
+SVT_HIP_FWD_DECL(32, 16) SVT_HIP_FWD_DECL(32, 64) SVT_HIP_FWD_DECL(64, 32) SVT_HIP_FWD_DECL(4, 16) SVT_HIP_FWD_DECL(16, 4)
+SVT_HIP_FWD_DECL(8, 32) SVT_HIP_FWD_DECL(32, 8) SVT_HIP_FWD_DECL(16, 64) SVT_HIP_FWD_DECL(64, 16)
+
+/* svt_handle_transformWxH / _N2_N4: energy of the discarded 64-point area + repack to 32-wide */
+SVT_HIP_API uint64_t svt_handle_transform16x64_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform32x64_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform64x16_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform64x32_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform64x64_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform16x64_N2_N4_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform32x64_N2_N4_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform64x16_N2_N4_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform64x32_N2_N4_hip(int32_t *output);
+SVT_HIP_API uint64_t svt_handle_transform64x64_N2_N4_hip(int32_t *output);
+
+/* inverse + add; the three signature flavours of common_dsp_rtcd.h (square / 4xN / the rest) */
+#define SVT_HIP_INV_DECL_SQ(W, H)                                                                                    \
+    SVT_HIP_API void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, \
+                                                            uint16_t *output_w, int32_t stride_w, int32_t tx_type,  \
+                                                            int32_t bd);
+#define SVT_HIP_INV_DECL_TS(W, H)                                                                                    \
+    SVT_HIP_API void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, \
+                                                            uint16_t *output_w, int32_t stride_w, int32_t tx_type,  \
+                                                            int32_t tx_size, int32_t bd);
+#define SVT_HIP_INV_DECL_EOB(W, H)                                                                                   \
+    SVT_HIP_API void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, \
+                                                            uint16_t *output_w, int32_t stride_w, int32_t tx_type,  \
+                                                            int32_t tx_size, int32_t eob, int32_t bd);
+SVT_HIP_INV_DECL_SQ(4, 4) SVT_HIP_INV_DECL_SQ(8, 8) SVT_HIP_INV_DECL_SQ(16, 16) SVT_HIP_INV_DECL_SQ(32, 32)
+SVT_HIP_INV_DECL_SQ(64, 64) SVT_HIP_INV_DECL_TS(4, 8) SVT_HIP_INV_DECL_TS(8, 4) SVT_HIP_INV_DECL_TS(4, 16)
+SVT_HIP_INV_DECL_TS(16, 4) SVT_HIP_INV_DECL_EOB(8, 16) SVT_HIP_INV_DECL_EOB(16, 8) SVT_HIP_INV_DECL_EOB(16, 32)
+SVT_HIP_INV_DECL_EOB(32, 16) SVT_HIP_INV_DECL_EOB(32, 64) SVT_HIP_INV_DECL_EOB(64, 32) SVT_HIP_INV_DECL_EOB(8, 32)
+SVT_HIP_INV_DECL_EOB(32, 8) SVT_HIP_INV_DECL_EOB(16, 64) SVT_HIP_INV_DECL_EOB(64, 16)
+
+/* quantizers */
+#define SVT_HIP_QARGS                                                                                           \
+    const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr,            \
+        const int16_t *quant_ptr, const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr,   \
+        const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, const int16_t *iscan
+SVT_HIP_API void svt_aom_quantize_b_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int32_t log_scale);
+SVT_HIP_API void svt_av1_quantize_b_qm_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int32_t log_scale);
+SVT_HIP_API void svt_aom_highbd_quantize_b_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int32_t log_scale);
+SVT_HIP_API void svt_av1_highbd_quantize_b_qm_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int32_t log_scale);
+SVT_HIP_API void svt_av1_quantize_fp_hip(SVT_HIP_QARGS);
+SVT_HIP_API void svt_av1_quantize_fp_32x32_hip(SVT_HIP_QARGS);
+SVT_HIP_API void svt_av1_quantize_fp_64x64_hip(SVT_HIP_QARGS);
+SVT_HIP_API void svt_av1_quantize_fp_qm_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
+SVT_HIP_API void svt_av1_highbd_quantize_fp_hip(SVT_HIP_QARGS, int16_t log_scale);
+SVT_HIP_API void svt_av1_highbd_quantize_fp_qm_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tier B — batched, fused transform block processing on device-resident data:
+ *   residual --fwd txfm--> coeff --[64-pt: energy + repack]--> quantize --> qcoeff/dqcoeff/eob
+ *            --[optional]--> inverse txfm + prediction --> reconstruction
+ * One call = n blocks of ONE size (w x h); type / shape / quantizer parameters vary per block.
+ * All offsets are BYTE offsets into one device arena `d_base`; SVT_HIP_NO_OFFSET disables an output.
+ * ------------------------------------------------------------------------------------------- */
+#define SVT_HIP_NO_OFFSET (~(uint64_t)0)
+
+enum { /* SvtHipTxfmDesc::quant_mode */
+    SVT_HIP_QUANT_NONE = 0,
+    SVT_HIP_QUANT_B,        /* svt_aom_quantize_b          (full_loop.c:25-75)   */
+    SVT_HIP_QUANT_B_HBD,    /* svt_aom_highbd_quantize_b   (full_loop.c:145-194) */
+    SVT_HIP_QUANT_FP,       /* svt_av1_quantize_fp*        (full_loop.c:278-338) */
+    SVT_HIP_QUANT_FP_HBD    /* svt_av1_highbd_quantize_fp* (full_loop.c:383-449) */
+};
+enum { /* SvtHipTxfmDesc::flags */
+    SVT_HIP_TX_FWD     = 1, /* run the forward transform from `residual_off` */
+    SVT_HIP_TX_INV     = 2, /* run the inverse transform + add (needs dqcoeff: computed here or read from dqcoeff_off) */
+    SVT_HIP_TX_PIXEL16 = 4, /* pred / recon are uint16 planes (else uint8, bit_depth must be 8) */
+    SVT_HIP_TX_FULLCOEFF = 8 /* coeff_off receives the complete [h][w] array even for 64-point sizes (no repack) */
+};
+
+typedef struct SvtHipTxfmDesc {
+    uint64_t residual_off;            /* int16 [h][residual_stride] */
+    uint64_t coeff_off;               /* int32 out: [h][w], or [min(h,32)][min(w,32)] repacked for 64-point sizes */
+    uint64_t qcoeff_off, dqcoeff_off; /* int32 [n], n = min(w,32)*min(h,32) */
+    uint64_t pred_off, recon_off;     /* pixel planes (SVT_HIP_TX_INV) */
+    uint64_t iscan_off;               /* int16 iscan[n] (position of raster index in scan order) */
+    uint64_t qm_off, iqm_off;         /* uint8 [n] quantisation matrices or SVT_HIP_NO_OFFSET */
+    uint32_t residual_stride;         /* in int16 units */
+    uint32_t pred_stride, recon_stride; /* in pixels */
+    int16_t  zbin[2], round[2], quant[2], quant_shift[2], dequant[2]; /* [0] DC, [1] AC */
+    uint8_t  tx_type, shape /* 0 full, 1 N2, 2 N4 */, bit_depth, quant_mode, log_scale, flags;
+    uint8_t  pad_[2];
+} SvtHipTxfmDesc;
+
+typedef struct SvtHipTxfmResult {
+    uint64_t three_quad_energy; /* svt_handle_transformWxH return value (0 for sizes without a 64-point side) */
+    uint16_t eob;
+    uint16_t pad_[3];
+} SvtHipTxfmResult;
+
+SVT_HIP_API int32_t svt_hip_txfm_quant_batch(uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
+                                             uint32_t n_blocks, uint32_t w, uint32_t h, void *stream);
+
+/* Stand-alone batched quantiser over device coefficient arrays (same descriptor; coeff_off is the INPUT). */
+SVT_HIP_API int32_t svt_hip_quantize_batch(uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
+                                           uint32_t n_blocks, uint32_t n_coeffs, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_TXFM_H */

@@ -1,0 +1,629 @@
+// txfm.hip — fused forward transform -> (64-pt energy/repack) -> quantise -> [inverse transform + reconstruction]
+// for batches of transform blocks, plus the ABI-identical per-call entry points (include/svt_hip_txfm.h).
+//
+// Mapping: a transform block (TB) of W x H uses L = max(W, H) adjacent lanes of one wavefront.  Column pass: lane c
+// owns column c (H values in VGPRs, 1-D network fully unrolled, txfm_device.hpp); the W x H intermediate goes
+// through LDS (row pitch W+1: conflict-free both ways); row pass: lane r owns row r and — still in registers —
+// applies the 64-point energy/zero-out, the quantiser (scan position via the caller's iscan table, eob by a
+// lane-group max-reduction) and, if requested, feeds the de-quantised row straight into the inverse row pass.
+// The per-TB HBM traffic is therefore exactly the algorithmic minimum: residual in, qcoeff/dqcoeff (and recon) out.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/svt_hip_txfm.h"
+#include "common.hpp"
+#include "txfm_device.hpp"
+
+using namespace svthip;
+using namespace svthip::txd;
+
+namespace {
+
+// ---- per-size constants (transforms.h:26-49, inv_transforms.c:17-35; see oracle/src/orc_txfm.c) ----
+constexpr int8_t FWD_SHIFT[5][5][3] = {
+    {{2, 0, 0}, {2, -1, 0}, {2, -1, 0}, {0, 0, 0}, {0, 0, 0}},   {{2, -1, 0}, {2, -1, 0}, {2, -2, 0}, {2, -2, 0}, {0, 0, 0}},
+    {{2, -1, 0}, {2, -2, 0}, {2, -2, 0}, {2, -4, 0}, {0, -2, 0}}, {{0, 0, 0}, {2, -2, 0}, {2, -4, 0}, {2, -4, 0}, {0, -2, -2}},
+    {{0, 0, 0}, {0, 0, 0}, {2, -4, 0}, {2, -4, -2}, {0, -2, -2}}};
+constexpr int8_t FWD_COS_COL[5][5] = {{13, 13, 13, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 13, 12, 13}, {0, 13, 13, 12, 13}, {0, 0, 13, 12, 13}};
+constexpr int8_t FWD_COS_ROW[5][5] = {{13, 13, 12, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 12, 13, 12}, {0, 12, 13, 12, 11}, {0, 0, 12, 11, 10}};
+constexpr int8_t INV_SHIFT0[5][5]  = {{0, 0, -1, 0, 0}, {0, -1, -1, -2, 0}, {-1, -1, -2, -1, -2}, {0, -2, -1, -2, -1}, {0, 0, -2, -1, -2}};
+__device__ const uint8_t VTX_D[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3};
+__device__ const uint8_t HTX_D[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int pow2floor(int v) {
+    int p = 1;
+    while (p * 2 <= v) p *= 2;
+    return p;
+}
+template <int W, int H>
+struct Geo {
+    static constexpr int L  = cmax(W, H);
+    static constexpr int PW = W + 1;
+    static constexpr int NT = cmin(256 / L, pow2floor(cmax(1, 12288 / (H * PW))));
+    static constexpr int IW = cmin(W, 32), IH = cmin(H, 32);
+    static constexpr int WI = clog2(W) - 2, HI = clog2(H) - 2;
+    static constexpr bool RECT = (W == 2 * H) || (H == 2 * W);
+};
+
+// ---- quantiser (per coefficient; semantics of full_loop.c:25-75, 145-194, 278-338, 383-449) ----
+struct QP {
+    int32_t        zbin[2], round[2], quant[2], qshift[2], dequant[2];
+    int32_t        log_scale, mode;
+    const uint8_t *qm, *iqm;
+};
+__device__ __forceinline__ int32_t rpot(int32_t v, int n) { return (v + ((1 << n) >> 1)) >> n; }
+__device__ __forceinline__ void load_qp(QP &q, const SvtHipTxfmDesc &d, const uint8_t *base) {
+    q.log_scale = d.log_scale, q.mode = d.quant_mode;
+    for (int i = 0; i < 2; i++) {
+        q.zbin[i]    = rpot(d.zbin[i], d.log_scale);
+        q.round[i]   = rpot(d.round[i], d.log_scale);
+        q.quant[i]   = d.quant[i];
+        q.qshift[i]  = d.quant_shift[i];
+        q.dequant[i] = d.dequant[i];
+    }
+    q.qm  = d.qm_off == SVT_HIP_NO_OFFSET ? nullptr : base + d.qm_off;
+    q.iqm = d.iqm_off == SVT_HIP_NO_OFFSET ? nullptr : base + d.iqm_off;
+}
+__device__ __forceinline__ int64_t clamp_i16(int64_t v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+__device__ __forceinline__ void quant_one(const QP &q, int32_t c, uint32_t rc, int32_t &qc, int32_t &dqc) {
+    const int     ac   = rc != 0;
+    const int32_t sign = c < 0 ? -1 : 0;
+    const int32_t absc = (c ^ sign) - sign;
+    const int32_t wt = q.qm ? q.qm[rc] : 32, iwt = q.iqm ? q.iqm[rc] : 32;
+    const int     ls = q.log_scale;
+    int32_t       aq = 0, dq = q.dequant[ac];
+    if (q.mode == SVT_HIP_QUANT_B) {
+        if (mul32(absc, wt) >= (q.zbin[ac] << 5)) {
+            int64_t tmp = clamp_i16((int64_t)add32(absc, q.round[ac]));
+            tmp *= wt;
+            aq = (int32_t)(((((tmp * q.quant[ac]) >> 16) + tmp) * q.qshift[ac]) >> (16 - ls + 5));
+            dq = (q.dequant[ac] * iwt + 16) >> 5;
+        }
+    } else if (q.mode == SVT_HIP_QUANT_B_HBD) {
+        const int32_t cw = mul32(c, wt);
+        if (cw >= q.zbin[ac] * 32 || cw <= -q.zbin[ac] * 32) {
+            const int64_t tmpw = ((int64_t)absc + q.round[ac]) * wt;
+            const int64_t tmp2 = ((tmpw * q.quant[ac]) >> 16) + tmpw;
+            aq = (int32_t)((tmp2 * q.qshift[ac]) >> (16 - ls + 5));
+            dq = (q.dequant[ac] * iwt + 16) >> 5;
+        }
+    } else if (q.mode == SVT_HIP_QUANT_FP) {
+        if (!q.qm && !q.iqm) {
+            if (((int64_t)absc << (1 + ls)) >= (int64_t)q.dequant[ac]) {
+                const int64_t a2 = clamp_i16((int64_t)absc + q.round[ac]);
+                aq = (int32_t)((a2 * q.quant[ac]) >> (16 - ls));
+            }
+        } else {
+            dq = (q.dequant[ac] * iwt + 16) >> 5;
+            if ((int64_t)absc * wt >= (int64_t)(q.dequant[ac] << (5 - (1 + ls)))) {
+                const int64_t a2 = clamp_i16((int64_t)absc + q.round[ac]);
+                aq = (int32_t)((a2 * wt * q.quant[ac]) >> (16 - ls + 5));
+            }
+        }
+    } else {  // SVT_HIP_QUANT_FP_HBD
+        if (q.qm || q.iqm) {
+            dq = (q.dequant[ac] * iwt + 16) >> 5;
+            if ((int64_t)absc * wt >= (int64_t)(q.dequant[ac] << (5 - (1 + ls)))) {
+                const int64_t tmp = (int64_t)absc + q.round[ac];
+                aq = (int32_t)((tmp * q.quant[ac] * wt) >> (16 - ls + 5));
+            }
+        } else {
+            if ((int32_t)((uint32_t)absc << (1 + ls)) >= q.dequant[ac]) {
+                const int64_t tmp = (int64_t)absc + q.round[ac];
+                aq = (int32_t)((tmp * q.quant[ac]) >> (16 - ls));
+            }
+        }
+    }
+    qc                = (aq ^ sign) - sign;
+    const int32_t adq = mul32(aq, dq) >> ls;
+    dqc               = (adq ^ sign) - sign;
+}
+
+template <int L>
+__device__ __forceinline__ uint32_t group_max(uint32_t v) {
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off, 64);
+        v                = o > v ? o : v;
+    }
+    return v;
+}
+template <int L>
+__device__ __forceinline__ uint64_t group_sum64(uint64_t v) {
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint16_t clip_pixel_add(uint32_t dest, int32_t trans, int bd) {
+    const int64_t mx = ((int64_t)1 << (7 + bd)) - 1 + ((int64_t)914 << (bd - 7)), mn = -mx - 1;
+    int64_t       t  = trans;
+    t                = t > mx ? mx : (t < mn ? mn : t);
+    const int32_t v  = (int32_t)dest + (int32_t)t;
+    const int32_t hi = (1 << bd) - 1;
+    return (uint16_t)(v < 0 ? 0 : (v > hi ? hi : v));
+}
+
+template <int W, int H>
+__global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(uint8_t *__restrict__ base,
+                                                                            const SvtHipTxfmDesc *__restrict__ descs,
+                                                                            SvtHipTxfmResult *__restrict__ results,
+                                                                            uint32_t n) {
+    using G = Geo<W, H>;
+    constexpr int L = G::L, PW = G::PW, NT = G::NT, IW = G::IW, IH = G::IH;
+    __shared__ int32_t buf[NT][H * PW];
+    const int          t = threadIdx.x % L, slot = threadIdx.x / L;
+    const uint32_t     tb   = blockIdx.x * NT + slot;
+    const bool         live = tb < n;
+    const SvtHipTxfmDesc &d = descs[live ? tb : 0];
+    const int vk = VTX_D[d.tx_type & 15], hk = HTX_D[d.tx_type & 15];
+    const bool ud = vk == 2, lr = hk == 2;
+    const int  bd = d.bit_depth;
+    const bool do_fwd = d.flags & SVT_HIP_TX_FWD, do_inv = d.flags & SVT_HIP_TX_INV;
+    constexpr int sh0 = FWD_SHIFT[G::WI][G::HI][0], sh1 = FWD_SHIFT[G::WI][G::HI][1], sh2 = FWD_SHIFT[G::WI][G::HI][2];
+    int32_t *lds = buf[slot];
+    int32_t  row[W];
+#pragma unroll
+    for (int c = 0; c < W; c++) row[c] = 0;
+
+    // ------------------------------------------------------------------ forward: columns
+    if (do_fwd) {
+        if (live && t < W) {
+            int32_t        v[H];
+            const int16_t *res = (const int16_t *)(base + d.residual_off);
+#pragma unroll
+            for (int r = 0; r < H; r++) v[r] = (int32_t)((uint32_t)(int32_t)res[(size_t)(ud ? H - 1 - r : r) * d.residual_stride + t] << sh0);
+            fwd1d<H>(v, vk, FWD_COS_COL[G::WI][G::HI]);
+            const int cc = lr ? W - 1 - t : t;
+#pragma unroll
+            for (int r = 0; r < H; r++) lds[r * PW + cc] = sh1 < 0 ? rshift64(v[r], -sh1) : v[r];
+        }
+        __syncthreads();
+        // -------------------------------------------------------------- forward: rows
+        if (live && t < H) {
+#pragma unroll
+            for (int c = 0; c < W; c++) row[c] = lds[t * PW + c];
+            fwd1d<W>(row, hk, FWD_COS_ROW[G::WI][G::HI]);
+            const int kw = W >> d.shape, kh = H >> d.shape;
+#pragma unroll
+            for (int c = 0; c < W; c++) {
+                int32_t x = sh2 < 0 ? rshift64(row[c], -sh2) : row[c];
+                if (G::RECT)
+                    x = rshift64((int64_t)x * 5793, 12);
+                row[c] = (t < kh && c < kw) ? x : 0;
+            }
+        }
+    }
+    // ---------------------------------------------------------------------- 64-point energy (svt_handle_transformWxH)
+    uint64_t energy = 0;
+    if constexpr (W == 64 || H == 64) {
+        if (do_fwd && live && t < H) {
+#pragma unroll
+            for (int c = 0; c < W; c++)
+                if (t >= IH || c >= IW)
+                    energy += (uint64_t)((int64_t)row[c] * (int64_t)row[c]);
+        }
+        energy = group_sum64<L>(energy);
+    }
+    // ---------------------------------------------------------------------- coefficients out / quantise
+    uint32_t eob = 0;
+    if (live && do_fwd && d.coeff_off != SVT_HIP_NO_OFFSET && (d.flags & SVT_HIP_TX_FULLCOEFF) && t < H) {
+        int32_t *co = (int32_t *)(base + d.coeff_off) + t * W;
+#pragma unroll
+        for (int c = 0; c < W; c++) co[c] = row[c];
+    }
+    if (live && t < IH) {
+        if (do_fwd && d.coeff_off != SVT_HIP_NO_OFFSET && !(d.flags & SVT_HIP_TX_FULLCOEFF)) {
+            int32_t *co = (int32_t *)(base + d.coeff_off) + t * IW;
+#pragma unroll
+            for (int c = 0; c < IW; c++) co[c] = row[c];
+        }
+        if (d.quant_mode != SVT_HIP_QUANT_NONE) {
+            QP q;
+            load_qp(q, d, base);
+            const int16_t *iscan = (const int16_t *)(base + d.iscan_off);
+            int32_t       *qo = d.qcoeff_off == SVT_HIP_NO_OFFSET ? nullptr : (int32_t *)(base + d.qcoeff_off) + t * IW;
+            int32_t       *dqo = d.dqcoeff_off == SVT_HIP_NO_OFFSET ? nullptr : (int32_t *)(base + d.dqcoeff_off) + t * IW;
+            if (!do_fwd) {  // quantise coefficients that already live in memory
+                const int32_t *ci = (const int32_t *)(base + d.coeff_off) + t * IW;
+#pragma unroll
+                for (int c = 0; c < IW; c++) row[c] = ci[c];
+            }
+#pragma unroll
+            for (int c = 0; c < IW; c++) {
+                const uint32_t rc = (uint32_t)(t * IW + c);
+                int32_t        qc, dqc;
+                quant_one(q, row[c], rc, qc, dqc);
+                if (qc) {
+                    const uint32_t pos = (uint32_t)(uint16_t)iscan[rc] + 1u;
+                    eob                = pos > eob ? pos : eob;
+                }
+                if (qo) qo[c] = qc;
+                if (dqo) dqo[c] = dqc;
+                row[c] = dqc;
+            }
+        } else if (do_inv && !do_fwd) {
+            const int32_t *dqi = (const int32_t *)(base + d.dqcoeff_off) + t * IW;
+#pragma unroll
+            for (int c = 0; c < IW; c++) row[c] = dqi[c];
+        }
+    }
+    eob = group_max<L>(eob);
+    if (live && t == 0) {
+        SvtHipTxfmResult r;
+        r.three_quad_energy = energy;
+        r.eob               = (uint16_t)eob;
+        r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+        results[tb]                       = r;
+    }
+    // ---------------------------------------------------------------------- inverse: rows
+    __syncthreads();
+    if (live && do_inv && t < H) {
+        const int range_row = bd == 8 ? 16 : (bd == 10 ? 18 : 20);
+        const int clamp_in  = bd + 8;
+        bool      any       = false;
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int32_t x = (t < IH && c < IW) ? row[c] : 0;
+            if (G::RECT)
+                x = rshift64((int64_t)x * 2896, 12);
+            row[c] = clampv<true>(x, clamp_in);
+            any |= row[c] != 0;
+        }
+        if (any) {  // an all-zero row stays all-zero through every 1-D kernel
+            inv1d<W>(row, hk, range_row);
+            constexpr int ish0 = INV_SHIFT0[G::WI][G::HI];
+#pragma unroll
+            for (int c = 0; c < W; c++) row[c] = ish0 < 0 ? rshift64(row[c], -ish0) : row[c];
+        }
+#pragma unroll
+        for (int c = 0; c < W; c++) lds[t * PW + c] = row[c];
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------------- inverse: columns + reconstruction
+    if (live && do_inv && t < W) {
+        int32_t   v[H];
+        const int range_col = bd == 12 ? 18 : 16, col_clamp = bd + 6 > 16 ? bd + 6 : 16;
+        const int cc = lr ? W - 1 - t : t;
+#pragma unroll
+        for (int r = 0; r < H; r++) v[r] = clampv<true>(lds[r * PW + cc], col_clamp);
+        inv1d<H>(v, vk, range_col);
+        if (d.flags & SVT_HIP_TX_PIXEL16) {
+            const uint16_t *pr = (const uint16_t *)(base + d.pred_off);
+            uint16_t       *rc = (uint16_t *)(base + d.recon_off);
+#pragma unroll
+            for (int r = 0; r < H; r++)
+                rc[(size_t)r * d.recon_stride + t] = clip_pixel_add(pr[(size_t)r * d.pred_stride + t], rshift64(v[ud ? H - 1 - r : r], 4), bd);
+        } else {
+            const uint8_t *pr = base + d.pred_off;
+            uint8_t       *rc = base + d.recon_off;
+#pragma unroll
+            for (int r = 0; r < H; r++)
+                rc[(size_t)r * d.recon_stride + t] = (uint8_t)clip_pixel_add(pr[(size_t)r * d.pred_stride + t], rshift64(v[ud ? H - 1 - r : r], 4), 8);
+        }
+    }
+}
+
+// Stand-alone quantiser: one workgroup per block of n coefficients.
+__global__ __launch_bounds__(256) void quantize_kernel(uint8_t *__restrict__ base, const SvtHipTxfmDesc *__restrict__ descs,
+                                                       SvtHipTxfmResult *__restrict__ results, uint32_t n_coeffs) {
+    __shared__ uint32_t   s_eob;
+    const SvtHipTxfmDesc &d = descs[blockIdx.x];
+    if (threadIdx.x == 0)
+        s_eob = 0;
+    __syncthreads();
+    QP q;
+    load_qp(q, d, base);
+    const int32_t *ci    = (const int32_t *)(base + d.coeff_off);
+    const int16_t *iscan = (const int16_t *)(base + d.iscan_off);
+    int32_t       *qo = (int32_t *)(base + d.qcoeff_off), *dqo = (int32_t *)(base + d.dqcoeff_off);
+    uint32_t       eob = 0;
+    for (uint32_t rc = threadIdx.x; rc < n_coeffs; rc += 256) {
+        int32_t qc, dqc;
+        quant_one(q, ci[rc], rc, qc, dqc);
+        if (qc) {
+            const uint32_t pos = (uint32_t)(uint16_t)iscan[rc] + 1u;
+            eob                = pos > eob ? pos : eob;
+        }
+        qo[rc] = qc, dqo[rc] = dqc;
+    }
+    eob = group_max<64>(eob);
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(&s_eob, eob);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SvtHipTxfmResult r;
+        r.three_quad_energy = 0, r.eob = (uint16_t)s_eob, r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+        results[blockIdx.x] = r;
+    }
+}
+
+// svt_handle_transformWxH on a coefficient buffer that already lives in memory (Tier A only).
+__global__ __launch_bounds__(256) void handle64_kernel(int32_t *__restrict__ co, int w, int h, int energy_on, uint64_t *__restrict__ out) {
+    __shared__ unsigned long long s_e;
+    if (threadIdx.x == 0)
+        s_e = 0;
+    __syncthreads();
+    const int iw = w < 32 ? w : 32, ih = h < 32 ? h : 32;
+    uint64_t  e  = 0;
+    if (energy_on)
+        for (int i = threadIdx.x; i < w * h; i += 256) {
+            const int r = i / w, c = i - r * w;
+            if (r >= ih || c >= iw)
+                e += (uint64_t)((int64_t)co[i] * (int64_t)co[i]);
+        }
+    e = group_sum64<64>(e);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(&s_e, (unsigned long long)e);
+    __syncthreads();
+    if (w == 64) {  // repack rows 1..ih-1 to a pitch of 32 (rows move towards lower addresses: go row by row)
+        for (int r = 1; r < ih; r++) {
+            int32_t v = 0;
+            if (threadIdx.x < 32)
+                v = co[r * 64 + threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x < 32)
+                co[r * 32 + threadIdx.x] = v;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0)
+        *out = s_e;
+}
+
+std::once_flag g_tables_once;
+int32_t        g_tables_rc = SVT_HIP_OK;
+void           upload_tables() {
+    int32_t cosv[4][64];
+    for (int b = 0; b < 4; b++)
+        for (int j = 0; j < 64; j++) cosv[b][j] = (int32_t)llround(cos(M_PI * j / 128.0) * (double)(1 << (10 + b)));
+    // AV1 sinpi constants (inv_transforms.c:3226-3234), bits 10..13
+    const int32_t sinv[4][5] = {{0, 330, 621, 836, 951}, {0, 660, 1241, 1672, 1901}, {0, 1321, 2482, 3344, 3803}, {0, 2642, 4964, 6689, 7606}};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_cospi), cosv, sizeof(cosv)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(d_sinpi), sinv, sizeof(sinv)) != hipSuccess) {
+        set_error("uploading transform constant tables failed");
+        g_tables_rc = SVT_HIP_ERR_RUNTIME;
+    }
+}
+int32_t txfm_ready() {
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    std::call_once(g_tables_once, upload_tables);
+    return g_tables_rc;
+}
+
+template <int W, int H>
+void launch_txfm(uint8_t *base, const SvtHipTxfmDesc *descs, SvtHipTxfmResult *res, uint32_t n, hipStream_t st) {
+    using G = Geo<W, H>;
+    hipLaunchKernelGGL((txfm_kernel<W, H>), dim3((n + G::NT - 1) / G::NT), dim3(G::NT * G::L), 0, st, base, descs, res, n);
+}
+
+bool dispatch_txfm(uint32_t w, uint32_t h, uint8_t *base, const SvtHipTxfmDesc *descs, SvtHipTxfmResult *res, uint32_t n,
+                   hipStream_t st) {
+#define CASE(W, H)                                \
+    if (w == W && h == H) {                       \
+        launch_txfm<W, H>(base, descs, res, n, st); \
+        return true;                              \
+    }
+    CASE(4, 4) CASE(8, 8) CASE(16, 16) CASE(32, 32) CASE(64, 64) CASE(4, 8) CASE(8, 4) CASE(8, 16) CASE(16, 8) CASE(16, 32)
+    CASE(32, 16) CASE(32, 64) CASE(64, 32) CASE(4, 16) CASE(16, 4) CASE(8, 32) CASE(32, 8) CASE(16, 64) CASE(64, 16)
+#undef CASE
+    return false;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ Tier B
+extern "C" int32_t svt_hip_txfm_quant_batch(uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
+                                            uint32_t n_blocks, uint32_t w, uint32_t h, void *stream) {
+    if (!d_base || !d_desc || !d_result) {
+        set_error("svt_hip_txfm_quant_batch: NULL pointer");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    const int32_t rc = txfm_ready();
+    if (rc != SVT_HIP_OK)
+        return rc;
+    if (n_blocks == 0)
+        return SVT_HIP_OK;
+    if (!dispatch_txfm(w, h, d_base, d_desc, d_result, n_blocks, resolve_stream(stream))) {
+        set_error("svt_hip_txfm_quant_batch: %ux%u is not an AV1 transform size", w, h);
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_quantize_batch(uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
+                                          uint32_t n_blocks, uint32_t n_coeffs, void *stream) {
+    if (!d_base || !d_desc || !d_result || n_coeffs == 0) {
+        set_error("svt_hip_quantize_batch: bad argument");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    const int32_t rc = txfm_ready();
+    if (rc != SVT_HIP_OK)
+        return rc;
+    if (n_blocks == 0)
+        return SVT_HIP_OK;
+    hipLaunchKernelGGL(quantize_kernel, dim3(n_blocks), dim3(256), 0, resolve_stream(stream), d_base, d_desc, d_result, n_coeffs);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Tier A
+namespace {
+
+void fatal(const char *what) {
+    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
+    abort();
+}
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+// One-block arena in the per-thread scratch: [desc][result][buffers...]
+struct Arena {
+    uint8_t *h, *d;
+    size_t   used;
+    Arena(size_t bytes) {
+        Scratch &sc = tls_scratch();
+        h = sc.host(bytes), d = sc.device(bytes), used = 512;
+    }
+    size_t put(const void *src, size_t bytes) {
+        const size_t off = used;
+        if (src)
+            memcpy(h + off, src, bytes);
+        used += up256(bytes + 16);
+        return off;
+    }
+};
+
+void run_one(int w, int h, Arena &a, size_t upload_bytes, hipStream_t st) {
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.d, a.h, upload_bytes, hipMemcpyHostToDevice, st));
+    if (!dispatch_txfm((uint32_t)w, (uint32_t)h, a.d, (const SvtHipTxfmDesc *)a.d, (SvtHipTxfmResult *)(a.d + 256), 1, st))
+        fatal("bad transform size");
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+}
+
+void fwd_tier_a(int w, int h, int shape, int16_t *input, int32_t *output, uint32_t stride, int32_t tx_type, uint8_t bd) {
+    if (txfm_ready() != SVT_HIP_OK)
+        fatal("forward transform");
+    const size_t in_bytes = ((size_t)(h - 1) * stride + w) * 2, out_bytes = (size_t)w * h * 4;
+    Arena        a(1024 + up256(in_bytes + 16) + up256(out_bytes + 16));
+    SvtHipTxfmDesc *dsc = (SvtHipTxfmDesc *)a.h;
+    memset(dsc, 0, sizeof(*dsc));
+    dsc->residual_off = a.put(input, in_bytes);
+    dsc->coeff_off    = a.put(nullptr, out_bytes);
+    dsc->qcoeff_off = dsc->dqcoeff_off = dsc->qm_off = dsc->iqm_off = dsc->iscan_off = dsc->pred_off = dsc->recon_off = SVT_HIP_NO_OFFSET;
+    dsc->residual_stride = stride;
+    dsc->tx_type = (uint8_t)tx_type, dsc->shape = (uint8_t)shape, dsc->bit_depth = bd;
+    dsc->quant_mode = SVT_HIP_QUANT_NONE, dsc->flags = SVT_HIP_TX_FWD | SVT_HIP_TX_FULLCOEFF;
+    hipStream_t st = resolve_stream(nullptr);
+    run_one(w, h, a, dsc->coeff_off, st);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.h + dsc->coeff_off, a.d + dsc->coeff_off, out_bytes, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    memcpy(output, a.h + dsc->coeff_off, out_bytes);
+}
+
+void inv_tier_a(int w, int h, const int32_t *input, uint16_t *out_r, int32_t stride_r, uint16_t *out_w, int32_t stride_w,
+                int32_t tx_type, int32_t bd) {
+    if (txfm_ready() != SVT_HIP_OK)
+        fatal("inverse transform");
+    const int    iw = w < 32 ? w : 32, ih = h < 32 ? h : 32;
+    const size_t co_bytes = (size_t)iw * ih * 4, pr_bytes = ((size_t)(h - 1) * stride_r + w) * 2,
+                 rc_bytes = ((size_t)(h - 1) * stride_w + w) * 2;
+    Arena           a(1024 + up256(co_bytes + 16) + up256(pr_bytes + 16) + up256(rc_bytes + 16));
+    SvtHipTxfmDesc *dsc = (SvtHipTxfmDesc *)a.h;
+    memset(dsc, 0, sizeof(*dsc));
+    dsc->dqcoeff_off = a.put(input, co_bytes);
+    dsc->pred_off    = a.put(out_r, pr_bytes);
+    dsc->recon_off   = a.put(nullptr, rc_bytes);
+    dsc->residual_off = dsc->coeff_off = dsc->qcoeff_off = dsc->qm_off = dsc->iqm_off = dsc->iscan_off = SVT_HIP_NO_OFFSET;
+    dsc->pred_stride = (uint32_t)stride_r, dsc->recon_stride = (uint32_t)stride_w;
+    dsc->tx_type = (uint8_t)tx_type, dsc->bit_depth = (uint8_t)bd;
+    dsc->quant_mode = SVT_HIP_QUANT_NONE, dsc->flags = SVT_HIP_TX_INV | SVT_HIP_TX_PIXEL16;
+    hipStream_t st = resolve_stream(nullptr);
+    run_one(w, h, a, dsc->recon_off, st);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.h + dsc->recon_off, a.d + dsc->recon_off, rc_bytes, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    const uint16_t *rc = (const uint16_t *)(a.h + dsc->recon_off);
+    for (int r = 0; r < h; r++) memcpy(out_w + (size_t)r * stride_w, rc + (size_t)r * stride_w, (size_t)w * 2);
+}
+
+void quant_tier_a(int mode, const int32_t *coeff_ptr, intptr_t n, const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                  const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob,
+                  const int16_t *iscan, const uint8_t *qm, const uint8_t *iqm, int log_scale) {
+    if (txfm_ready() != SVT_HIP_OK)
+        fatal("quantize");
+    const size_t    cb = (size_t)n * 4;
+    Arena           a(1024 + 3 * up256(cb + 16) + up256((size_t)n * 2 + 16) + 2 * up256((size_t)n + 16));
+    SvtHipTxfmDesc *dsc = (SvtHipTxfmDesc *)a.h;
+    memset(dsc, 0, sizeof(*dsc));
+    dsc->coeff_off = a.put(coeff_ptr, cb);
+    dsc->iscan_off = a.put(iscan, (size_t)n * 2);
+    dsc->qm_off    = qm ? a.put(qm, (size_t)n) : SVT_HIP_NO_OFFSET;
+    dsc->iqm_off   = iqm ? a.put(iqm, (size_t)n) : SVT_HIP_NO_OFFSET;
+    const size_t upload = a.used;
+    dsc->qcoeff_off     = a.put(nullptr, cb);
+    dsc->dqcoeff_off    = a.put(nullptr, cb);
+    dsc->residual_off = dsc->pred_off = dsc->recon_off = SVT_HIP_NO_OFFSET;
+    for (int i = 0; i < 2; i++) {
+        dsc->zbin[i] = zbin ? zbin[i] : 0, dsc->round[i] = round[i], dsc->quant[i] = quant[i];
+        dsc->quant_shift[i] = quant_shift ? quant_shift[i] : 0, dsc->dequant[i] = dequant[i];
+    }
+    dsc->quant_mode = (uint8_t)mode, dsc->log_scale = (uint8_t)log_scale;
+    hipStream_t st = resolve_stream(nullptr);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.d, a.h, upload, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(quantize_kernel, dim3(1), dim3(256), 0, st, a.d, (const SvtHipTxfmDesc *)a.d, (SvtHipTxfmResult *)(a.d + 256),
+                       (uint32_t)n);
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.h + 256, a.d + 256, sizeof(SvtHipTxfmResult), hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.h + dsc->qcoeff_off, a.d + dsc->qcoeff_off, a.used - dsc->qcoeff_off, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    memcpy(qcoeff, a.h + dsc->qcoeff_off, cb);
+    memcpy(dqcoeff, a.h + dsc->dqcoeff_off, cb);
+    *eob = ((const SvtHipTxfmResult *)(a.h + 256))->eob;
+}
+
+uint64_t handle_tier_a(int w, int h, int energy_on, int32_t *output) {
+    if (txfm_ready() != SVT_HIP_OK)
+        fatal("handle_transform");
+    const size_t bytes = (size_t)w * h * 4;
+    Arena        a(1024 + up256(bytes + 16));
+    const size_t off = a.put(output, bytes);
+    hipStream_t  st  = resolve_stream(nullptr);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.d + off, a.h + off, bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(handle64_kernel, dim3(1), dim3(256), 0, st, (int32_t *)(a.d + off), w, h, energy_on, (uint64_t *)(a.d + 256));
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    const int    iw = w < 32 ? w : 32, ih = h < 32 ? h : 32;
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.h + 256, a.d + 256, 8, hipMemcpyDeviceToHost, st));
+    if (w == 64)
+        SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.h + off, a.d + off, (size_t)iw * ih * 4, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    if (w == 64)  // rows 1..ih-1 were repacked; everything beyond the packed area is left as the C function leaves it
+        for (int r = 1; r < ih; r++) memmove(output + r * 32, a.h + off + (size_t)r * 32 * 4, 32 * 4);
+    return *(const uint64_t *)(a.h + 256);
+}
+
+}  // namespace
+
+#define FWD_DEF(W, H)                                                                                                          \
+    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { fwd_tier_a(W, H, 0, i, o, s, t, b); } \
+    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { fwd_tier_a(W, H, 1, i, o, s, t, b); } \
+    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { fwd_tier_a(W, H, 2, i, o, s, t, b); }
+FWD_DEF(4, 4) FWD_DEF(8, 8) FWD_DEF(16, 16) FWD_DEF(32, 32) FWD_DEF(64, 64) FWD_DEF(4, 8) FWD_DEF(8, 4) FWD_DEF(8, 16) FWD_DEF(16, 8)
+FWD_DEF(16, 32) FWD_DEF(32, 16) FWD_DEF(32, 64) FWD_DEF(64, 32) FWD_DEF(4, 16) FWD_DEF(16, 4) FWD_DEF(8, 32) FWD_DEF(32, 8)
+FWD_DEF(16, 64) FWD_DEF(64, 16)
+
+#define INV_SQ(W, H)                                                                                                         \
+    extern "C" void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *i, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, \
+                                                           int32_t t, int32_t bd) { inv_tier_a(W, H, i, r, sr, w, sw, t, bd); }
+#define INV_TS(W, H)                                                                                                         \
+    extern "C" void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *i, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, \
+                                                           int32_t t, int32_t, int32_t bd) { inv_tier_a(W, H, i, r, sr, w, sw, t, bd); }
+#define INV_EOB(W, H)                                                                                                        \
+    extern "C" void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *i, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, \
+                                                           int32_t t, int32_t, int32_t, int32_t bd) { inv_tier_a(W, H, i, r, sr, w, sw, t, bd); }
+INV_SQ(4, 4) INV_SQ(8, 8) INV_SQ(16, 16) INV_SQ(32, 32) INV_SQ(64, 64) INV_TS(4, 8) INV_TS(8, 4) INV_TS(4, 16) INV_TS(16, 4)
+INV_EOB(8, 16) INV_EOB(16, 8) INV_EOB(16, 32) INV_EOB(32, 16) INV_EOB(32, 64) INV_EOB(64, 32) INV_EOB(8, 32) INV_EOB(32, 8)
+INV_EOB(16, 64) INV_EOB(64, 16)
+
+#define HANDLE_DEF(W, H)                                                                                                  \
+    extern "C" uint64_t svt_handle_transform##W##x##H##_hip(int32_t *o) { return handle_tier_a(W, H, 1, o); }             \
+    extern "C" uint64_t svt_handle_transform##W##x##H##_N2_N4_hip(int32_t *o) { return handle_tier_a(W, H, 0, o); }
+HANDLE_DEF(16, 64) HANDLE_DEF(32, 64) HANDLE_DEF(64, 16) HANDLE_DEF(64, 32) HANDLE_DEF(64, 64)
+
+#define QA SVT_HIP_QARGS
+#define QP_ coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan
+extern "C" void svt_aom_quantize_b_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B, QP_, qm, iqm, ls); }
+extern "C" void svt_av1_quantize_b_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B, QP_, qm, iqm, ls); }
+extern "C" void svt_aom_highbd_quantize_b_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B_HBD, QP_, qm, iqm, ls); }
+extern "C" void svt_av1_highbd_quantize_b_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B_HBD, QP_, qm, iqm, ls); }
+extern "C" void svt_av1_quantize_fp_hip(QA) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 0); }
+extern "C" void svt_av1_quantize_fp_32x32_hip(QA) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 1); }
+extern "C" void svt_av1_quantize_fp_64x64_hip(QA) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 2); }
+extern "C" void svt_av1_quantize_fp_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int16_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP, QP_, qm, iqm, ls); }
+extern "C" void svt_av1_highbd_quantize_fp_hip(QA, int16_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP_HBD, QP_, nullptr, nullptr, ls); }
+extern "C" void svt_av1_highbd_quantize_fp_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int16_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP_HBD, QP_, qm, iqm, ls); }

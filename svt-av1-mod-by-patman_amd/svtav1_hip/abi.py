@@ -144,3 +144,23 @@ def load():
                   "svt_compute_mean_square_values_8x8_hip"):
             getattr(_lib, n).restype = C.c_uint64
     return _lib
+
+
+NO_OFFSET = 0xFFFFFFFFFFFFFFFF
+QUANT_NONE, QUANT_B, QUANT_B_HBD, QUANT_FP, QUANT_FP_HBD = range(5)
+TX_FWD, TX_INV, TX_PIXEL16, TX_FULLCOEFF = 1, 2, 4, 8
+
+
+class TxfmDesc(C.Structure):
+    _fields_ = [("residual_off", C.c_uint64), ("coeff_off", C.c_uint64), ("qcoeff_off", C.c_uint64),
+                ("dqcoeff_off", C.c_uint64), ("pred_off", C.c_uint64), ("recon_off", C.c_uint64),
+                ("iscan_off", C.c_uint64), ("qm_off", C.c_uint64), ("iqm_off", C.c_uint64),
+                ("residual_stride", C.c_uint32), ("pred_stride", C.c_uint32), ("recon_stride", C.c_uint32),
+                ("zbin", C.c_int16 * 2), ("round", C.c_int16 * 2), ("quant", C.c_int16 * 2),
+                ("quant_shift", C.c_int16 * 2), ("dequant", C.c_int16 * 2),
+                ("tx_type", C.c_uint8), ("shape", C.c_uint8), ("bit_depth", C.c_uint8), ("quant_mode", C.c_uint8),
+                ("log_scale", C.c_uint8), ("flags", C.c_uint8), ("pad_", C.c_uint8 * 2)]
+
+
+class TxfmResult(C.Structure):
+    _fields_ = [("three_quad_energy", C.c_uint64), ("eob", C.c_uint16), ("pad_", C.c_uint16 * 3)]

@@ -1,0 +1,239 @@
+"""GPU parity: transforms + quantisers of libsvtav1_hip (through the C-ABI) against the oracle, bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import tx_cases as T
+from svtav1_hip import abi, device
+from tx_cases import P, V
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "txfm.npz")
+
+
+def hip_inverse(hip, w, h, co, pred, ps, rec, rs, tt, bd):
+    fn = getattr(hip, f"svt_av1_inv_txfm2d_add_{w}x{h}_hip")
+    if w == h:
+        fn(P(co), P(pred), ps, P(rec), rs, tt, bd)
+    elif (w, h) in ((4, 8), (8, 4), (4, 16), (16, 4)):
+        fn(P(co), P(pred), ps, P(rec), rs, tt, 0, bd)
+    else:
+        fn(P(co), P(pred), ps, P(rec), rs, tt, 0, len(co), bd)
+
+
+@pytest.mark.parametrize("w,h", T.SIZES)
+def test_tier_a_fwd_inv(hip, orc, w, h):
+    rng = np.random.default_rng(w * 100 + h)
+    for tt in range(16):
+        if not orc.orc_txfm_valid(w, h, tt):
+            continue
+        for bd in (8, 10):
+            trial = (tt + bd) % 3
+            res = T.residual(rng, w, h, bd, trial)
+            for shape, suf in ((0, ""), (1, "_N2"), (2, "_N4")):
+                o1, o2 = np.zeros(w * h, np.int32), np.full(w * h, 5, np.int32)
+                orc.orc_fwd_txfm2d(P(res), P(o1), C.c_uint32(w + 3), w, h, tt, bd, shape)
+                getattr(hip, f"svt_av1_fwd_txfm2d_{w}x{h}{suf}_hip")(P(res), P(o2), C.c_uint32(w + 3), tt, C.c_uint8(bd))
+                assert np.array_equal(o1, o2), (w, h, tt, bd, trial, shape)
+            for itrial in range(3):
+                co = T.coeffs_for_inverse(rng, orc, w, h, tt, bd, itrial)
+                pred = rng.integers(0, 1 << bd, size=(h, w + 5)).astype(np.uint16)
+                r1, r2 = np.zeros((h, w + 7), np.uint16), np.zeros((h, w + 7), np.uint16)
+                orc.orc_inv_txfm2d_add(P(co), P(pred), w + 5, P(r1), w + 7, w, h, tt, bd)
+                hip_inverse(hip, w, h, co, pred, w + 5, r2, w + 7, tt, bd)
+                assert np.array_equal(r1, r2), (w, h, tt, bd, itrial)
+    if max(w, h) == 64:
+        orc.orc_handle_transform64.restype = C.c_uint64
+        for suf, en in (("", 1), ("_N2_N4", 0)):
+            fn = getattr(hip, f"svt_handle_transform{w}x{h}{suf}_hip")
+            fn.restype = C.c_uint64
+            co = rng.integers(-100000, 100000, size=w * h).astype(np.int32)
+            c2 = co.copy()
+            e1 = orc.orc_handle_transform64(P(co), w, h) * en
+            e2 = fn(P(c2))
+            kw, kh = min(w, 32), min(h, 32)
+            assert e1 == e2 and np.array_equal(co[:kw * kh], c2[:kw * kh])
+
+
+def test_tier_a_golden(hip):
+    """HIP == committed outputs of the reference's own transform functions."""
+    import test_txfm_oracle as TT
+    gold = np.load(GOLD)
+    for i, (w, h, tt, bd, res, pred) in enumerate(TT.golden_cases()):
+        if f"fwd{i}" not in gold:
+            continue
+        co = np.zeros(w * h, np.int32)
+        getattr(hip, f"svt_av1_fwd_txfm2d_{w}x{h}_hip")(P(res), P(co), C.c_uint32(w + 3), tt, C.c_uint8(bd))
+        assert np.array_equal(co, gold[f"fwd{i}"]), (w, h, tt, bd)
+        ci = co.reshape(h, w)[:min(h, 32), :min(w, 32)].copy().reshape(-1)
+        rec = np.zeros((h, w + 7), np.uint16)
+        hip_inverse(hip, w, h, ci, pred, w + 5, rec, w + 7, tt, bd)
+        assert np.array_equal(rec, gold[f"inv{i}"]), (w, h, tt, bd)
+
+
+def test_tier_a_quantizers(hip, orc):
+    rng = np.random.default_rng(2)
+    for trial in range(120):
+        c = T.quant_case(rng, trial)
+        n, t, ls = c["n"], c["t"], c["ls"]
+        qm = P(c["qm"]) if c["qm"] is not None else None
+        iqm = P(c["iqm"]) if c["iqm"] is not None else None
+
+        def run(fn, rnd, qnt, *tail):
+            qc, dq, eob = np.full(n, 7, np.int32), np.full(n, 7, np.int32), C.c_uint16(9999)
+            fn(P(c["coeff"]), C.c_ssize_t(n), P(t["zbin"]), P(rnd), P(qnt), P(t["qshift"]), P(qc), P(dq), P(t["dequant"]),
+               C.byref(eob), P(c["scan"]), P(c["iscan"]), *tail)
+            return qc, dq, eob.value
+        pairs = [(run(hip.svt_aom_quantize_b_hip, t["round"], t["quant"], qm, iqm, C.c_int32(ls)), T.orc_quant(orc, 1, c)),
+                 (run(hip.svt_av1_quantize_b_qm_hip, t["round"], t["quant"], qm, iqm, C.c_int32(ls)), T.orc_quant(orc, 1, c)),
+                 (run(hip.svt_aom_highbd_quantize_b_hip, t["round"], t["quant"], qm, iqm, C.c_int32(ls)), T.orc_quant(orc, 2, c)),
+                 (run(hip.svt_av1_highbd_quantize_b_qm_hip, t["round"], t["quant"], qm, iqm, C.c_int32(ls)), T.orc_quant(orc, 2, c)),
+                 (run(hip.svt_av1_quantize_fp_qm_hip, t["round_fp"], t["quant_fp"], qm, iqm, C.c_int16(ls)), T.orc_quant(orc, 3, c)),
+                 (run(hip.svt_av1_highbd_quantize_fp_qm_hip, t["round_fp"], t["quant_fp"], qm, iqm, C.c_int16(ls)), T.orc_quant(orc, 4, c))]
+        if c["qm"] is None:
+            f = (hip.svt_av1_quantize_fp_hip, hip.svt_av1_quantize_fp_32x32_hip, hip.svt_av1_quantize_fp_64x64_hip)[ls]
+            pairs += [(run(f, t["round_fp"], t["quant_fp"]), T.orc_quant(orc, 3, c)),
+                      (run(hip.svt_av1_highbd_quantize_fp_hip, t["round_fp"], t["quant_fp"], C.c_int16(ls)), T.orc_quant(orc, 4, c))]
+        for k, (a, b) in enumerate(pairs):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (trial, k)
+
+
+class ArenaBuilder:
+    def __init__(self):
+        self.chunks, self.size = [], 0
+
+    def add(self, arr=None, nbytes=None):
+        off = self.size
+        nbytes = arr.nbytes if arr is not None else nbytes
+        self.chunks.append((off, None if arr is None else np.ascontiguousarray(arr).view(np.uint8).reshape(-1)))
+        self.size += (nbytes + 255) // 256 * 256 + 256
+        return off
+
+    def build(self):
+        buf = np.zeros(self.size, np.uint8)
+        for off, a in self.chunks:
+            if a is not None:
+                buf[off:off + a.size] = a
+        return buf
+
+
+@pytest.mark.parametrize("w,h", T.SIZES)
+def test_tier_b_fused_batch(hip, orc, w, h):
+    """residual -> fwd -> [energy/repack] -> quantise -> inverse -> recon for hundreds of blocks in one launch,
+    every stage compared with the oracle pipeline."""
+    rng = np.random.default_rng(1000 + w * 100 + h)
+    n_tb = 300 if w * h <= 1024 else 60
+    iw, ih = min(w, 32), min(h, 32)
+    n = iw * ih
+    ls = 2 if max(w, h) == 64 and (w * h) > 1024 else (1 if w * h > 256 and max(w, h) >= 32 and min(w, h) >= 16 else 0)
+    types = [tt for tt in range(16) if orc.orc_txfm_valid(w, h, tt)]
+    scan = rng.permutation(n).astype(np.int16)
+    iscan = np.empty(n, np.int16)
+    iscan[scan] = np.arange(n)
+    ab = ArenaBuilder()
+    iscan_off = ab.add(iscan)
+    descs, expect = [], []
+    for i in range(n_tb):
+        bd = 8 if i % 3 == 0 else 10
+        pix16 = bd == 10 or i % 2 == 0
+        tt = types[i % len(types)]
+        shape = (0, 0, 1, 2)[i % 4]
+        mode = 1 + (i % 4)
+        tq = T.quant_tables(rng, bd)
+        res = T.residual(rng, w, h, bd, 0, pad=5) // (1 + (i % 5))
+        res = res.astype(np.int16)
+        pred16 = rng.integers(0, 1 << bd, size=(h, w + 2)).astype(np.uint16)
+        d = abi.TxfmDesc()
+        d.residual_off, d.residual_stride = ab.add(res), w + 5
+        d.coeff_off = ab.add(nbytes=n * 4) if i % 2 else abi.NO_OFFSET
+        d.qcoeff_off, d.dqcoeff_off = ab.add(nbytes=n * 4), ab.add(nbytes=n * 4)
+        d.pred_off = ab.add(pred16 if pix16 else pred16.astype(np.uint8))
+        d.recon_off = ab.add(nbytes=h * (w + 4) * (2 if pix16 else 1))
+        d.pred_stride, d.recon_stride = w + 2, w + 4
+        d.iscan_off, d.qm_off, d.iqm_off = iscan_off, abi.NO_OFFSET, abi.NO_OFFSET
+        rnd, qnt = (tq["round"], tq["quant"]) if mode <= 2 else (tq["round_fp"], tq["quant_fp"])
+        for k in range(2):
+            d.zbin[k], d.round[k], d.quant[k] = int(tq["zbin"][k]), int(rnd[k]), int(qnt[k])
+            d.quant_shift[k], d.dequant[k] = int(tq["qshift"][k]), int(tq["dequant"][k])
+        d.tx_type, d.shape, d.bit_depth, d.quant_mode, d.log_scale = tt, shape, bd, mode, ls
+        d.flags = abi.TX_FWD | abi.TX_INV | (abi.TX_PIXEL16 if pix16 else 0)
+        descs.append(d)
+        # oracle pipeline
+        co = np.zeros(w * h, np.int32)
+        orc.orc_fwd_txfm2d(P(res), P(co), C.c_uint32(w + 5), w, h, tt, bd, shape)
+        energy = 0
+        if max(w, h) == 64:
+            orc.orc_handle_transform64.restype = C.c_uint64
+            energy = orc.orc_handle_transform64(P(co), w, h)
+        co = co[:n].copy()
+        qc, dq, eob = T.orc_quant(orc, mode, dict(n=n, ls=ls, coeff=co, scan=scan, iscan=iscan, qm=None, iqm=None, t=tq))
+        rec = np.zeros((h, w + 4), np.uint16)
+        orc.orc_inv_txfm2d_add(P(dq), P(pred16), w + 2, P(rec), w + 4, w, h, tt, bd)
+        expect.append((co, qc, dq, eob, energy, rec if pix16 else rec.astype(np.uint8), pix16, d))
+    arena = ab.build()
+    darena = device.DeviceBuffer(hip, arena.nbytes + 256)
+    darena.upload(arena)
+    darr = (abi.TxfmDesc * n_tb)(*descs)
+    ddesc = device.DeviceBuffer(hip, C.sizeof(darr))
+    ddesc.upload(np.frombuffer(darr, dtype=np.uint8))
+    dres = device.DeviceBuffer(hip, 16 * n_tb)
+    device.check(hip, hip.svt_hip_txfm_quant_batch(V(darena.ptr), V(ddesc.ptr), V(dres.ptr), C.c_uint32(n_tb), C.c_uint32(w),
+                                                   C.c_uint32(h), None), "svt_hip_txfm_quant_batch")
+    out = darena.download(np.uint8, (arena.nbytes,))
+    res_raw = dres.download(np.uint8, (n_tb, 16))
+    for i, (co, qc, dq, eob, energy, rec, pix16, d) in enumerate(expect):
+        g = lambda off, cnt, dt: out[off:off + cnt * np.dtype(dt).itemsize].view(dt)
+        if d.coeff_off != abi.NO_OFFSET:
+            assert np.array_equal(g(d.coeff_off, n, np.int32), co), ("coeff", i)
+        assert np.array_equal(g(d.qcoeff_off, n, np.int32), qc), ("qcoeff", i)
+        assert np.array_equal(g(d.dqcoeff_off, n, np.int32), dq), ("dqcoeff", i)
+        assert int(res_raw[i, 8:10].view(np.uint16)[0]) == eob, ("eob", i)
+        assert int(res_raw[i, :8].view(np.uint64)[0]) == energy, ("energy", i)
+        got = g(d.recon_off, h * (w + 4), np.uint16 if pix16 else np.uint8).reshape(h, w + 4)
+        assert np.array_equal(got[:, :w], rec[:, :w]), ("recon", i)
+
+
+def test_quantize_batch(hip, orc):
+    rng = np.random.default_rng(77)
+    n, n_tb = 1024, 40
+    ab = ArenaBuilder()
+    descs, expect = [], []
+    for i in range(n_tb):
+        c = T.quant_case(rng, i)
+        c["n"] = n
+        c["coeff"] = rng.integers(-3000, 3000, size=n).astype(np.int32)
+        c["scan"] = rng.permutation(n).astype(np.int16)
+        c["iscan"] = np.empty(n, np.int16)
+        c["iscan"][c["scan"]] = np.arange(n)
+        c["qm"] = c["iqm"] = None
+        mode = 1 + i % 4
+        t = c["t"]
+        d = abi.TxfmDesc()
+        d.coeff_off, d.iscan_off = ab.add(c["coeff"]), ab.add(c["iscan"])
+        d.qcoeff_off, d.dqcoeff_off = ab.add(nbytes=n * 4), ab.add(nbytes=n * 4)
+        d.qm_off = d.iqm_off = abi.NO_OFFSET
+        rnd, qnt = (t["round"], t["quant"]) if mode <= 2 else (t["round_fp"], t["quant_fp"])
+        for k in range(2):
+            d.zbin[k], d.round[k], d.quant[k] = int(t["zbin"][k]), int(rnd[k]), int(qnt[k])
+            d.quant_shift[k], d.dequant[k] = int(t["qshift"][k]), int(t["dequant"][k])
+        d.quant_mode, d.log_scale = mode, c["ls"]
+        descs.append(d)
+        expect.append(T.orc_quant(orc, mode, c))
+    arena = ab.build()
+    darena = device.DeviceBuffer(hip, arena.nbytes + 256)
+    darena.upload(arena)
+    darr = (abi.TxfmDesc * n_tb)(*descs)
+    ddesc = device.DeviceBuffer(hip, C.sizeof(darr))
+    ddesc.upload(np.frombuffer(darr, dtype=np.uint8))
+    dres = device.DeviceBuffer(hip, 16 * n_tb)
+    device.check(hip, hip.svt_hip_quantize_batch(V(darena.ptr), V(ddesc.ptr), V(dres.ptr), C.c_uint32(n_tb), C.c_uint32(n), None),
+                 "svt_hip_quantize_batch")
+    out = darena.download(np.uint8, (arena.nbytes,))
+    res_raw = dres.download(np.uint8, (n_tb, 16))
+    for i, (qc, dq, eob) in enumerate(expect):
+        d = descs[i]
+        assert np.array_equal(out[d.qcoeff_off:d.qcoeff_off + 4 * n].view(np.int32), qc)
+        assert np.array_equal(out[d.dqcoeff_off:d.dqcoeff_off + 4 * n].view(np.int32), dq)
+        assert int(res_raw[i, 8:10].view(np.uint16)[0]) == eob
