@@ -1,0 +1,88 @@
+/*
+ * svt_hip_lf.h — C-ABI for the in-loop filters: CDEF, deblocking, self-guided restoration
+ * (SURVEY.md §8 rows a9–a11).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   Source/Lib/Codec/common_dsp_rtcd.c:796-804   svt_aom_cdef_find_dir, svt_aom_cdef_find_dir_dual,
+ *                                                svt_cdef_filter_block, svt_aom_copy_rect8_8bit_to_16bit
+ *   Source/Lib/Codec/aom_dsp_rtcd.c:207-208      svt_compute_cdef_dist_16bit, svt_compute_cdef_dist_8bit
+ *   Source/Lib/Codec/cdef_process.c:106-349      cdef_seg_search            (Tier B: svt_hip_cdef_search_plane)
+ *   Source/Lib/Codec/enc_cdef.c:284-610          svt_av1_cdef_frame         (Tier B: svt_hip_cdef_apply_plane)
+ */
+#ifndef SVT_HIP_LF_H
+#define SVT_HIP_LF_H
+
+#include "svt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVT_HIP_CDEF_BSTRIDE 144      /* CDEF_BSTRIDE, cdef.h:35 */
+#define SVT_HIP_CDEF_VERY_LARGE 0x7F7F /* CDEF_VERY_LARGE, cdef.h:38 */
+
+typedef struct SvtHipCdefList { /* CdefList, definitions.h:255-259 */
+    uint8_t by, bx;
+} SvtHipCdefList;
+
+/* ---------------------------------------------------------------------------------------------
+ * Tier A (host pointers, RTCD signatures; BlockSize values: BLOCK_4X4=0, 4X8=1, 8X4=2, 8X8=3)
+ * ------------------------------------------------------------------------------------------- */
+SVT_HIP_API uint8_t svt_aom_cdef_find_dir_hip(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift);
+SVT_HIP_API void    svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1,
+                                                   int32_t *var2, int32_t coeff_shift, uint8_t *out1, uint8_t *out2);
+SVT_HIP_API void    svt_cdef_filter_block_hip(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in,
+                                              int32_t pri_strength, int32_t sec_strength, int32_t dir, int32_t pri_damping,
+                                              int32_t sec_damping, int32_t bsize, int32_t coeff_shift,
+                                              uint8_t subsampling_factor);
+SVT_HIP_API void    svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride,
+                                                         int32_t v, int32_t h);
+SVT_HIP_API uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t dstride, const uint16_t *src,
+                                                     const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize,
+                                                     int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
+SVT_HIP_API uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8,
+                                                    const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize,
+                                                    int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tier B — one picture plane per call, device pointers.
+ *   recon / source : top-left sample of the picture area (no padding needed; samples outside the
+ *                    8-aligned picture are CDEF_VERY_LARGE as in the reference)
+ *   filt8x8        : uint8 [ceil(h8)][ceil(w8)] in units of 8x8 LUMA blocks, non-zero = block is filtered
+ *                    (what svt_sb_compute_cdef_list derives from the skip flags, enc_cdef.c:238-276)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct SvtHipCdefPlane {
+    void    *recon;       /* uint8 or uint16 samples */
+    void    *source;      /* search: the original picture; apply: the OUTPUT plane (must not alias recon) */
+    uint32_t recon_stride, source_stride; /* in samples */
+    uint32_t width, height;               /* plane size in samples (luma: 8-aligned picture size; chroma: half) */
+    uint8_t  is_16bit, xdec, ydec, pli;   /* pli: 0 luma, 1/2 chroma; xdec == ydec (4:2:0 or 4:4:4) — the reference
+                                           * encoder accepts 4:2:0 only (enc_settings.c:447); others: BAD_PARAMETER */
+} SvtHipCdefPlane;
+
+#define SVT_HIP_CDEF_MAX_STRENGTHS 64
+typedef struct SvtHipCdefSearchParams {
+    int32_t n_strengths;
+    int8_t  strengths[SVT_HIP_CDEF_MAX_STRENGTHS]; /* pri*4+sec as in default_first/second_pass_fs; -1 = not tested */
+    int32_t pri_damping, sec_damping;              /* 3 + (base_q_idx >> 6), cdef_process.c:139-140 */
+    int32_t coeff_shift;                           /* bit_depth - 8 */
+    int32_t subsampling_factor;                    /* cdef_ctrls->subsampling_factor (capped per block size inside) */
+} SvtHipCdefSearchParams;
+
+/* mse[fb][gi] (uint64, fb raster over 64x64 filter blocks) = curr_mse * subsampling_factor of
+ * cdef_process.c:283-286 for this plane; dir / var: [fb][8][8] luma direction / variance (uint8 / int32),
+ * written when pli == 0 and read when pli != 0 (run the luma plane first). */
+SVT_HIP_API int32_t svt_hip_cdef_search_plane(const SvtHipCdefPlane *plane, const uint8_t *d_filt8x8,
+                                              const SvtHipCdefSearchParams *prm, uint64_t *d_mse, uint8_t *d_dir,
+                                              int32_t *d_var, void *stream);
+
+/* Apply: strength per filter block (uint8 [n_fb], pri*4+sec with sec already in {0,1,2,3}->{0,1,2,4} mapping
+ * applied inside); blocks that are not filtered are copied through. */
+SVT_HIP_API int32_t svt_hip_cdef_apply_plane(const SvtHipCdefPlane *plane, const uint8_t *d_filt8x8,
+                                             const uint8_t *d_fb_strength, int32_t damping, int32_t coeff_shift,
+                                             const uint8_t *d_dir, const int32_t *d_var, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_LF_H */

@@ -1,0 +1,27 @@
+/* oracle/src/orc_lf.h — TEST INFRASTRUCTURE (CPU restatement of the in-loop filter part of the hot path). */
+#ifndef ORC_LF_H
+#define ORC_LF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/svt_hip_lf.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define ORC_API __attribute__((visibility("default")))
+
+ORC_API uint8_t  orc_cdef_find_dir(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift);
+ORC_API void     orc_cdef_filter_block(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength,
+                                       int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize,
+                                       int32_t coeff_shift, uint8_t subsampling_factor);
+ORC_API uint64_t orc_compute_cdef_dist(const void *dst, int32_t dstride, const void *src, const SvtHipCdefList *dlist,
+                                       int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli,
+                                       uint8_t subsampling_factor, int is16);
+ORC_API void     orc_cdef_search_plane(const SvtHipCdefPlane *pl, const uint8_t *filt8x8, const SvtHipCdefSearchParams *prm,
+                                       uint64_t *mse, uint8_t *dir, int32_t *var);
+ORC_API void     orc_cdef_apply_plane(const SvtHipCdefPlane *pl, const uint8_t *filt8x8, const uint8_t *fb_strength, int damping,
+                                      int coeff_shift, const uint8_t *dir, const int32_t *var);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,494 @@
+// loopfilter_cdef.hip — CDEF on gfx950: per-64x64 filter-block strength search and frame apply,
+// plus the ABI-identical per-call entry points.  Replaces cdef_seg_search (cdef_process.c:106-349),
+// svt_av1_cdef_frame (enc_cdef.c:284-610) and their leaves (cdef.c:150-307, enc_cdef.c:23-219).
+//
+// One workgroup owns one filter block of one plane: the (64+16) x (64+6) input tile is staged once in LDS as
+// uint16 with CDEF_VERY_LARGE outside the picture, direction/variance of the 8x8 blocks are found once, and all
+// strength candidates are evaluated from that tile — filtered samples never go to memory during the search, only
+// the per-block distortion sums do (LDS atomics), so the search reads each picture sample exactly once from HBM.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/svt_hip_lf.h"
+#include "common.hpp"
+
+using namespace svthip;
+
+namespace {
+
+constexpr int BS = SVT_HIP_CDEF_BSTRIDE, VL = SVT_HIP_CDEF_VERY_LARGE, VB = 3, HB = 8;
+constexpr int TILE_ROWS = 64 + 2 * VB;
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int msb(unsigned n) { return 31 - __builtin_clz(n); }
+
+__device__ const int16_t DIRS_D[12][2] = {{1 * BS + 0, 2 * BS + 0},  {1 * BS + 0, 2 * BS - 1}, {-1 * BS + 1, -2 * BS + 2},
+                                          {0 * BS + 1, -1 * BS + 2}, {0 * BS + 1, 0 * BS + 2}, {0 * BS + 1, 1 * BS + 2},
+                                          {1 * BS + 1, 2 * BS + 2},  {1 * BS + 0, 2 * BS + 1}, {1 * BS + 0, 2 * BS + 0},
+                                          {1 * BS + 0, 2 * BS - 1},  {-1 * BS + 1, -2 * BS + 2}, {0 * BS + 1, -1 * BS + 2}};
+
+__device__ __forceinline__ int32_t constrain(int32_t diff, int32_t threshold, int32_t damping) {
+    if (!threshold)
+        return 0;
+    const int32_t shift = imax(0, damping - msb((unsigned)threshold));
+    const int32_t ad    = diff < 0 ? -diff : diff;
+    const int32_t m     = imin(ad, imax(0, threshold - (ad >> shift)));
+    return diff < 0 ? -m : m;
+}
+__device__ __forceinline__ int adjust_strength(int strength, int var) {
+    const int i = (var >> 6) ? imin(msb((unsigned)(var >> 6)), 12) : 0;
+    return var ? (strength * (4 + i) + 8) >> 4 : 0;
+}
+
+// One output sample of svt_cdef_filter_block_c (cdef.c:253-307); `p` points at the sample inside a stride-144 tile.
+__device__ __forceinline__ int32_t cdef_pixel(const uint16_t *p, int pri_strength, int sec_strength, int dir, int pri_damping,
+                                              int sec_damping, int coeff_shift) {
+    const int     tsel = (pri_strength >> coeff_shift) & 1;
+    const int32_t pt0 = tsel ? 3 : 4, pt1 = tsel ? 3 : 2;
+    const int16_t x   = (int16_t)p[0];
+    int16_t       sum = 0;
+    int32_t       mx = x, mn = x;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int32_t pt = k ? pt1 : pt0, st = k ? 1 : 2;
+        const int     o0 = DIRS_D[dir + 2][k], o1 = DIRS_D[dir + 4][k], o2 = DIRS_D[dir][k];
+        const int16_t p0 = (int16_t)p[o0], p1 = (int16_t)p[-o0];
+        sum = (int16_t)(sum + (int16_t)(pt * constrain(p0 - x, pri_strength, pri_damping)));
+        sum = (int16_t)(sum + (int16_t)(pt * constrain(p1 - x, pri_strength, pri_damping)));
+        if (p0 != VL) mx = imax(p0, mx);
+        if (p1 != VL) mx = imax(p1, mx);
+        mn = imin(p0, mn), mn = imin(p1, mn);
+        const int16_t s0 = (int16_t)p[o1], s1 = (int16_t)p[-o1], s2 = (int16_t)p[o2], s3 = (int16_t)p[-o2];
+        if (s0 != VL) mx = imax(s0, mx);
+        if (s1 != VL) mx = imax(s1, mx);
+        if (s2 != VL) mx = imax(s2, mx);
+        if (s3 != VL) mx = imax(s3, mx);
+        mn = imin(s0, mn), mn = imin(s1, mn), mn = imin(s2, mn), mn = imin(s3, mn);
+        sum = (int16_t)(sum + (int16_t)(st * constrain(s0 - x, sec_strength, sec_damping)));
+        sum = (int16_t)(sum + (int16_t)(st * constrain(s1 - x, sec_strength, sec_damping)));
+        sum = (int16_t)(sum + (int16_t)(st * constrain(s2 - x, sec_strength, sec_damping)));
+        sum = (int16_t)(sum + (int16_t)(st * constrain(s3 - x, sec_strength, sec_damping)));
+    }
+    int32_t y = (int32_t)x + ((8 + sum - (sum < 0)) >> 4);
+    return y < mn ? mn : (y > mx ? mx : y);
+}
+
+// svt_aom_cdef_find_dir_c (cdef.c:150-210) for one 8x8 block, one thread.
+__device__ int find_dir_block(const uint16_t *img, int stride, int32_t *var, int coeff_shift) {
+    const int32_t div_table[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
+    int32_t       cost[8], partial[8][15];
+    for (int a = 0; a < 8; a++) {
+        cost[a] = 0;
+        for (int b = 0; b < 15; b++) partial[a][b] = 0;
+    }
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) {
+            const int32_t x = (img[i * stride + j] >> coeff_shift) - 128;
+            partial[0][i + j] += x;
+            partial[1][i + j / 2] += x;
+            partial[2][i] += x;
+            partial[3][3 + i - j / 2] += x;
+            partial[4][7 + i - j] += x;
+            partial[5][3 - i / 2 + j] += x;
+            partial[6][j] += x;
+            partial[7][i / 2 + j] += x;
+        }
+    for (int i = 0; i < 8; i++) {
+        cost[2] += partial[2][i] * partial[2][i];
+        cost[6] += partial[6][i] * partial[6][i];
+    }
+    cost[2] *= div_table[8];
+    cost[6] *= div_table[8];
+    for (int i = 0; i < 7; i++) {
+        cost[0] += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * div_table[i + 1];
+        cost[4] += (partial[4][i] * partial[4][i] + partial[4][14 - i] * partial[4][14 - i]) * div_table[i + 1];
+    }
+    cost[0] += partial[0][7] * partial[0][7] * div_table[8];
+    cost[4] += partial[4][7] * partial[4][7] * div_table[8];
+    for (int i = 1; i < 8; i += 2) {
+        for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j] * partial[i][3 + j];
+        cost[i] *= div_table[8];
+        for (int j = 0; j < 3; j++)
+            cost[i] += (partial[i][j] * partial[i][j] + partial[i][10 - j] * partial[i][10 - j]) * div_table[2 * j + 2];
+    }
+    int32_t best = 0;
+    int     dir  = 0;
+    for (int i = 0; i < 8; i++)
+        if (cost[i] > best)
+            best = cost[i], dir = i;
+    *var = (best - cost[(dir + 4) & 7]) >> 10;
+    return dir;
+}
+
+// enc_cdef.c:23-48: the luma distortion of one 8xN block from its five sums (IEEE double, no contraction).
+__device__ __forceinline__ uint64_t dist_8xn(uint64_t ss, uint64_t sd, uint64_t ss2, uint64_t sd2, uint64_t ssd, int coeff_shift) {
+    const uint64_t svar = ss2 - ((ss * ss + 32) >> 6);
+    const uint64_t dvar = sd2 - ((sd * sd + 32) >> 6);
+    const double   num  = (double)(sd2 + ss2 - 2 * ssd) * .5 * (double)(svar + dvar + (uint64_t)(400 << 2 * coeff_shift));
+    const double   den  = sqrt((double)(20000 << 4 * coeff_shift) + (double)svar * (double)dvar);
+    return (uint64_t)floor(.5 + num / den);
+}
+
+__device__ __forceinline__ uint32_t load_px(const void *p, size_t idx, int is16) {
+    return is16 ? ((const uint16_t *)p)[idx] : ((const uint8_t *)p)[idx];
+}
+
+struct FbLds {
+    uint16_t       tile[TILE_ROWS * BS];
+    SvtHipCdefList dl[64];
+    uint8_t        dir[64];
+    int32_t        var[64];
+    uint32_t       sums[64][5];
+    unsigned long long total;
+    int            n;
+};
+
+// stage tile + dlist; returns cdef_count (uniform).  Contains barriers.
+__device__ int stage_fb(FbLds &S, const SvtHipCdefPlane &pl, const uint8_t *filt, int fbx, int fby) {
+    const int lw = (int)pl.width << pl.xdec, lh = (int)pl.height << pl.ydec;
+    const int w8 = (lw + 7) / 8, h8 = (lh + 7) / 8;
+    const int bw = 64 >> pl.xdec, bh = 64 >> pl.ydec;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int r = 0; r < 8 && fby * 8 + r < h8; r++)
+            for (int c = 0; c < 8 && fbx * 8 + c < w8; c++)
+                if (filt[(size_t)(fby * 8 + r) * w8 + fbx * 8 + c])
+                    S.dl[n].by = (uint8_t)r, S.dl[n].bx = (uint8_t)c, n++;
+        S.n = n;
+    }
+    for (int idx = threadIdx.x; idx < (bh + 2 * VB) * (bw + 2 * HB); idx += blockDim.x) {
+        const int ry = idx / (bw + 2 * HB), rx = idx - ry * (bw + 2 * HB);
+        const int py = fby * bh + ry - VB, px = fbx * bw + rx - HB;
+        uint16_t  v  = VL;
+        if (py >= 0 && px >= 0 && py < (int)pl.height && px < (int)pl.width)
+            v = (uint16_t)load_px(pl.recon, (size_t)py * pl.recon_stride + px, pl.is_16bit);
+        S.tile[ry * BS + rx] = v;
+    }
+    __syncthreads();
+    return S.n;
+}
+
+__global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, const uint8_t *__restrict__ filt,
+                                                          SvtHipCdefSearchParams prm, uint64_t *__restrict__ mse,
+                                                          uint8_t *__restrict__ gdir, int32_t *__restrict__ gvar, int nhfb) {
+    __shared__ FbLds S;
+    const int fb = blockIdx.x, fbx = fb % nhfb, fby = fb / nhfb;
+    const int n  = stage_fb(S, pl, filt, fbx, fby);
+    if (n == 0)
+        return;
+    const uint16_t *in = S.tile + VB * BS + HB;
+    const int       bwl = 3 - pl.xdec, bhl = 3 - pl.ydec, bw = 1 << bwl, bh = 1 << bhl;
+    const int       bsize = pl.ydec ? (pl.xdec ? 0 : 2) : (pl.xdec ? 1 : 3);
+    int             sub   = prm.subsampling_factor;
+    sub                   = bsize == 3 ? imin(sub, 4) : (bsize == 0 ? imin(sub, 1) : imin(sub, 2));
+    // direction / variance per 8x8 block
+    if ((int)threadIdx.x < n) {
+        const int by = S.dl[threadIdx.x].by, bx = S.dl[threadIdx.x].bx;
+        if (pl.pli == 0) {
+            int32_t   v;
+            const int d = find_dir_block(in + 8 * by * BS + 8 * bx, BS, &v, prm.coeff_shift);
+            S.dir[by * 8 + bx] = (uint8_t)d, S.var[by * 8 + bx] = v;
+            gdir[(size_t)fb * 64 + by * 8 + bx] = (uint8_t)d, gvar[(size_t)fb * 64 + by * 8 + bx] = v;
+        } else {
+            S.dir[by * 8 + bx] = gdir[(size_t)fb * 64 + by * 8 + bx];
+            S.var[by * 8 + bx] = gvar[(size_t)fb * 64 + by * 8 + bx];
+        }
+    }
+    __syncthreads();
+    const size_t soff  = (size_t)(fby * (64 >> pl.ydec)) * pl.source_stride + fbx * (64 >> pl.xdec);
+    const int    rows  = bh / sub;  // filtered rows per block
+    const int    items = n * rows * bw;
+    for (int gi = 0; gi < prm.n_strengths; gi++) {
+        if (prm.strengths[gi] < 0)
+            continue;
+        int pri = prm.strengths[gi] / 4, sec = prm.strengths[gi] % 4;
+        sec += sec == 3;
+        const int pri_s = pri << prm.coeff_shift, sec_s = sec << prm.coeff_shift;
+        const int pd = prm.pri_damping + prm.coeff_shift - (pl.pli != 0), sd = prm.sec_damping + prm.coeff_shift - (pl.pli != 0);
+        for (int i = threadIdx.x; i < 64 * 5; i += blockDim.x) (&S.sums[0][0])[i] = 0;
+        if (threadIdx.x == 0)
+            S.total = 0;
+        __syncthreads();
+        unsigned long long acc = 0;
+        for (int it = threadIdx.x; it < items; it += blockDim.x) {
+            const int bi = it / (rows * bw), rem = it - bi * rows * bw;
+            const int i = (rem / bw) * sub, j = rem - (rem / bw) * bw;
+            const int by = S.dl[bi].by, bx = S.dl[bi].bx;
+            const uint16_t *p = in + ((by << bhl) + i) * BS + (bx << bwl) + j;
+            int32_t         y;
+            if (pri_s == 0 && sec_s == 0) {
+                y = pl.is_16bit ? p[0] : (uint8_t)p[0];
+            } else {
+                const int t = pl.pli ? pri_s : adjust_strength(pri_s, S.var[by * 8 + bx]);
+                y           = cdef_pixel(p, t, sec_s, pri_s ? S.dir[by * 8 + bx] : 0, pd, sd, prm.coeff_shift);
+                y           = pl.is_16bit ? (uint16_t)(int16_t)y : (uint8_t)(int16_t)y;
+            }
+            const int32_t o = (int32_t)load_px(pl.source, soff + (size_t)((by << bhl) + i) * pl.source_stride + (bx << bwl) + j, pl.is_16bit);
+            if (bsize == 3 && pl.pli == 0) {
+                atomicAdd(&S.sums[bi][0], (uint32_t)y);
+                atomicAdd(&S.sums[bi][1], (uint32_t)o);
+                atomicAdd(&S.sums[bi][2], (uint32_t)(y * y));
+                atomicAdd(&S.sums[bi][3], (uint32_t)(o * o));
+                atomicAdd(&S.sums[bi][4], (uint32_t)(y * o));
+            } else {
+                const int32_t e = o - y;
+                acc += (unsigned long long)(int64_t)(e * e);
+            }
+        }
+        __syncthreads();
+        if (bsize == 3 && pl.pli == 0 && (int)threadIdx.x < n) {
+            const uint32_t *s = S.sums[threadIdx.x];
+            acc = dist_8xn(s[0], s[1], s[2], s[3], s[4], prm.coeff_shift);  // src = filtered (packed), dst = source picture
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd(&S.total, acc);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            mse[(size_t)fb * prm.n_strengths + gi] = ((uint64_t)S.total >> 2 * prm.coeff_shift) * (uint64_t)sub;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void cdef_apply_kernel(SvtHipCdefPlane pl, const uint8_t *__restrict__ filt,
+                                                         const uint8_t *__restrict__ fb_strength, int damping, int coeff_shift,
+                                                         const uint8_t *__restrict__ gdir, const int32_t *__restrict__ gvar, int nhfb) {
+    __shared__ FbLds S;
+    __shared__ uint8_t on[64];
+    const int fb = blockIdx.x, fbx = fb % nhfb, fby = fb / nhfb;
+    const int n  = stage_fb(S, pl, filt, fbx, fby);
+    int       pri = fb_strength[fb] / 4, sec = fb_strength[fb] % 4;
+    sec += sec == 3;
+    const bool active = (pri || sec) && n > 0;
+    if (threadIdx.x < 64)
+        on[threadIdx.x] = 0;
+    __syncthreads();
+    if (active && (int)threadIdx.x < n)
+        on[S.dl[threadIdx.x].by * 8 + S.dl[threadIdx.x].bx] = 1;
+    __syncthreads();
+    const uint16_t *in = S.tile + VB * BS + HB;
+    const int       bwl = 3 - pl.xdec, bhl = 3 - pl.ydec;
+    const int       fw = 64 >> pl.xdec, fh = 64 >> pl.ydec;
+    const int       pri_s = pri << coeff_shift, sec_s = sec << coeff_shift, dmp = damping + coeff_shift - (pl.pli != 0);
+    for (int idx = threadIdx.x; idx < fw * fh; idx += blockDim.x) {
+        const int y = idx / fw, x = idx - y * fw;
+        const int py = fby * fh + y, px = fbx * fw + x;
+        if (py >= (int)pl.height || px >= (int)pl.width)
+            continue;
+        const int by = y >> bhl, bx = x >> bwl;
+        int32_t   v  = in[y * BS + x];
+        if (on[by * 8 + bx]) {
+            const int t = pl.pli ? pri_s : adjust_strength(pri_s, gvar[(size_t)fb * 64 + by * 8 + bx]);
+            v           = cdef_pixel(in + y * BS + x, t, sec_s, pri_s ? gdir[(size_t)fb * 64 + by * 8 + bx] : 0, dmp, dmp, coeff_shift);
+        }
+        if (pl.is_16bit)
+            ((uint16_t *)pl.source)[(size_t)py * pl.source_stride + px] = (uint16_t)(int16_t)v;
+        else
+            ((uint8_t *)pl.source)[(size_t)py * pl.source_stride + px] = (uint8_t)(int16_t)v;
+    }
+}
+
+// ---- Tier A kernels ----
+__global__ void find_dir_kernel(const uint16_t *img1, const uint16_t *img2, int stride, int coeff_shift, int32_t *out /* dir1,var1,dir2,var2 */) {
+    if (threadIdx.x < 2) {
+        const uint16_t *img = threadIdx.x ? img2 : img1;
+        if (img) {
+            int32_t v;
+            out[2 * threadIdx.x]     = find_dir_block(img, stride, &v, coeff_shift);
+            out[2 * threadIdx.x + 1] = v;
+        }
+    }
+}
+__global__ void filter_block_kernel(uint8_t *dst8, uint16_t *dst16, int dstride, const uint16_t *in, int pri, int sec, int dir, int pd,
+                                    int sd, int bsize, int coeff_shift, int sub) {
+    const int bh = 4 << (bsize == 3 || bsize == 1), bw = 4 << (bsize == 3 || bsize == 2);
+    const int i = threadIdx.x / 8, j = threadIdx.x & 7;
+    if (i >= bh || j >= bw || (i % sub))
+        return;
+    const int32_t y = cdef_pixel(in + i * BS + j, pri, sec, dir, pd, sd, coeff_shift);
+    if (dst8)
+        dst8[i * dstride + j] = (uint8_t)(int16_t)y;
+    else
+        dst16[i * dstride + j] = (uint16_t)(int16_t)y;
+}
+__global__ __launch_bounds__(256) void dist_kernel(const void *dst, int dstride, const void *src, const SvtHipCdefList *dlist, int n,
+                                                   int bsize, int coeff_shift, int pli, int sub, int is16, uint64_t *out) {
+    __shared__ unsigned long long total;
+    if (threadIdx.x == 0)
+        total = 0;
+    __syncthreads();
+    const int          bw = 4 << (bsize == 3 || bsize == 2), bh = 4 << (bsize == 3 || bsize == 1);
+    const int          wl = bw == 8 ? 3 : 2, hl = bh == 8 ? 3 : 2;
+    unsigned long long acc = 0;
+    for (int bi = threadIdx.x; bi < n; bi += blockDim.x) {
+        const int    by = dlist[bi].by, bx = dlist[bi].bx;
+        const size_t so = (size_t)bi << (wl + hl), dof = (size_t)(by << hl) * dstride + (bx << wl);
+        if (bsize == 3 && pli == 0) {
+            uint64_t ss = 0, sd = 0, ss2 = 0, sd2 = 0, ssd = 0;
+            for (int i = 0; i < 8; i += sub)
+                for (int j = 0; j < 8; j++) {
+                    const int32_t s = (int32_t)load_px(src, so + 8 * i + j, is16), d = (int32_t)load_px(dst, dof + (size_t)i * dstride + j, is16);
+                    ss += s, sd += d, ss2 += (uint64_t)(s * s), sd2 += (uint64_t)(d * d), ssd += (uint64_t)(s * d);
+                }
+            acc += dist_8xn(ss, sd, ss2, sd2, ssd, coeff_shift);
+        } else {
+            for (int i = 0; i < bh; i += sub)
+                for (int j = 0; j < bw; j++) {
+                    const int32_t e = (int32_t)load_px(dst, dof + (size_t)i * dstride + j, is16) - (int32_t)load_px(src, so + bw * i + j, is16);
+                    acc += (unsigned long long)(int64_t)(e * e);
+                }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(&total, acc);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *out = (uint64_t)total >> 2 * coeff_shift;
+}
+
+// xdec != ydec (4:2:2 / 4:4:0) is refused: the reference encoder only accepts 4:2:0 (enc_settings.c:447) and its filter_fb
+// remaps chroma directions in place for those layouts (cdef.c:389-396), which no reachable reference path exercises.
+bool plane_ok(const SvtHipCdefPlane *p) {
+    return p && p->recon && p->source && p->width && p->height && p->xdec <= 1 && p->ydec == p->xdec && (p->pli == 0 ? p->xdec == 0 : p->pli <= 2);
+}
+void fatal(const char *what) {
+    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
+    abort();
+}
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ Tier B
+extern "C" int32_t svt_hip_cdef_search_plane(const SvtHipCdefPlane *plane, const uint8_t *d_filt8x8, const SvtHipCdefSearchParams *prm,
+                                             uint64_t *d_mse, uint8_t *d_dir, int32_t *d_var, void *stream) {
+    if (!plane_ok(plane) || !d_filt8x8 || !prm || !d_mse || !d_dir || !d_var || prm->n_strengths < 1 ||
+        prm->n_strengths > SVT_HIP_CDEF_MAX_STRENGTHS || prm->subsampling_factor < 1) {
+        set_error("svt_hip_cdef_search_plane: bad argument");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    const int lw = (int)plane->width << plane->xdec, lh = (int)plane->height << plane->ydec;
+    const int nhfb = (lw + 63) / 64, nvfb = (lh + 63) / 64;
+    hipLaunchKernelGGL(cdef_search_kernel, dim3(nhfb * nvfb), dim3(256), 0, resolve_stream(stream), *plane, d_filt8x8, *prm, d_mse, d_dir,
+                       d_var, nhfb);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_cdef_apply_plane(const SvtHipCdefPlane *plane, const uint8_t *d_filt8x8, const uint8_t *d_fb_strength,
+                                            int32_t damping, int32_t coeff_shift, const uint8_t *d_dir, const int32_t *d_var,
+                                            void *stream) {
+    if (!plane_ok(plane) || !d_filt8x8 || !d_fb_strength || !d_dir || !d_var || plane->recon == plane->source) {
+        set_error("svt_hip_cdef_apply_plane: bad argument (input and output planes must differ)");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    const int lw = (int)plane->width << plane->xdec, lh = (int)plane->height << plane->ydec;
+    const int nhfb = (lw + 63) / 64, nvfb = (lh + 63) / 64;
+    hipLaunchKernelGGL(cdef_apply_kernel, dim3(nhfb * nvfb), dim3(256), 0, resolve_stream(stream), *plane, d_filt8x8, d_fb_strength,
+                       damping, coeff_shift, d_dir, d_var, nhfb);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Tier A
+extern "C" void svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2,
+                                               int32_t coeff_shift, uint8_t *out1, uint8_t *out2) {
+    if (!ensure_init())
+        fatal("cdef_find_dir");
+    hipStream_t  st   = resolve_stream(nullptr);
+    Scratch     &sc   = tls_scratch();
+    const size_t span = ((size_t)7 * stride + 8) * 2, o2 = up256(span + 16), ores = 2 * o2;
+    uint8_t     *d = sc.device(ores + 256), *h = sc.host(ores + 256);
+    memcpy(h, img1, span);
+    if (img2)
+        memcpy(h + o2, img2, span);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, h, ores, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(find_dir_kernel, dim3(1), dim3(64), 0, st, (const uint16_t *)d, img2 ? (const uint16_t *)(d + o2) : nullptr, stride,
+                       coeff_shift, (int32_t *)(d + ores));
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + ores, d + ores, 16, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    const int32_t *r = (const int32_t *)(h + ores);
+    *out1 = (uint8_t)r[0], *var1 = r[1];
+    if (img2)
+        *out2 = (uint8_t)r[2], *var2 = r[3];
+}
+extern "C" uint8_t svt_aom_cdef_find_dir_hip(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift) {
+    uint8_t d = 0;
+    svt_aom_cdef_find_dir_dual_hip(img, nullptr, stride, var, nullptr, coeff_shift, &d, nullptr);
+    return d;
+}
+
+extern "C" void svt_cdef_filter_block_hip(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength,
+                                          int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize,
+                                          int32_t coeff_shift, uint8_t subsampling_factor) {
+    if (!ensure_init())
+        fatal("cdef_filter_block");
+    const int    bh = 4 << (bsize == 3 || bsize == 1), bw = 4 << (bsize == 3 || bsize == 2);
+    const size_t before = 2 * BS + 2, after = (size_t)(bh - 1 + 2) * BS + bw + 2;  // taps reach +-(2 rows, 2 columns)
+    const size_t in_bytes = (before + after) * 2, px = dst16 ? 2 : 1, out_bytes = ((size_t)(bh - 1) * dstride + bw) * px;
+    hipStream_t  st = resolve_stream(nullptr);
+    Scratch     &sc = tls_scratch();
+    const size_t oo = up256(in_bytes + 16);
+    uint8_t     *d = sc.device(oo + out_bytes + 256), *h = sc.host(oo + out_bytes + 256);
+    memcpy(h, in - before, in_bytes);
+    memcpy(h + oo, dst16 ? (const void *)dst16 : (const void *)dst8, out_bytes);  // rows skipped by sub-sampling keep their content
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, h, oo + out_bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(filter_block_kernel, dim3(1), dim3(64), 0, st, dst16 ? nullptr : d + oo, dst16 ? (uint16_t *)(d + oo) : nullptr,
+                       dstride, (const uint16_t *)d + before, pri_strength, sec_strength, dir, pri_damping, sec_damping, bsize, coeff_shift,
+                       (int)subsampling_factor);
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + oo, d + oo, out_bytes, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    for (int r = 0; r < bh; r++)
+        memcpy((uint8_t *)(dst16 ? (void *)dst16 : (void *)dst8) + (size_t)r * dstride * px, h + oo + (size_t)r * dstride * px, bw * px);
+}
+
+// Pure 8-bit -> 16-bit widening of a host rectangle: no arithmetic, evaluated on the calling thread
+// (the device-resident equivalent is the tile staging of the kernels above).
+extern "C" void svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v,
+                                                     int32_t hh) {
+    for (int32_t i = 0; i < v; i++)
+        for (int32_t j = 0; j < hh; j++) dst[i * dstride + j] = src[i * sstride + j];
+}
+
+static uint64_t dist_tier_a(const void *dst, int32_t dstride, const void *src, const SvtHipCdefList *dlist, int32_t n, int32_t bsize,
+                            int32_t coeff_shift, int32_t pli, uint8_t sub, int is16) {
+    if (n <= 0)
+        return 0;
+    if (!ensure_init())
+        fatal("compute_cdef_dist");
+    const int    bw = 4 << (bsize == 3 || bsize == 2), bh = 4 << (bsize == 3 || bsize == 1), px = is16 ? 2 : 1;
+    int          maxy = 0, maxx = 0;
+    for (int i = 0; i < n; i++) maxy = dlist[i].by > maxy ? dlist[i].by : maxy, maxx = dlist[i].bx > maxx ? dlist[i].bx : maxx;
+    const size_t dst_bytes = ((size_t)((maxy + 1) * bh - 1) * dstride + (size_t)(maxx + 1) * bw) * px;
+    const size_t src_bytes = (size_t)n * bw * bh * px, dl_bytes = (size_t)n * sizeof(SvtHipCdefList);
+    const size_t o_src = up256(dst_bytes + 16), o_dl = o_src + up256(src_bytes + 16), o_res = o_dl + up256(dl_bytes + 16);
+    hipStream_t  st = resolve_stream(nullptr);
+    Scratch     &sc = tls_scratch();
+    uint8_t     *d = sc.device(o_res + 256), *h = sc.host(o_res + 256);
+    memcpy(h, dst, dst_bytes), memcpy(h + o_src, src, src_bytes), memcpy(h + o_dl, dlist, dl_bytes);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, h, o_res, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dist_kernel, dim3(1), dim3(256), 0, st, (const void *)d, dstride, (const void *)(d + o_src),
+                       (const SvtHipCdefList *)(d + o_dl), n, bsize, coeff_shift, pli, (int)sub, is16, (uint64_t *)(d + o_res));
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + o_res, d + o_res, 8, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    return *(const uint64_t *)(h + o_res);
+}
+extern "C" uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t dstride, const uint16_t *src, const SvtHipCdefList *dlist,
+                                                    int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) {
+    return dist_tier_a(dst, dstride, src, dlist, cdef_count, bsize, coeff_shift, pli, sub, 1);
+}
+extern "C" uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const SvtHipCdefList *dlist,
+                                                   int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) {
+    return dist_tier_a(dst8, dstride, src8, dlist, cdef_count, bsize, coeff_shift, pli, sub, 0);
+}

@@ -164,3 +164,18 @@ class TxfmDesc(C.Structure):
 
 class TxfmResult(C.Structure):
     _fields_ = [("three_quad_energy", C.c_uint64), ("eob", C.c_uint16), ("pad_", C.c_uint16 * 3)]
+
+
+class CdefList(C.Structure):
+    _fields_ = [("by", C.c_uint8), ("bx", C.c_uint8)]
+
+
+class CdefPlane(C.Structure):
+    _fields_ = [("recon", C.c_void_p), ("source", C.c_void_p), ("recon_stride", C.c_uint32), ("source_stride", C.c_uint32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("is_16bit", C.c_uint8), ("xdec", C.c_uint8),
+                ("ydec", C.c_uint8), ("pli", C.c_uint8)]
+
+
+class CdefSearchParams(C.Structure):
+    _fields_ = [("n_strengths", C.c_int32), ("strengths", C.c_int8 * 64), ("pri_damping", C.c_int32),
+                ("sec_damping", C.c_int32), ("coeff_shift", C.c_int32), ("subsampling_factor", C.c_int32)]
