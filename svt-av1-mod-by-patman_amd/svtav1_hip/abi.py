@@ -147,6 +147,11 @@ def load():
 
 
 NO_OFFSET = 0xFFFFFFFFFFFFFFFF
+# SvtHipStatus (include/svt_hip.h:34-39), as the signed int32 values a ctypes call returns
+SVT_HIP_OK = 0
+SVT_HIP_ERR_NO_DEVICE = 0x80001000 - (1 << 32)
+SVT_HIP_ERR_BAD_PARAMETER = 0x80001005 - (1 << 32)
+SVT_HIP_ERR_RUNTIME = 0x80001001 - (1 << 32)
 QUANT_NONE, QUANT_B, QUANT_B_HBD, QUANT_FP, QUANT_FP_HBD = range(5)
 TX_FWD, TX_INV, TX_PIXEL16, TX_FULLCOEFF = 1, 2, 4, 8
 
