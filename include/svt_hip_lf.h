@@ -82,6 +82,69 @@ SVT_HIP_API int32_t svt_hip_cdef_apply_plane(const SvtHipCdefPlane *plane, const
                                              const uint8_t *d_fb_strength, int32_t damping, int32_t coeff_shift,
                                              const uint8_t *d_dir, const int32_t *d_var, void *stream);
 
+/* =============================================================================================
+ * Deblocking
+ *   Source/Lib/Codec/common_dsp_rtcd.h:1043-1074  svt_aom_lpf_{horizontal,vertical}_{4,6,8,14} and the highbd set
+ *   Source/Lib/Codec/deblocking_filter.c:162-282  set_lpf_parameters
+ *   Source/Lib/Codec/deblocking_filter.c:287-653  svt_av1_filter_block_plane_vert/horz, svt_aom_loop_filter_sb,
+ *                                                 svt_av1_loop_filter_frame   (Tier B: svt_hip_loop_filter_frame)
+ *   Source/Lib/Codec/deblocking_common.c:582-600  svt_aom_update_sharpness (lim / mblim; hev_thr = level >> 4,
+ *                                                 deblocking_filter.c:47)
+ * ============================================================================================= */
+
+/* Tier A: RTCD signatures, host pointers.  `s` points at the first q0 sample of a 4-sample edge segment;
+ * the call reads/writes up to 7 samples on either side of the edge (what the reference touches). */
+#define SVT_HIP_DECL_LPF(dir, n)                                                                                              \
+    SVT_HIP_API void svt_aom_lpf_##dir##_##n##_hip(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit,    \
+                                                   const uint8_t *thresh);                                                    \
+    SVT_HIP_API void svt_aom_highbd_lpf_##dir##_##n##_hip(uint16_t *s, int32_t pitch, const uint8_t *blimit,                  \
+                                                          const uint8_t *limit, const uint8_t *thresh, int32_t bd);
+SVT_HIP_DECL_LPF(horizontal, 4)
+SVT_HIP_DECL_LPF(horizontal, 6)
+SVT_HIP_DECL_LPF(horizontal, 8)
+SVT_HIP_DECL_LPF(horizontal, 14)
+SVT_HIP_DECL_LPF(vertical, 4)
+SVT_HIP_DECL_LPF(vertical, 6)
+SVT_HIP_DECL_LPF(vertical, 8)
+SVT_HIP_DECL_LPF(vertical, 14)
+#undef SVT_HIP_DECL_LPF
+
+/* One record per 4x4 luma mode-info unit: the fields set_lpf_parameters reads through pcs->mi_grid_base,
+ * gathered into a flat array (INTEGRATION.md shows the gather loop).  Enum values are the reference's
+ * BlockSize / TxSize (definitions.h). */
+typedef struct SvtHipLfMi {
+    uint8_t bsize;      /* mbmi->block_mi.bsize */
+    uint8_t tx_size_y;  /* tx_depth_to_tx_size[skip_inter ? 0 : tx_depth][bsize]   (get_transform_size, :145-150) */
+    uint8_t tx_size_uv; /* av1_get_max_uv_txsize(bsize, 1, 1) */
+    uint8_t skip_inter; /* block_mi.skip && is_inter_block_no_intrabc(ref_frame[0]) */
+    uint8_t segment_id; /* block_mi.segment_id */
+    uint8_t ref_frame0; /* block_mi.ref_frame[0] (INTRA_FRAME = 0) */
+    uint8_t mode_lf;    /* mode_lf_lut[block_mi.mode] (deblocking_common.h:33-37) */
+    uint8_t reserved;
+} SvtHipLfMi;
+
+typedef struct SvtHipLfFrame {
+    void             *plane[3];  /* device; top-left picture sample of Y, Cb, Cr (4:2:0).  Filtered IN PLACE.  The buffer
+                                  * must be padded like the reference's recon pictures: whole 4x4 units are filtered and
+                                  * taps reach 7 samples past an edge, also below / right of the picture. */
+    uint32_t          stride[3]; /* in samples */
+    uint32_t          width, height; /* unpadded luma size (plane_ptr->dst.width/height, :90-96); chroma is >> 1 */
+    const SvtHipLfMi *mi;        /* device; [mi_rows][mi_stride] */
+    uint32_t          mi_stride, mi_rows, mi_cols; /* mi_cols = aligned_width >> 2, mi_rows = aligned_height >> 2 */
+    uint8_t           lvl[3][8][2][8][2]; /* LoopFilterInfoN.lvl after svt_av1_loop_filter_frame_init */
+    uint8_t           filter_level[2], filter_level_u, filter_level_v; /* frm_hdr.loop_filter_params: plane on/off */
+    uint8_t           sharpness_level;
+    uint8_t           bit_depth; /* static_config.encoder_bit_depth: 8 / 10 */
+    uint8_t           is_16bit;  /* samples are uint16 (is_16bit_pipeline or bit_depth > 8) */
+    uint8_t           plane_start, plane_end; /* as svt_av1_loop_filter_frame(.., plane_start, plane_end) */
+    uint8_t           reserved[3];
+} SvtHipLfFrame;
+
+/* Whole-frame deblocking: all vertical edges, then all horizontal edges, per plane (the order
+ * svt_aom_loop_filter_sb's combine_vert_horz_lf schedule is equivalent to).  delta_lf is not supported —
+ * the reference never enables it (resource_coordination_process.c:410-412). */
+SVT_HIP_API int32_t svt_hip_loop_filter_frame(const SvtHipLfFrame *frame, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,11 @@ ORC_API void     orc_cdef_search_plane(const SvtHipCdefPlane *pl, const uint8_t 
                                        uint64_t *mse, uint8_t *dir, int32_t *var);
 ORC_API void     orc_cdef_apply_plane(const SvtHipCdefPlane *pl, const uint8_t *filt8x8, const uint8_t *fb_strength, int damping,
                                       int coeff_shift, const uint8_t *dir, const int32_t *var);
+/* deblocking (orc_dlf.c) */
+ORC_API void   orc_lpf(void *s, int32_t pitch, int blimit, int limit, int thresh, int bd, int is16, int len, int vertical);
+ORC_API void   orc_lf_thresholds(int level, int sharpness, int *lim, int *mblim, int *hev_thr);
+ORC_API void   orc_loop_filter_frame(const SvtHipLfFrame *f, int sb_size); /* f->plane / f->mi are HOST pointers here */
+ORC_API size_t orc_sizeof_lf_frame(void);
 #ifdef __cplusplus
 }
 #endif

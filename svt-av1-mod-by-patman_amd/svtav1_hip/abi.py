@@ -184,3 +184,19 @@ class CdefPlane(C.Structure):
 class CdefSearchParams(C.Structure):
     _fields_ = [("n_strengths", C.c_int32), ("strengths", C.c_int8 * 64), ("pri_damping", C.c_int32),
                 ("sec_damping", C.c_int32), ("coeff_shift", C.c_int32), ("subsampling_factor", C.c_int32)]
+
+
+class LfMi(C.Structure):          # SvtHipLfMi (include/svt_hip_lf.h)
+    _fields_ = [(n, C.c_uint8) for n in ("bsize", "tx_size_y", "tx_size_uv", "skip_inter", "segment_id", "ref_frame0", "mode_lf",
+                                         "reserved")]
+
+
+class LfFrame(C.Structure):       # SvtHipLfFrame
+    _fields_ = [("plane", C.c_void_p * 3), ("stride", C.c_uint32 * 3), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("mi", C.c_void_p), ("mi_stride", C.c_uint32), ("mi_rows", C.c_uint32), ("mi_cols", C.c_uint32),
+                ("lvl", C.c_uint8 * 768), ("filter_level", C.c_uint8 * 2), ("filter_level_u", C.c_uint8),
+                ("filter_level_v", C.c_uint8), ("sharpness_level", C.c_uint8), ("bit_depth", C.c_uint8), ("is_16bit", C.c_uint8),
+                ("plane_start", C.c_uint8), ("plane_end", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+
+LF_MI_DTYPE = [(n, "u1") for n in ("bsize", "tx_size_y", "tx_size_uv", "skip_inter", "segment_id", "ref_frame0", "mode_lf", "reserved")]

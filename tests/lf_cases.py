@@ -144,3 +144,147 @@ def golden_cdef_inputs(lw, lh, bd, is16, fmt, sub, seed):
         source = np.clip(recon.astype(np.int32) + rng.integers(-6, 7, size=recon.shape), 0, (1 << bd) - 1).astype(dt)
         planes.append((pli, xdec, ydec, w, h, recon, source))
     return filt, strengths, damping, fbs, planes
+
+
+# ------------------------------------------------------------------------------------------------ deblocking
+# BlockSize enum (definitions.h): value by (width, height)
+BSIZE = {(4, 4): 0, (4, 8): 1, (8, 4): 2, (8, 8): 3, (8, 16): 4, (16, 8): 5, (16, 16): 6, (16, 32): 7, (32, 16): 8, (32, 32): 9,
+         (32, 64): 10, (64, 32): 11, (64, 64): 12, (64, 128): 13, (128, 64): 14, (128, 128): 15, (4, 16): 16, (16, 4): 17,
+         (8, 32): 18, (32, 8): 19, (16, 64): 20, (64, 16): 21}
+
+
+class RefLfModeInfo(C.Structure):   # oracle/ref_harness_lf.c
+    _fields_ = [(n, C.c_void_p) for n in ("bsize", "tx_depth", "skip", "ref_frame0", "mode", "segment_id")]
+
+
+class RefLfHeader(C.Structure):
+    _fields_ = [("filter_level", C.c_int32 * 2), ("filter_level_u", C.c_int32), ("filter_level_v", C.c_int32),
+                ("sharpness_level", C.c_int32), ("mode_ref_delta_enabled", C.c_uint8), ("ref_deltas", C.c_int8 * 8),
+                ("mode_deltas", C.c_int8 * 2), ("segmentation_enabled", C.c_uint8), ("seg_lf_data", (C.c_int16 * 4) * 8),
+                ("seg_lf_enabled", (C.c_uint8 * 4) * 8)]
+
+
+def random_mode_info(rng, mi_rows, mi_cols, mi_stride, sb=64, p_skip=0.45, p_intra=0.3, max_depth=2):
+    """A random but structurally valid block partition of the picture: per-4x4 arrays of the fields
+    set_lpf_parameters reads (bsize, tx_depth, skip, ref_frame[0], mode, segment_id)."""
+    f = {k: np.zeros((mi_rows, mi_stride), np.uint8) for k in ("bsize", "tx_depth", "skip", "ref_frame0", "mode", "segment_id")}
+
+    def leaf(x, y, w, h):
+        if x >= mi_cols * 4 or y >= mi_rows * 4:
+            return
+        intra = rng.random() < p_intra
+        vals = dict(bsize=BSIZE[(w, h)], tx_depth=int(rng.integers(0, max_depth + 1)), skip=int(rng.random() < p_skip),
+                    ref_frame0=0 if intra else int(rng.integers(1, 8)), mode=int(rng.integers(0, 13)) if intra else int(rng.integers(13, 25)),
+                    segment_id=int(rng.integers(0, 8)))
+        for k, v in vals.items():
+            f[k][y // 4:min((y + h) // 4, mi_rows), x // 4:min((x + w) // 4, mi_cols)] = v
+
+    def part(x, y, s):
+        if x >= mi_cols * 4 or y >= mi_rows * 4:
+            return
+        kinds = ["none", "split", "horz", "vert"] if s > 4 else ["none"]
+        if 16 <= s <= 64:
+            kinds += ["horz4", "vert4"]
+        if s >= 16:
+            kinds += ["horz_a", "horz_b", "vert_a", "vert_b"]
+        w = [3 if k == "split" and s > 16 else 1 for k in kinds]
+        k = kinds[int(rng.choice(len(kinds), p=np.array(w) / sum(w)))]
+        hs = s // 2
+        if k == "none":
+            leaf(x, y, s, s)
+        elif k == "split":
+            for dy in (0, hs):
+                for dx in (0, hs):
+                    part(x + dx, y + dy, hs)
+        elif k == "horz":
+            leaf(x, y, s, hs), leaf(x, y + hs, s, hs)
+        elif k == "vert":
+            leaf(x, y, hs, s), leaf(x + hs, y, hs, s)
+        elif k == "horz4":
+            for i in range(4):
+                leaf(x, y + i * s // 4, s, s // 4)
+        elif k == "vert4":
+            for i in range(4):
+                leaf(x + i * s // 4, y, s // 4, s)
+        elif k == "horz_a":
+            leaf(x, y, hs, hs), leaf(x + hs, y, hs, hs), leaf(x, y + hs, s, hs)
+        elif k == "horz_b":
+            leaf(x, y, s, hs), leaf(x, y + hs, hs, hs), leaf(x + hs, y + hs, hs, hs)
+        elif k == "vert_a":
+            leaf(x, y, hs, hs), leaf(x, y + hs, hs, hs), leaf(x + hs, y, hs, s)
+        elif k == "vert_b":
+            leaf(x, y, hs, s), leaf(x + hs, y, hs, hs), leaf(x + hs, y + hs, hs, hs)
+
+    for y in range(0, mi_rows * 4, sb):
+        for x in range(0, mi_cols * 4, sb):
+            part(x, y, sb)
+    return f
+
+
+def lf_header(rng, variant):
+    """Frame-header loop-filter parameters; `variant` walks through the branches of svt_av1_loop_filter_frame_init."""
+    h = RefLfHeader()
+    h.filter_level[0], h.filter_level[1] = int(rng.integers(1, 64)), int(rng.integers(1, 64))
+    h.filter_level_u, h.filter_level_v = int(rng.integers(1, 64)), int(rng.integers(1, 64))
+    h.sharpness_level = (0, 3, 7, 5)[variant % 4]
+    if variant % 3 == 1:
+        h.mode_ref_delta_enabled = 1
+        for i, v in enumerate((1, 0, 0, 0, -1, 0, -1, -1)):      # the AV1 default ref deltas
+            h.ref_deltas[i] = v + int(rng.integers(-2, 3))
+        h.mode_deltas[0], h.mode_deltas[1] = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+    if variant % 3 == 2:
+        h.segmentation_enabled = 1
+        for s in range(8):
+            for k in range(4):
+                h.seg_lf_enabled[s][k] = int(rng.random() < 0.6)
+                h.seg_lf_data[s][k] = int(rng.integers(-40, 41))
+    if variant == 5:
+        h.filter_level_u = 0                                      # plane switched off
+    if variant == 7:
+        h.filter_level[0] = h.filter_level[1] = 0                 # luma off => everything off (the `break`, :570-572)
+    return h
+
+
+PAD = 32
+
+
+def lf_planes(rng, w, h, bd, is16):
+    """Three padded 4:2:0 planes with blocky content (so that every filter and both flat branches fire)."""
+    dt = np.uint16 if is16 else np.uint8
+    out = []
+    for pl in range(3):
+        pw, ph = (w >> (pl > 0)) + 2 * PAD, (h >> (pl > 0)) + 2 * PAD
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        img = (1 << bd) * (0.5 + 0.25 * np.sin(xx / 23.0) * np.cos(yy / 31.0))
+        img += (1 << (bd - 8)) * rng.integers(-6, 7, size=(ph // 8 + 1, pw // 8 + 1)).repeat(8, 0).repeat(8, 1)[:ph, :pw]   # block steps
+        img += (1 << (bd - 8)) * rng.integers(-40, 41, size=(ph // 32 + 1, pw // 32 + 1)).repeat(32, 0).repeat(32, 1)[:ph, :pw] * (rng.random() < 0.5)
+        img += rng.integers(-1, 2, size=(ph, pw)) * (1 << (bd - 8)) * (rng.random((ph, pw)) < 0.3)
+        out.append(np.clip(np.rint(img), 0, (1 << bd) - 1).astype(dt))
+    return out
+
+
+def lf_frame(planes, w, h, mi_ptr, mi_stride, mi_rows, mi_cols, hdr, bd, is16, plane_start=0, plane_end=3, lvl=None):
+    f = abi.LfFrame()
+    for i, p in enumerate(planes):
+        if isinstance(p, np.ndarray):
+            f.plane[i] = p.ctypes.data + (PAD * p.shape[1] + PAD) * p.itemsize
+            f.stride[i] = p.shape[1]
+        else:
+            f.plane[i], f.stride[i] = p
+    f.width, f.height, f.mi, f.mi_stride, f.mi_rows, f.mi_cols = w, h, mi_ptr, mi_stride, mi_rows, mi_cols
+    f.filter_level[0], f.filter_level[1] = hdr.filter_level[0], hdr.filter_level[1]
+    f.filter_level_u, f.filter_level_v, f.sharpness_level = hdr.filter_level_u, hdr.filter_level_v, hdr.sharpness_level
+    f.bit_depth, f.is_16bit, f.plane_start, f.plane_end = bd, is16, plane_start, plane_end
+    if lvl is not None:
+        C.memmove(f.lvl, lvl.ctypes.data, 768)
+    return f
+
+
+def ref_deblock(ref, planes, w, h, minfo, mi_stride, mi_rows, mi_cols, hdr, bd, is16, sb_size=64, plane_start=0, plane_end=3):
+    """Run the REAL svt_av1_loop_filter_frame in place on `planes`; returns (flat SvtHipLfMi array, lvl table)."""
+    m = RefLfModeInfo(*[minfo[k].ctypes.data for k in ("bsize", "tx_depth", "skip", "ref_frame0", "mode", "segment_id")])
+    flat = np.zeros((mi_rows, mi_stride), abi.LF_MI_DTYPE)
+    ref.ref_lf_gather(mi_rows * mi_stride, C.byref(m), P(flat))
+    f = lf_frame(planes, w, h, None, mi_stride, mi_rows, mi_cols, hdr, bd, is16, plane_start, plane_end)
+    assert ref.ref_loop_filter_frame(C.byref(f), C.byref(m), C.byref(hdr), sb_size) == 0
+    return flat, np.frombuffer(bytes(f.lvl), np.uint8).copy()
