@@ -31,3 +31,17 @@ for key, lw, lh, bd, is16, fmt, sub, seed in L.GOLDEN_CDEF:
         store[k + "_dir"], store[k + "_var"] = ldir.copy(), lvar.copy()
 np.savez_compressed(os.path.join(HERE, "cdef.npz"), **store)
 print("cdef.npz:", len(store), "arrays", os.path.getsize(os.path.join(HERE, "cdef.npz")), "bytes")
+
+# ---- deblocking: the REAL svt_av1_loop_filter_frame on seeded pictures / partitions (lf_cases.golden_dlf_inputs)
+store = {}
+for key, w, h, bd, is16, variant, sb, seed in L.GOLDEN_DLF:
+    mi_cols, mi_rows, mi_stride, minfo, hdr, planes = L.golden_dlf_inputs(w, h, bd, is16, variant, sb, seed)
+    out = [p.copy() for p in planes]
+    flat, lvl = L.ref_deblock(ref, out, w, h, minfo, mi_stride, mi_rows, mi_cols, hdr, bd, is16, sb)
+    store[key + "_mi"], store[key + "_lvl"] = flat.view(np.uint8).reshape(mi_rows, mi_stride, 8), lvl
+    store[key + "_meta"] = np.array([w, h, bd, is16, mi_cols, mi_rows, mi_stride, hdr.filter_level[0], hdr.filter_level[1],
+                                     hdr.filter_level_u, hdr.filter_level_v, hdr.sharpness_level], np.int32)
+    for i in range(3):
+        store[f"{key}_in{i}"], store[f"{key}_out{i}"] = planes[i], out[i]
+np.savez_compressed(os.path.join(HERE, "dlf.npz"), **store)
+print("dlf.npz:", len(store), "arrays", os.path.getsize(os.path.join(HERE, "dlf.npz")), "bytes")

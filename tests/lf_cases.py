@@ -288,3 +288,36 @@ def ref_deblock(ref, planes, w, h, minfo, mi_stride, mi_rows, mi_cols, hdr, bd, 
     f = lf_frame(planes, w, h, None, mi_stride, mi_rows, mi_cols, hdr, bd, is16, plane_start, plane_end)
     assert ref.ref_loop_filter_frame(C.byref(f), C.byref(m), C.byref(hdr), sb_size) == 0
     return flat, np.frombuffer(bytes(f.lvl), np.uint8).copy()
+
+
+GOLDEN_DLF = [  # key, w, h, bd, is16, header variant, sb, seed
+    ("a_8bit", 200, 136, 8, 0, 1, 64, 21), ("b_10bit_seg", 136, 72, 10, 1, 2, 64, 22), ("c_8in16_sb128", 264, 136, 8, 1, 0, 128, 23)]
+
+
+def golden_dlf_inputs(w, h, bd, is16, variant, sb, seed):
+    rng = np.random.default_rng(seed)
+    mi_cols, mi_rows = (w + 7) // 8 * 2, (h + 7) // 8 * 2
+    mi_stride = mi_cols + 1
+    minfo = random_mode_info(rng, mi_rows, mi_cols, mi_stride, sb=sb)
+    hdr = lf_header(rng, variant)
+    planes = lf_planes(rng, mi_cols * 4, mi_rows * 4, bd, is16)
+    return mi_cols, mi_rows, mi_stride, minfo, hdr, planes
+
+
+class GoldHdr:
+    """The header fields lf_frame() needs, rebuilt from a golden fixture's meta row."""
+
+    def __init__(self, meta):
+        self.filter_level = [int(meta[7]), int(meta[8])]
+        self.filter_level_u, self.filter_level_v, self.sharpness_level = int(meta[9]), int(meta[10]), int(meta[11])
+
+
+def golden_dlf_cases():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dlf.npz"))
+    for key in sorted(k[:-5] for k in g.files if k.endswith("_meta")):
+        meta = g[key + "_meta"]
+        w, h, bd, is16, mi_cols, mi_rows, mi_stride = (int(v) for v in meta[:7])
+        flat = np.ascontiguousarray(g[key + "_mi"]).view(abi.LF_MI_DTYPE).reshape(mi_rows, mi_stride)
+        yield (key, w, h, bd, is16, mi_cols, mi_rows, mi_stride, flat, g[key + "_lvl"].copy(), GoldHdr(meta),
+               [g[f"{key}_in{i}"].copy() for i in range(3)], [g[f"{key}_out{i}"] for i in range(3)])

@@ -179,3 +179,109 @@ def test_tier_b_bad_arguments(hip):
     pl = abi.CdefPlane(0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     assert hip.svt_hip_cdef_search_plane(C.byref(pl), None, C.byref(prm), None, None, None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
     assert hip.svt_hip_cdef_apply_plane(C.byref(pl), None, None, 3, 0, None, None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+
+
+# ------------------------------------------------------------------------------------------------ deblocking
+@pytest.mark.parametrize("d,n", [(d, n) for d in ("horizontal", "vertical") for n in (4, 6, 8, 14)])
+def test_tier_a_lpf(hip, orc, d, n):
+    import test_lf_oracle as TL
+    rng = np.random.default_rng(50 + n + (d == "vertical"))
+    for trial in range(48):
+        bd = (8, 10, 8)[trial % 3]
+        is16 = int(trial % 3 != 0)
+        a = TL.lpf_block(rng, bd, trial)
+        if d == "horizontal":
+            a = a.T
+        a = np.ascontiguousarray(a).astype(np.uint16 if is16 else np.uint8)
+        level, sharp = int(rng.integers(0, 64)), int(rng.integers(0, 8))
+        lim, mblim, hev = C.c_int(), C.c_int(), C.c_int()
+        orc.orc_lf_thresholds(level, sharp, C.byref(lim), C.byref(mblim), C.byref(hev))
+        th = [np.full(16, v.value, np.uint8) for v in (mblim, lim, hev)]
+        b = a.copy()
+        off = (8 * 16 + 4) if d == "horizontal" else (4 * 16 + 8)
+        orc.orc_lpf(V(a.ctypes.data + off * a.itemsize), 16, mblim.value, lim.value, hev.value, bd, is16, n, int(d == "vertical"))
+        if is16:
+            getattr(hip, f"svt_aom_highbd_lpf_{d}_{n}_hip")(V(b.ctypes.data + 2 * off), 16, P(th[0]), P(th[1]), P(th[2]), bd)
+        else:
+            getattr(hip, f"svt_aom_lpf_{d}_{n}_hip")(V(b.ctypes.data + off), 16, P(th[0]), P(th[1]), P(th[2]))
+        assert np.array_equal(a, b), (d, n, trial)
+
+
+def gpu_deblock(hip, planes, w, h, flat, mi_stride, mi_rows, mi_cols, hdr, bd, is16, lvl, ps=0, pe=3):
+    bufs = [device.DeviceBuffer(hip, p.nbytes) for p in planes]
+    for b, p in zip(bufs, planes):
+        b.upload(p)
+    d_mi = device.DeviceBuffer(hip, flat.nbytes)
+    d_mi.upload(flat.view(np.uint8))
+    dev_planes = [(b.ptr + (L.PAD * p.shape[1] + L.PAD) * p.itemsize, p.shape[1]) for b, p in zip(bufs, planes)]
+    f = L.lf_frame(dev_planes, w, h, d_mi.ptr, mi_stride, mi_rows, mi_cols, hdr, bd, is16, ps, pe, lvl)
+    device.check(hip, hip.svt_hip_loop_filter_frame(C.byref(f), None), "loop_filter_frame")
+    device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+    return [b.download(p.dtype, p.shape) for b, p in zip(bufs, planes)]
+
+
+class OrcLvl:
+    """Level table for GPU-box tests (no reference there): filter_level per plane/direction, segment/ref/mode deltas
+    drawn at random — any table is a valid input, the reference's derivation of it is control-plane code."""
+
+    @staticmethod
+    def make(rng, hdr):
+        lvl = rng.integers(0, 64, size=(3, 8, 2, 8, 2)).astype(np.uint8)
+        lvl[:, :, :, :, :] = np.where(rng.random(lvl.shape) < 0.15, 0, lvl)
+        return lvl.reshape(-1)
+
+
+@pytest.mark.parametrize("variant", range(8))
+def test_tier_b_deblock_frame(hip, orc, variant):
+    rng = np.random.default_rng(300 + variant)
+    w, h = ((200, 136), (328, 184), (64, 64), (136, 264), (196, 134), (322, 182), (1920, 1080), (130, 258))[variant]
+    bd, is16 = ((8, 0), (10, 1), (8, 1))[variant % 3]
+    mi_cols, mi_rows = (w + 7) // 8 * 2, (h + 7) // 8 * 2
+    mi_stride = mi_cols + 3
+    minfo = L.random_mode_info(rng, mi_rows, mi_cols, mi_stride, sb=128 if variant == 3 else 64)
+    hdr = L.lf_header(rng, variant)
+    lvl = OrcLvl.make(rng, hdr)
+    # flat SvtHipLfMi records without the reference: the same table lookups, restated in the test
+    flat = np.zeros((mi_rows, mi_stride), abi.LF_MI_DTYPE)
+    skip_inter = (minfo["skip"] != 0) & (minfo["ref_frame0"] > 0)
+    flat["bsize"], flat["skip_inter"], flat["segment_id"], flat["ref_frame0"] = minfo["bsize"], skip_inter, minfo["segment_id"], minfo["ref_frame0"]
+    flat["mode_lf"] = np.isin(minfo["mode"], (13, 14, 16, 17, 18, 19, 20, 21, 22, 24))
+    flat["tx_size_y"] = rng.integers(0, 19, size=flat.shape)   # any TxSize: the kernel only needs its two dimensions
+    flat["tx_size_uv"] = rng.integers(0, 19, size=flat.shape)
+    # keep transform sizes constant inside a block and no larger than it (what a real partition guarantees)
+    bw = np.array([4, 4, 8, 8, 8, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 4, 16, 8, 32, 16, 64])
+    bh = np.array([4, 8, 4, 8, 16, 8, 16, 32, 16, 32, 64, 32, 64, 128, 64, 128, 16, 4, 32, 8, 64, 16])
+    txw = np.array([4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64])
+    txh = np.array([4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16])
+    sq = {4: 0, 8: 1, 16: 2, 32: 3, 64: 4}
+    for r in range(mi_rows):
+        for c in range(mi_cols):
+            b = int(minfo["bsize"][r, c])
+            d = int(minfo["tx_depth"][r, c])
+            side = max(4, min(bw[b], bh[b], 64) >> d)
+            flat["tx_size_y"][r, c] = sq[side]
+            flat["tx_size_uv"][r, c] = sq[max(4, min(bw[b] // 2, bh[b] // 2, 32))]
+    planes = L.lf_planes(rng, mi_cols * 4, mi_rows * 4, bd, is16)
+    p_orc = [p.copy() for p in planes]
+    ps, pe = (0, 3) if variant != 4 else (1, 3)
+    f = L.lf_frame(p_orc, w, h, flat.ctypes.data, mi_stride, mi_rows, mi_cols, hdr, bd, is16, ps, pe, lvl)
+    orc.orc_loop_filter_frame(C.byref(f), 64)
+    got = gpu_deblock(hip, planes, w, h, flat, mi_stride, mi_rows, mi_cols, hdr, bd, is16, lvl, ps, pe)
+    changed = 0
+    for a, b, o in zip(p_orc, got, planes):
+        assert np.array_equal(a, b), np.argwhere(a != b)[:5]
+        changed += int((a != o).sum())
+    assert (changed > 0) == (variant != 7)
+
+
+def test_tier_b_deblock_golden(hip):
+    for key, w, h, bd, is16, mi_cols, mi_rows, mi_stride, flat, lvl, hdr, planes, want in L.golden_dlf_cases():
+        got = gpu_deblock(hip, planes, w, h, flat, mi_stride, mi_rows, mi_cols, hdr, bd, is16, lvl)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), key
+
+
+def test_tier_b_deblock_bad_arguments(hip):
+    f = abi.LfFrame()
+    assert hip.svt_hip_loop_filter_frame(C.byref(f), None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+    assert hip.svt_hip_loop_filter_frame(None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER

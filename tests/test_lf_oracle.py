@@ -282,3 +282,15 @@ def test_loop_filter_frame(orc, ref, variant):
         assert np.array_equal(a, b), np.argwhere(a != b)[:5]
         changed += int((a != o).sum())
     assert (changed > 0) == (variant != 7)
+
+
+def test_loop_filter_oracle_vs_golden(orc):
+    """No reference needed: tests/golden/dlf.npz (made by the real svt_av1_loop_filter_frame) pins the oracle."""
+    n = 0
+    for key, w, h, bd, is16, mi_cols, mi_rows, mi_stride, flat, lvl, hdr, planes, want in L.golden_dlf_cases():
+        f = L.lf_frame(planes, w, h, flat.ctypes.data, mi_stride, mi_rows, mi_cols, hdr, bd, is16, 0, 3, lvl)
+        orc.orc_loop_filter_frame(C.byref(f), 64)      # the schedule's SB size does not change the result
+        for a, b in zip(planes, want):
+            assert np.array_equal(a, b), key
+        n += 1
+    assert n == len(L.GOLDEN_DLF)
