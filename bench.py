@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "svt-av1-mod-by-patman_amd"))
 import torch  # noqa: E402  (device memory, streams/events, torch.distributed: plumbing only)
 import torch.distributed as dist  # noqa: E402
 
-from svtav1_hip import abi, frames  # noqa: E402
+from svtav1_hip import abi, frames, shard  # noqa: E402
 
 WIDTH, HEIGHT = 1920, 1080
 L0_OFFS, L1_OFFS = (-1, -2), (1, 2)     # references of picture i: i-1, i-2 (list 0), i+1, i+2 (list 1)
@@ -223,8 +223,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        shard.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -235,10 +234,7 @@ def main():
         step(k)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dev)       # slowest rank defines the step time
 
     me_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_me]))
     n_refs = len(L0_OFFS) + len(L1_OFFS)

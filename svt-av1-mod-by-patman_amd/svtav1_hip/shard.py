@@ -1,0 +1,57 @@
+"""Multi-GPU layout of the hot path: pictures are sharded across ranks, nothing else.
+
+The open-loop analysis of one picture (pyramid, variance, ME against its reference pictures) reads only that
+picture and its references' source pictures, so a clip splits into contiguous segments, one per
+rank (= one per GPU), each carrying `lookback` / `lookahead` context pictures so that every reference is resident
+locally.  There is no exchange step in the data path; the process group is used for the start/stop barrier, the
+max-over-ranks timing and (optionally) collecting the small per-picture results on rank 0.
+"""
+import torch
+import torch.distributed as dist
+
+
+def segment(n_pictures, world, rank, lookback=2, lookahead=2):
+    """Pictures [first, last) are analysed by `rank`; [ctx_first, ctx_last) must be resident on it.
+    Only pictures with a full set of references are analysed: indices lookback .. n_pictures - lookahead - 1."""
+    lo, hi = lookback, n_pictures - lookahead
+    n = max(hi - lo, 0)
+    base, rem = divmod(n, world)
+    first = lo + rank * base + min(rank, rem)
+    last = first + base + (1 if rank < rem else 0)
+    if first >= last:
+        return first, first, first, first
+    return first, last, first - lookback, last + lookahead
+
+
+def max_over_ranks(value, device="cpu"):
+    """The timing reduction of the bench contract (slowest rank defines the step time)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def analyse_segment(analyse_picture, n_pictures, world, rank, lookback=2, lookahead=2):
+    """Run `analyse_picture(i)` for this rank's pictures; returns {picture index: result}."""
+    first, last, _, _ = segment(n_pictures, world, rank, lookback, lookahead)
+    return {i: analyse_picture(i) for i in range(first, last)}
+
+
+def gather_on_root(local_results):
+    """Collect the per-picture results of all ranks on rank 0 (control-plane sized data: a few KB per picture)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dict(local_results)
+    parts = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(local_results, parts, dst=0)
+    if dist.get_rank() != 0:
+        return None
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    return merged

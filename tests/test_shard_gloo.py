@@ -1,0 +1,92 @@
+"""CPU, world_size 2 over gloo: the picture sharding of the multi-GPU path gives exactly the single-process result.
+The compute inside each rank is the oracle (test-only) — what is under test is the host-side sharding logic that
+bench.py / a multi-GPU integration uses: segment boundaries, context pictures, result gathering, timing reduction."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import me_cases as M
+from svtav1_hip import frames, shard
+
+W, H, N = 192, 128, 11
+L0, L1 = (-1, -2), (1, 2)
+
+
+def analyse_factory():
+    import pyorc
+    orc = pyorc.oracle()
+    clip = M.make_clip("pan", W, H, N, seed=3)
+
+    def analyse(i, lo=0, hi=N):
+        # a rank only builds pyramids for its resident window [lo, hi)
+        pyrs = {k: None for k in range(N)}
+        built = M.build_pyramids(orc, clip[lo:hi])
+        for k, p in zip(range(lo, hi), built):
+            pyrs[k] = p
+        prm = M.scenario_params("m8_360p_tl2", i, [i + o for o in L0], [i + o for o in L1])
+        return M.run_cpu(orc.orc_me_frame_range, prm, pyrs, i, [i + o for o in L0], [i + o for o in L1], W, H)
+    return analyse
+
+
+def worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        analyse = analyse_factory()
+        first, last, c0, c1 = shard.segment(N, world, rank)
+        local = shard.analyse_segment(lambda i: analyse(i, c0, c1), N, world, rank)
+        assert sorted(local) == list(range(first, last))
+        shard.barrier()
+        slowest = shard.max_over_ranks(1.0 + rank)
+        merged = shard.gather_on_root(local)
+        if rank == 0:
+            q.put((slowest, {i: {k: v.copy() for k, v in r.items()} for i, r in merged.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_segments_partition_the_clip():
+    for n in (5, 11, 20, 64):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                first, last, c0, c1 = shard.segment(n, world, r)
+                seen += list(range(first, last))
+                if last > first:
+                    assert c0 == first - 2 and c1 == last + 2 and c0 >= 0 and c1 <= n
+            assert seen == list(range(2, n - 2))
+            sizes = [shard.segment(n, world, r)[1] - shard.segment(n, world, r)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    slowest, merged = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert slowest == 2.0
+    analyse = analyse_factory()
+    assert sorted(merged) == list(range(2, N - 2))
+    for i in sorted(merged):
+        M.assert_same(analyse(i), merged[i], f"picture {i}")
