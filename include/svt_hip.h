@@ -60,6 +60,21 @@ SVT_HIP_API int32_t svt_hip_stream_create(void **stream);
 SVT_HIP_API int32_t svt_hip_stream_destroy(void *stream);
 SVT_HIP_API int32_t svt_hip_stream_sync(void *stream);
 
+/* ---- installing the Tier A functions into the reference's RTCD dispatch -------------------------------
+ * Every Tier A export is named <reference pointer name>_hip and has that pointer's exact signature
+ * (aom_dsp_rtcd.h / common_dsp_rtcd.h).  svt_hip_rtcd_lookup("svt_sad_loop_kernel") returns
+ * &svt_sad_loop_kernel_hip, or NULL when this library has no replacement for that pointer.  (One alias: the
+ * reference's `downsample_2d` pointer, aom_dsp_rtcd.h:838, resolves to svt_aom_downsample_2d_hip.)
+ * svt_hip_install_rtcd assigns all bindings it can resolve and reports how many; it installs nothing and
+ * returns SVT_HIP_ERR_NO_DEVICE when no gfx950 device can be initialised, so the caller keeps the CPU
+ * functions selected by svt_aom_setup_rtcd_internal (aom_dsp_rtcd.c:187).  See INTEGRATION.md. */
+typedef struct SvtHipRtcdBinding {
+    const char *name; /* the reference's pointer variable, e.g. "svt_av1_fwd_txfm2d_16x16" */
+    void      **slot; /* its address, e.g. (void **)&svt_av1_fwd_txfm2d_16x16 */
+} SvtHipRtcdBinding;
+SVT_HIP_API void   *svt_hip_rtcd_lookup(const char *reference_pointer_name);
+SVT_HIP_API int32_t svt_hip_install_rtcd(const SvtHipRtcdBinding *bindings, uint32_t n, uint32_t *n_installed);
+
 /* One padded 8-bit plane (mirror of the luma part of EbPictureBufferDesc,
  * Source/Lib/Codec/pic_buffer_desc.h:34-75).  `buf` points at the first byte of the padded
  * buffer (buffer_y); sample (x,y) of the picture is buf[(org_y+y)*stride + org_x + x]. */

@@ -182,3 +182,46 @@ int32_t svt_hip_stream_sync(void *stream) {
 }
 
 }  // extern "C"
+
+// ---- RTCD installation: <reference pointer name> -> this library's <name>_hip export, resolved through the
+// dynamic symbol table of the library itself so that the list can never drift from what is exported.
+#include <dlfcn.h>
+
+extern "C" void *svt_hip_rtcd_lookup(const char *name) {
+    // the one RTCD pointer of the path whose variable has no svt_ prefix (aom_dsp_rtcd.h:838)
+    if (name && strcmp(name, "downsample_2d") == 0)
+        name = "svt_aom_downsample_2d";
+    if (!name || strncmp(name, "svt_", 4) != 0 || strncmp(name, "svt_hip_", 8) == 0 || strlen(name) > 200)
+        return nullptr;
+    static void *self = [] {
+        Dl_info info;
+        if (!dladdr((void *)&svt_hip_rtcd_lookup, &info) || !info.dli_fname)
+            return (void *)nullptr;
+        return dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+    }();
+    if (!self)
+        return nullptr;
+    char sym[256];
+    snprintf(sym, sizeof(sym), "%s_hip", name);
+    return dlsym(self, sym);
+}
+
+extern "C" int32_t svt_hip_install_rtcd(const SvtHipRtcdBinding *b, uint32_t n, uint32_t *n_installed) {
+    if (n_installed)
+        *n_installed = 0;
+    if (!b && n) {
+        svthip::set_error("svt_hip_install_rtcd: null binding table");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    if (!svthip::ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;  // nothing installed: the caller keeps its CPU pointers
+    uint32_t done = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        void *fn = b[i].slot ? svt_hip_rtcd_lookup(b[i].name) : nullptr;
+        if (fn)
+            *b[i].slot = fn, done++;
+    }
+    if (n_installed)
+        *n_installed = done;
+    return SVT_HIP_OK;
+}

@@ -8,17 +8,20 @@ from svtav1_hip import abi
 
 
 def declared_symbols():
+    """Every function the public headers declare, after macro expansion (the transform / loop-filter families are
+    declared through token-pasting macros)."""
+    import subprocess
     names = []
     for h in sorted(glob.glob(os.path.join(abi.REPO_ROOT, "include", "*.h"))):
-        text = open(h).read()
-        names += re.findall(r"SVT_HIP_API[^;(]*?\b(svt_\w+)\s*\(", text, flags=re.S)
-    return names
+        text = subprocess.run(["gcc", "-E", "-P", h], check=True, capture_output=True, text=True).stdout
+        names += re.findall(r'visibility\("default"\)\)\)[^;(]*?\b(svt_\w+)\s*\(', text, flags=re.S)
+    return sorted(set(names))
 
 
 def test_library_exports_every_declared_symbol():
     lib = abi.load()
     names = declared_symbols()
-    assert len(names) >= 30
+    assert len(names) >= 150
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported by libsvtav1_hip.so"
 
@@ -32,6 +35,21 @@ def test_struct_sizes_match_header():
     assert orc.orc_sizeof_plane() == C.sizeof(abi.Plane8)
     assert C.sizeof(abi.SadLoopDesc) == 48 and C.sizeof(abi.SadLoopResult) == 16
     assert C.sizeof(abi.MeSearchResult) == 16
+    assert orc.orc_sizeof_lf_frame() == C.sizeof(abi.LfFrame)
+    assert C.sizeof(abi.LfMi) == 8 and C.sizeof(abi.CdefList) == 2
+
+
+def test_rtcd_lookup_covers_every_tier_a_export():
+    """svt_hip_rtcd_lookup(<reference pointer name>) resolves exactly the <name>_hip exports."""
+    lib = abi.load()
+    lib.svt_hip_rtcd_lookup.restype = C.c_void_p
+    tier_a = [n[:-4] for n in declared_symbols() if n.endswith("_hip") and not n.startswith("svt_hip_")]
+    assert len(tier_a) >= 120
+    for n in tier_a:
+        fn = lib.svt_hip_rtcd_lookup(n.encode())
+        assert fn == C.cast(getattr(lib, n + "_hip"), C.c_void_p).value, n
+    for n in ("svt_hip_init", "svt_no_such_kernel", "memcpy", ""):
+        assert lib.svt_hip_rtcd_lookup(n.encode()) is None
 
 
 def test_no_device_error_path():
