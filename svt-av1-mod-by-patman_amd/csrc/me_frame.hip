@@ -397,8 +397,28 @@ __device__ void cand_general(MeLds &L, const SvtHipMeParams &p, const uint32_t *
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
+// Phase timing for kernel tuning (make PROF=1): per-phase wall-clock ticks (100 MHz) summed over all workgroups.
+#ifdef SVT_HIP_ME_PROFILE
+__device__ unsigned long long g_me_prof[16];
+#define ME_PHASE(i)                                                        \
+    do {                                                                   \
+        if (threadIdx.x == 0) {                                            \
+            const unsigned long long t_ = wall_clock64();                  \
+            atomicAdd(&g_me_prof[i], t_ - prof_last);                      \
+            prof_last = t_;                                                \
+        }                                                                  \
+    } while (0)
+#else
+#define ME_PHASE(i) \
+    do {            \
+    } while (0)
+#endif
+
 __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
     __shared__ MeLds L;
+#ifdef SVT_HIP_ME_PROFILE
+    unsigned long long prof_last = wall_clock64();
+#endif
     const SvtHipMeFrameJob &job = jobs[blockIdx.y];
     const SvtHipMeParams   &p   = job.prm;
     const uint32_t          aw = (job.src.full.width + 7u) & ~7u, ah = (job.src.full.height + 7u) & ~7u;
@@ -457,6 +477,7 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
     }
     __syncthreads();
 
+    ME_PHASE(0);
     const int nlists = p.num_of_list_to_search;
 
     // ---- init_zz_sad (motion_estimation.c:2452-2507) ----
@@ -500,90 +521,85 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
         __syncthreads();
     }
 
+    ME_PHASE(1);
+    // The HME stages below are descriptor-parallel: every (reference, quadrant) — or (reference, pre-HME region) —
+    // is set up by its own lane, all of them are searched by ONE wg_multi_search call, and the same lane decodes its
+    // result.  f in [0, nref) numbers the references: list 0 first.
+    const int R0 = p.num_of_ref_pic_to_search[0], R1 = nlists > 1 ? p.num_of_ref_pic_to_search[1] : 0;
+    const int nref = R0 + R1;
+
     // ---- prehme_b64 (motion_estimation.c:1792-1866) ----
     if (p.prehme_enable) {
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                if (tid == 0) {
-                    int go = 0;
-                    if (tl > 0 || li == 0) {
-                        const uint32_t      factor = scaled_dist(pic_dist(p, li, ri));
-                        const SvtHipPlane8 &rp     = job.ref[li][ri].sixteenth;
-                        for (int si = 0; si < 2; si++) {
-                            PreHme     &d  = S.ph[li][ri][si];
-                            SearchDesc &sd = L.sh.desc[si];
-                            sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
-                            // check_prehme_early_exit (:1763-1789)
-                            if (p.me_early_exit_th && S.zz_sad[li][ri] < p.me_early_exit_th) {
-                                d.col = d.row = 0, d.sad = 0, d.valid = 1;
-                                continue;
-                            }
-                            if (p.prehme_l1_early_exit) {
-                                const PreHme &o = S.ph[0][ri][si];
-                                if (li == 1 && o.valid &&
-                                    ((o.sad < (32 * 32)) || ((ABSV(o.col) < 16) && (ABSV(o.row) < 16)))) {
-                                    d.col = (int16_t)-o.col, d.row = (int16_t)-o.row, d.sad = o.sad, d.valid = 1;
-                                    continue;
-                                }
-                            }
-                            if (!S.sr[li][ri].do_ref) {
-                                d.col = d.row = 0, d.sad = MAX_U32_;
-                                continue;
-                            }
-                            d.sa_w = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].width * factor), (uint32_t)p.prehme_sa_max[si].width);
-                            d.sa_h = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].height * factor), (uint32_t)p.prehme_sa_max[si].height);
-                            // prehme_core (:1638-1736)
-                            const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
-                            int16_t pad_w = (int16_t)rp.org_x - 1, pad_h = (int16_t)rp.org_y - 1;
-                            int16_t sa_w = (int16_t)d.sa_w, sa_h = (int16_t)d.sa_h;
-                            int16_t ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
-                            const int16_t W = (int16_t)rp.width, H = (int16_t)rp.height;
-                            ox   = ((ox16 + ox) < -pad_w) ? (int16_t)(-pad_w - ox16) : ox;
-                            sa_w = ((ox16 + ox) < -pad_w) ? (int16_t)(sa_w - (-pad_w - (ox16 + ox))) : sa_w;
-                            ox   = ((ox16 + ox) > W - 1) ? (int16_t)(ox - ((ox16 + ox) - (W - 1))) : ox;
-                            sa_w = ((ox16 + ox + sa_w) > W) ? (int16_t)MAXV(1, sa_w - ((ox16 + ox + sa_w) - W)) : sa_w;
-                            oy   = ((oy16 + oy) < -pad_h) ? (int16_t)(-pad_h - oy16) : oy;
-                            sa_h = ((oy16 + oy) < -pad_h) ? (int16_t)(sa_h - (-pad_h - (oy16 + oy))) : sa_h;
-                            oy   = ((oy16 + oy) > H - 1) ? (int16_t)(oy - ((oy16 + oy) - (H - 1))) : oy;
-                            sa_h = ((oy16 + oy + sa_h) > H) ? (int16_t)MAXV(1, sa_h - ((oy16 + oy + sa_h) - H)) : sa_h;
-                            const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
-                            const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
-                            const uint32_t bw = b64_w >> 2, bh = hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2);
-                            set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, p.prehme_skip_search_line && bw == 16 && bh <= 16);
-                            S.q_ox[si] = ox, S.q_oy[si] = oy;
-                            S.performed_phme[li][ri][si] = 1;
-                            go |= 1 << si;
-                        }
+        // list 1 reads list 0's results (l1 early exit :1771-1781, the tl == 0 mirror :1853-1860): one round per list
+        for (int li = 0; li < nlists; ++li) {
+            const int      nr   = li ? R1 : R0;
+            const int      ri   = (int)(tid >> 1), si = (int)(tid & 1);
+            const bool     mine = tid < 2u * (uint32_t)nr;
+            const bool     searching = tl > 0 || li == 0;  // uniform
+            int16_t        q_ox = 0, q_oy = 0;
+            bool           go = false;
+            if (mine) {
+                PreHme     &d  = S.ph[li][ri][si];
+                SearchDesc &sd = L.sh.desc[tid];
+                const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
+                sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+                if (searching) {
+                    const uint32_t factor = scaled_dist(pic_dist(p, li, ri));
+                    const PreHme   o      = S.ph[0][ri][si];
+                    // check_prehme_early_exit (:1763-1789)
+                    if (p.me_early_exit_th && S.zz_sad[li][ri] < p.me_early_exit_th) {
+                        d.col = d.row = 0, d.sad = 0, d.valid = 1;
+                    } else if (p.prehme_l1_early_exit && li == 1 && o.valid &&
+                               ((o.sad < (32 * 32)) || ((ABSV(o.col) < 16) && (ABSV(o.row) < 16)))) {
+                        d.col = (int16_t)-o.col, d.row = (int16_t)-o.row, d.sad = o.sad, d.valid = 1;
+                    } else if (!S.sr[li][ri].do_ref) {
+                        d.col = d.row = 0, d.sad = MAX_U32_;
                     } else {
-                        for (int si = 0; si < 2; si++) {
-                            S.ph[1][ri][si].col = (int16_t)-S.ph[0][ri][si].col;
-                            S.ph[1][ri][si].row = (int16_t)-S.ph[0][ri][si].row;
-                            S.ph[1][ri][si].sad = S.ph[0][ri][si].sad;
-                        }
+                        d.sa_w = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].width * factor), (uint32_t)p.prehme_sa_max[si].width);
+                        d.sa_h = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].height * factor), (uint32_t)p.prehme_sa_max[si].height);
+                        // prehme_core (:1638-1736)
+                        const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
+                        int16_t pad_w = (int16_t)rp.org_x - 1, pad_h = (int16_t)rp.org_y - 1;
+                        int16_t sa_w = (int16_t)d.sa_w, sa_h = (int16_t)d.sa_h;
+                        int16_t ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
+                        const int16_t W = (int16_t)rp.width, H = (int16_t)rp.height;
+                        ox   = ((ox16 + ox) < -pad_w) ? (int16_t)(-pad_w - ox16) : ox;
+                        sa_w = ((ox16 + ox) < -pad_w) ? (int16_t)(sa_w - (-pad_w - (ox16 + ox))) : sa_w;
+                        ox   = ((ox16 + ox) > W - 1) ? (int16_t)(ox - ((ox16 + ox) - (W - 1))) : ox;
+                        sa_w = ((ox16 + ox + sa_w) > W) ? (int16_t)MAXV(1, sa_w - ((ox16 + ox + sa_w) - W)) : sa_w;
+                        oy   = ((oy16 + oy) < -pad_h) ? (int16_t)(-pad_h - oy16) : oy;
+                        sa_h = ((oy16 + oy) < -pad_h) ? (int16_t)(sa_h - (-pad_h - (oy16 + oy))) : sa_h;
+                        oy   = ((oy16 + oy) > H - 1) ? (int16_t)(oy - ((oy16 + oy) - (H - 1))) : oy;
+                        sa_h = ((oy16 + oy + sa_h) > H) ? (int16_t)MAXV(1, sa_h - ((oy16 + oy + sa_h) - H)) : sa_h;
+                        const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
+                        const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
+                        const uint32_t bw = b64_w >> 2, bh = hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2);
+                        set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, p.prehme_skip_search_line && bw == 16 && bh <= 16);
+                        q_ox = ox, q_oy = oy;
+                        S.performed_phme[li][ri][si] = 1;
+                        go = true;
                     }
-                    S.go = go;
+                } else {
+                    d.col = (int16_t)-S.ph[0][ri][si].col;
+                    d.row = (int16_t)-S.ph[0][ri][si].row;
+                    d.sad = S.ph[0][ri][si].sad;
                 }
-                __syncthreads();
-                const int go = S.go;
-                if (go) {
-                    wg_multi_search(L.sh, 2, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2),
-                                    L.win, ME_WIN_DW);
-                    if (tid == 0) {
-                        for (int si = 0; si < 2; si++) {
-                            if (!(go & (1 << si)))
-                                continue;
-                            PreHme &d = S.ph[li][ri][si];
-                            decode_result(L.sh, si, hme_sub, &d.sad, &d.col, &d.row);
-                            d.col = (int16_t)(d.col + S.q_ox[si]);
-                            d.col = (int16_t)(d.col * 4);
-                            d.row = (int16_t)(d.row + S.q_oy[si]);
-                            d.row = (int16_t)(d.row * 4);
-                            d.valid = 1;
-                        }
-                    }
-                }
-                __syncthreads();
             }
+            if (searching) {
+                wg_multi_search(L.sh, 2u * (uint32_t)nr, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2),
+                                L.win, ME_WIN_DW);
+                if (go) {
+                    PreHme &d = S.ph[li][ri][si];
+                    decode_result(L.sh, tid, hme_sub, &d.sad, &d.col, &d.row);
+                    d.col = (int16_t)(d.col + q_ox);
+                    d.col = (int16_t)(d.col * 4);
+                    d.row = (int16_t)(d.row + q_oy);
+                    d.row = (int16_t)(d.row * 4);
+                    d.valid = 1;
+                }
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
             uint32_t best_sad = MAX_U32_;
             for (int li = 0; li < nlists; ++li)
@@ -607,227 +623,200 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
         __syncthreads();
     }
 
+    ME_PHASE(2);
     // ---- HME level 0 (motion_estimation.c:1976-2106) ----
     if (p.enable_hme_flag && p.enable_hme_level0_flag) {
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                if (tid == 0) {
-                    int go = 0;
-                    do {
-                        if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
-                            set_quadrants(S.l0x[li][ri], S.l0y[li][ri], S.l0s[li][ri], 0, 0, 0);
-                            break;
+        // With distance-based resizing, references other than the first read the first one's quadrant-(0,0) vector
+        // (get_hme_l0_search_area, :1881-1890): the first reference then gets a round of its own.
+        const bool dep = p.enable_me_sr_adjustment && p.distance_based_hme_resizing && p.reduce_hme_l0_sr_th_min &&
+            p.reduce_hme_l0_sr_th_max && nref > 1;
+        for (int f0 = 0; f0 < nref;) {
+            const int      f1   = (dep && f0 == 0) ? 1 : nref;
+            const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
+            const bool     mine = tid < nd;
+            const int      f    = f0 + (int)(tid >> 2);
+            const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
+            const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+            int16_t        q_ox = 0, q_oy = 0;
+            bool           go = false;
+            if (mine) {
+                SearchDesc         &sd = L.sh.desc[tid];
+                const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
+                sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+                const int psi = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
+                if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
+                    S.l0x[li][ri][sw_][sh_] = 0, S.l0y[li][ri][sw_][sh_] = 0, S.l0s[li][ri][sw_][sh_] = 0;
+                } else if (p.prev_me_stage_based_exit_th && S.performed_phme[li][ri][psi] &&
+                           S.ph[li][ri][psi].sad < (p.prev_me_stage_based_exit_th >> 4)) {
+                    S.l0x[li][ri][sw_][sh_] = S.ph[li][ri][psi].col, S.l0y[li][ri][sw_][sh_] = S.ph[li][ri][psi].row;
+                    S.l0s[li][ri][sw_][sh_] = S.ph[li][ri][psi].sad;
+                } else if (!S.sr[li][ri].do_ref) {
+                    S.l0x[li][ri][sw_][sh_] = 0, S.l0y[li][ri][sw_][sh_] = 0, S.l0s[li][ri][sw_][sh_] = MAX_U32_;
+                } else if (tl > 0 || li == 0) {
+                    // get_hme_l0_search_area (:1870-1937); hme_l0_sa is restored right after use (:2069-2073)
+                    SvtHipSearchArea mn = S.l0_min, mx = S.l0_max;
+                    if (p.enable_me_sr_adjustment && p.distance_based_hme_resizing) {
+                        uint8_t is_hor = 1, is_ver = 1, is_still = 0;
+                        if (p.reduce_hme_l0_sr_th_min && p.reduce_hme_l0_sr_th_max && (li || ri)) {
+                            const int16_t mvx = S.l0x[0][0][0][0], mvy = S.l0y[0][0][0][0];
+                            is_ver   = (ABSV(mvx) < p.reduce_hme_l0_sr_th_min) && (ABSV(mvy) > p.reduce_hme_l0_sr_th_max);
+                            is_hor   = (ABSV(mvx) > p.reduce_hme_l0_sr_th_max) && (ABSV(mvy) < p.reduce_hme_l0_sr_th_min);
+                            is_still = (ABSV(mvx) < (p.reduce_hme_l0_sr_th_min * 3)) && (ABSV(mvy) < (p.reduce_hme_l0_sr_th_min * 3));
                         }
-                        if (p.prev_me_stage_based_exit_th) {
-                            const int si = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
-                            if (S.performed_phme[li][ri][si] && S.ph[li][ri][si].sad < (p.prev_me_stage_based_exit_th >> 4)) {
-                                set_quadrants(S.l0x[li][ri], S.l0y[li][ri], S.l0s[li][ri], S.ph[li][ri][si].col,
-                                              S.ph[li][ri][si].row, S.ph[li][ri][si].sad);
-                                break;
-                            }
-                        }
-                        if (!S.sr[li][ri].do_ref) {
-                            set_quadrants(S.l0x[li][ri], S.l0y[li][ri], S.l0s[li][ri], 0, 0, MAX_U32_);
-                            break;
-                        }
-                        if (!(tl > 0 || li == 0))
-                            break;
-                        // get_hme_l0_search_area (:1870-1937); hme_l0_sa is restored right after use (:2069-2073)
-                        SvtHipSearchArea mn = S.l0_min, mx = S.l0_max;
-                        if (p.enable_me_sr_adjustment && p.distance_based_hme_resizing) {
-                            uint8_t is_hor = 1, is_ver = 1, is_still = 0;
-                            if (p.reduce_hme_l0_sr_th_min && p.reduce_hme_l0_sr_th_max && (li || ri)) {
-                                const int16_t mvx = S.l0x[0][0][0][0], mvy = S.l0y[0][0][0][0];
-                                is_ver   = (ABSV(mvx) < p.reduce_hme_l0_sr_th_min) && (ABSV(mvy) > p.reduce_hme_l0_sr_th_max);
-                                is_hor   = (ABSV(mvx) > p.reduce_hme_l0_sr_th_max) && (ABSV(mvy) < p.reduce_hme_l0_sr_th_min);
-                                is_still = (ABSV(mvx) < (p.reduce_hme_l0_sr_th_min * 3)) && (ABSV(mvy) < (p.reduce_hme_l0_sr_th_min * 3));
-                            }
-                            uint8_t xo = 1, yo = 1;
-                            if (!is_ver) yo = 2;
-                            if (!is_hor) xo = 2;
-                            if (p.enable_me_sr_adjustment == 2 && is_still) xo = yo = 4;
-                            mn.width  = (uint16_t)(mn.width / (xo + ri));
-                            mn.height = (uint16_t)(mn.height / (yo + ri));
-                            mx.width  = (uint16_t)(mx.width / (xo + ri));
-                            mx.height = (uint16_t)(mx.height / (yo + ri));
-                        }
-                        const int32_t factor = scaled_dist(pic_dist(p, li, ri));
-                        int16_t       w      = (int16_t)(mn.width / p.num_hme_sa_w);
-                        w = (int16_t)MINV((((w * factor) + 15) & ~0x0F), (((mx.width / p.num_hme_sa_w) + 15) & ~0x0F));
-                        int16_t h = (int16_t)(mn.height / p.num_hme_sa_h);
-                        h         = (int16_t)MINV((h * factor), (mx.height / p.num_hme_sa_h));
-                        const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
-                        const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
-                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
-                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
-                                // hme_level_0 (:820-920)
-                                int16_t sa_w = (int16_t)((w + 7) & ~0x07), sa_h = h;
-                                const int16_t xd = (int16_t)(sa_w * sw_), yd = (int16_t)(sa_h * sh_);
-                                int16_t ox = (int16_t)(-(int16_t)((sa_w * p.num_hme_sa_w) >> 1) + xd);
-                                int16_t oy = (int16_t)(-(int16_t)((sa_h * p.num_hme_sa_h) >> 1) + yd);
-                                hme_clamp(ox16, oy16, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width,
-                                          (int16_t)rp.height, &ox, &oy, &sa_w, &sa_h);
-                                const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
-                                const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
-                                const uint32_t qi = sh_ * 2 + sw_;
-                                set_desc(L.sh.desc[qi], p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-                                S.q_ox[qi] = ox, S.q_oy[qi] = oy;
-                            }
-                        go = 1;
-                    } while (0);
-                    S.go = go;
-                }
-                __syncthreads();
-                if (S.go) {
-                    wg_multi_search(L.sh, 4, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2),
-                                    L.win, ME_WIN_DW);
-                    if (tid == 0) {
-                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
-                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
-                                const uint32_t qi = sh_ * 2 + sw_;
-                                int16_t        mx = S.l0x[li][ri][sw_][sh_], my = S.l0y[li][ri][sw_][sh_];
-                                decode_result(L.sh, qi, hme_sub, &S.l0s[li][ri][sw_][sh_], &mx, &my);
-                                mx = (int16_t)(mx + S.q_ox[qi]), mx = (int16_t)(mx * 4);
-                                my = (int16_t)(my + S.q_oy[qi]), my = (int16_t)(my * 4);
-                                S.l0x[li][ri][sw_][sh_] = mx, S.l0y[li][ri][sw_][sh_] = my;
-                            }
-                        if (p.prehme_enable) {
-                            uint8_t  bw_ = 0, bh_ = 0;
-                            uint64_t mx = 0;
-                            if (S.l0s[li][ri][0][0] > mx) mx = S.l0s[li][ri][0][0], bw_ = 0, bh_ = 0;
-                            if (S.l0s[li][ri][1][0] > mx) mx = S.l0s[li][ri][1][0], bw_ = 1, bh_ = 0;
-                            if (S.l0s[li][ri][0][1] > mx) mx = S.l0s[li][ri][0][1], bw_ = 0, bh_ = 1;
-                            if (S.l0s[li][ri][1][1] > mx) bw_ = 1, bh_ = 1;
-                            const int si = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
-                            if (S.ph[li][ri][si].sad < S.l0s[li][ri][bw_][bh_]) {
-                                S.l0s[li][ri][bw_][bh_] = S.ph[li][ri][si].sad;
-                                S.l0x[li][ri][bw_][bh_] = S.ph[li][ri][si].col;
-                                S.l0y[li][ri][bw_][bh_] = S.ph[li][ri][si].row;
-                            }
-                        }
+                        uint8_t xo = 1, yo = 1;
+                        if (!is_ver) yo = 2;
+                        if (!is_hor) xo = 2;
+                        if (p.enable_me_sr_adjustment == 2 && is_still) xo = yo = 4;
+                        mn.width  = (uint16_t)(mn.width / (xo + ri));
+                        mn.height = (uint16_t)(mn.height / (yo + ri));
+                        mx.width  = (uint16_t)(mx.width / (xo + ri));
+                        mx.height = (uint16_t)(mx.height / (yo + ri));
                     }
+                    const int32_t factor = scaled_dist(pic_dist(p, li, ri));
+                    int16_t       w      = (int16_t)(mn.width / p.num_hme_sa_w);
+                    w = (int16_t)MINV((((w * factor) + 15) & ~0x0F), (((mx.width / p.num_hme_sa_w) + 15) & ~0x0F));
+                    int16_t h = (int16_t)(mn.height / p.num_hme_sa_h);
+                    h         = (int16_t)MINV((h * factor), (mx.height / p.num_hme_sa_h));
+                    const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
+                    // hme_level_0 (:820-920)
+                    int16_t       sa_w = (int16_t)((w + 7) & ~0x07), sa_h = h;
+                    const int16_t xd = (int16_t)(sa_w * sw_), yd = (int16_t)(sa_h * sh_);
+                    int16_t       ox = (int16_t)(-(int16_t)((sa_w * p.num_hme_sa_w) >> 1) + xd);
+                    int16_t       oy = (int16_t)(-(int16_t)((sa_h * p.num_hme_sa_h) >> 1) + yd);
+                    hme_clamp(ox16, oy16, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width, (int16_t)rp.height, &ox,
+                              &oy, &sa_w, &sa_h);
+                    const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
+                    const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
+                    set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+                    q_ox = ox, q_oy = oy;
+                    go   = true;
                 }
-                __syncthreads();
             }
+            wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
+                            ME_WIN_DW);
+            if (go) {
+                int16_t mx = S.l0x[li][ri][sw_][sh_], my = S.l0y[li][ri][sw_][sh_];
+                decode_result(L.sh, tid, hme_sub, &S.l0s[li][ri][sw_][sh_], &mx, &my);
+                mx = (int16_t)(mx + q_ox), mx = (int16_t)(mx * 4);
+                my = (int16_t)(my + q_oy), my = (int16_t)(my * 4);
+                S.l0x[li][ri][sw_][sh_] = mx, S.l0y[li][ri][sw_][sh_] = my;
+            }
+            __syncthreads();
+            // the pre-HME vector replaces the worst quadrant if it is better (:2086-2104): one lane per reference
+            if (go && qi == 0 && p.prehme_enable) {
+                uint8_t  bw_ = 0, bh_ = 0;
+                uint64_t mx = 0;
+                if (S.l0s[li][ri][0][0] > mx) mx = S.l0s[li][ri][0][0], bw_ = 0, bh_ = 0;
+                if (S.l0s[li][ri][1][0] > mx) mx = S.l0s[li][ri][1][0], bw_ = 1, bh_ = 0;
+                if (S.l0s[li][ri][0][1] > mx) mx = S.l0s[li][ri][0][1], bw_ = 0, bh_ = 1;
+                if (S.l0s[li][ri][1][1] > mx) bw_ = 1, bh_ = 1;
+                const int si = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
+                if (S.ph[li][ri][si].sad < S.l0s[li][ri][bw_][bh_]) {
+                    S.l0s[li][ri][bw_][bh_] = S.ph[li][ri][si].sad;
+                    S.l0x[li][ri][bw_][bh_] = S.ph[li][ri][si].col;
+                    S.l0y[li][ri][bw_][bh_] = S.ph[li][ri][si].row;
+                }
+            }
+            __syncthreads();
+            f0 = f1;
+        }
     }
 
+    ME_PHASE(3);
     // ---- HME level 1 (motion_estimation.c:2111-2192) ----
     if (p.enable_hme_flag && p.enable_hme_level1_flag) {
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                if (!(tl > 0 || li == 0))
-                    continue;
-                if (tid == 0) {
-                    int go = 0;
-                    if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
-                        set_quadrants(S.l1x[li][ri], S.l1y[li][ri], S.l1s[li][ri], 0, 0, 0);
-                    } else if (!S.sr[li][ri].do_ref) {
-                        set_quadrants(S.l1x[li][ri], S.l1y[li][ri], S.l1s[li][ri], 0, 0, MAX_U32_);
-                    } else {
-                        const SvtHipPlane8 &rp = job.ref[li][ri].quarter;
-                        const int16_t ox4 = (int16_t)(((int16_t)org_x) >> 1), oy4 = (int16_t)(((int16_t)org_y) >> 1);
-                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
-                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
-                                const uint32_t qi = sh_ * 2 + sw_;
-                                SearchDesc    &sd = L.sh.desc[qi];
-                                sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
-                                if (p.prev_me_stage_based_exit_th && S.l0s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 5)) {
-                                    S.l1x[li][ri][sw_][sh_] = S.l0x[li][ri][sw_][sh_];
-                                    S.l1y[li][ri][sw_][sh_] = S.l0y[li][ri][sw_][sh_];
-                                    S.l1s[li][ri][sw_][sh_] = S.l0s[li][ri][sw_][sh_];
-                                    continue;
-                                }
-                                // hme_level_1 (:923-1022)
-                                int16_t sa_w = (int16_t)(((int16_t)p.hme_l1_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l1_sa.height;
-                                int16_t ox = (int16_t)(-(sa_w >> 1) + (int16_t)(S.l0x[li][ri][sw_][sh_] >> 1));
-                                int16_t oy = (int16_t)(-(sa_h >> 1) + (int16_t)(S.l0y[li][ri][sw_][sh_] >> 1));
-                                hme_clamp(ox4, oy4, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width,
-                                          (int16_t)rp.height, &ox, &oy, &sa_w, &sa_h);
-                                const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox4) + ox);
-                                const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy4) + oy);
-                                set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-                                S.q_ox[qi] = ox, S.q_oy[qi] = oy;
-                                go |= 1 << qi;
-                            }
-                    }
-                    S.go = go;
+        const uint32_t nd   = (uint32_t)nref * 4u;
+        const bool     mine = tid < nd;
+        const int      f    = (int)(tid >> 2);
+        const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
+        const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+        int16_t        q_ox = 0, q_oy = 0;
+        bool           go = false;
+        if (mine) {
+            SearchDesc         &sd = L.sh.desc[tid];
+            const SvtHipPlane8 &rp = job.ref[li][ri].quarter;
+            sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+            if (tl > 0 || li == 0) {
+                if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
+                    S.l1x[li][ri][sw_][sh_] = 0, S.l1y[li][ri][sw_][sh_] = 0, S.l1s[li][ri][sw_][sh_] = 0;
+                } else if (!S.sr[li][ri].do_ref) {
+                    S.l1x[li][ri][sw_][sh_] = 0, S.l1y[li][ri][sw_][sh_] = 0, S.l1s[li][ri][sw_][sh_] = MAX_U32_;
+                } else if (p.prev_me_stage_based_exit_th && S.l0s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 5)) {
+                    S.l1x[li][ri][sw_][sh_] = S.l0x[li][ri][sw_][sh_];
+                    S.l1y[li][ri][sw_][sh_] = S.l0y[li][ri][sw_][sh_];
+                    S.l1s[li][ri][sw_][sh_] = S.l0s[li][ri][sw_][sh_];
+                } else {
+                    // hme_level_1 (:923-1022)
+                    const int16_t ox4 = (int16_t)(((int16_t)org_x) >> 1), oy4 = (int16_t)(((int16_t)org_y) >> 1);
+                    int16_t sa_w = (int16_t)(((int16_t)p.hme_l1_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l1_sa.height;
+                    int16_t ox = (int16_t)(-(sa_w >> 1) + (int16_t)(S.l0x[li][ri][sw_][sh_] >> 1));
+                    int16_t oy = (int16_t)(-(sa_h >> 1) + (int16_t)(S.l0y[li][ri][sw_][sh_] >> 1));
+                    hme_clamp(ox4, oy4, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width, (int16_t)rp.height, &ox,
+                              &oy, &sa_w, &sa_h);
+                    const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox4) + ox);
+                    const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy4) + oy);
+                    set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+                    q_ox = ox, q_oy = oy;
+                    go   = true;
                 }
-                __syncthreads();
-                const int go = S.go;
-                if (go) {
-                    wg_multi_search(L.sh, 4, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1),
-                                    L.win, ME_WIN_DW);
-                    if (tid == 0)
-                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
-                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
-                                const uint32_t qi = sh_ * 2 + sw_;
-                                if (!(go & (1 << qi)))
-                                    continue;
-                                int16_t mx = S.l1x[li][ri][sw_][sh_], my = S.l1y[li][ri][sw_][sh_];
-                                decode_result(L.sh, qi, hme_sub, &S.l1s[li][ri][sw_][sh_], &mx, &my);
-                                mx = (int16_t)(mx + S.q_ox[qi]), mx = (int16_t)(mx * 2);
-                                my = (int16_t)(my + S.q_oy[qi]), my = (int16_t)(my * 2);
-                                S.l1x[li][ri][sw_][sh_] = mx, S.l1y[li][ri][sw_][sh_] = my;
-                            }
-                }
-                __syncthreads();
             }
+        }
+        wg_multi_search(L.sh, nd, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1), L.win,
+                        ME_WIN_DW);
+        if (go) {
+            int16_t mx = S.l1x[li][ri][sw_][sh_], my = S.l1y[li][ri][sw_][sh_];
+            decode_result(L.sh, tid, hme_sub, &S.l1s[li][ri][sw_][sh_], &mx, &my);
+            mx = (int16_t)(mx + q_ox), mx = (int16_t)(mx * 2);
+            my = (int16_t)(my + q_oy), my = (int16_t)(my * 2);
+            S.l1x[li][ri][sw_][sh_] = mx, S.l1y[li][ri][sw_][sh_] = my;
+        }
+        __syncthreads();
     }
 
+    ME_PHASE(4);
     // ---- HME level 2 (motion_estimation.c:2197-2247) ----
     if (p.enable_hme_flag && p.enable_hme_level2_flag) {
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                if (!(tl > 0 || li == 0))
-                    continue;
-                if (tid == 0) {
-                    int                 go = 0;
-                    const SvtHipPlane8 &rp = job.ref[li][ri].full;
-                    for (uint32_t sh_ = 0; sh_ < 2; sh_++)
-                        for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
-                            const uint32_t qi = sh_ * 2 + sw_;
-                            SearchDesc    &sd = L.sh.desc[qi];
-                            sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
-                            if (p.prev_me_stage_based_exit_th && S.l1s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 2)) {
-                                S.l2x[li][ri][sw_][sh_] = S.l1x[li][ri][sw_][sh_];
-                                S.l2y[li][ri][sw_][sh_] = S.l1y[li][ri][sw_][sh_];
-                                S.l2s[li][ri][sw_][sh_] = S.l1s[li][ri][sw_][sh_];
-                                continue;
-                            }
-                            // hme_level_2 (:1025-1113)
-                            int16_t sa_w = (int16_t)(((int16_t)p.hme_l2_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l2_sa.height;
-                            int16_t ox = (int16_t)(-(sa_w >> 1) + S.l1x[li][ri][sw_][sh_]);
-                            int16_t oy = (int16_t)(-(sa_h >> 1) + S.l1y[li][ri][sw_][sh_]);
-                            hme_clamp((int16_t)org_x, (int16_t)org_y, 63, 63, (int16_t)rp.width, (int16_t)rp.height, &ox, &oy,
-                                      &sa_w, &sa_h);
-                            const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + (int16_t)org_x) + ox);
-                            const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + (int16_t)org_y) + oy);
-                            set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-                            S.q_ox[qi] = ox, S.q_oy[qi] = oy;
-                            go |= 1 << qi;
-                        }
-                    S.go = go;
+        const uint32_t nd   = (uint32_t)nref * 4u;
+        const bool     mine = tid < nd;
+        const int      f    = (int)(tid >> 2);
+        const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
+        const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+        int16_t        q_ox = 0, q_oy = 0;
+        bool           go = false;
+        if (mine) {
+            SearchDesc         &sd = L.sh.desc[tid];
+            const SvtHipPlane8 &rp = job.ref[li][ri].full;
+            sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+            if (tl > 0 || li == 0) {
+                if (p.prev_me_stage_based_exit_th && S.l1s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 2)) {
+                    S.l2x[li][ri][sw_][sh_] = S.l1x[li][ri][sw_][sh_];
+                    S.l2y[li][ri][sw_][sh_] = S.l1y[li][ri][sw_][sh_];
+                    S.l2s[li][ri][sw_][sh_] = S.l1s[li][ri][sw_][sh_];
+                } else {
+                    // hme_level_2 (:1025-1113)
+                    int16_t sa_w = (int16_t)(((int16_t)p.hme_l2_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l2_sa.height;
+                    int16_t ox = (int16_t)(-(sa_w >> 1) + S.l1x[li][ri][sw_][sh_]);
+                    int16_t oy = (int16_t)(-(sa_h >> 1) + S.l1y[li][ri][sw_][sh_]);
+                    hme_clamp((int16_t)org_x, (int16_t)org_y, 63, 63, (int16_t)rp.width, (int16_t)rp.height, &ox, &oy, &sa_w, &sa_h);
+                    const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + (int16_t)org_x) + ox);
+                    const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + (int16_t)org_y) + oy);
+                    set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+                    q_ox = ox, q_oy = oy;
+                    go   = true;
                 }
-                __syncthreads();
-                const int go = S.go;
-                if (go) {
-                    wg_multi_search(L.sh, 4, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, L.win, ME_WIN_DW);
-                    if (tid == 0)
-                        for (uint32_t sh_ = 0; sh_ < 2; sh_++)
-                            for (uint32_t sw_ = 0; sw_ < 2; sw_++) {
-                                const uint32_t qi = sh_ * 2 + sw_;
-                                if (!(go & (1 << qi)))
-                                    continue;
-                                int16_t mx = S.l2x[li][ri][sw_][sh_], my = S.l2y[li][ri][sw_][sh_];
-                                decode_result(L.sh, qi, hme_sub, &S.l2s[li][ri][sw_][sh_], &mx, &my);
-                                S.l2x[li][ri][sw_][sh_] = (int16_t)(mx + S.q_ox[qi]);
-                                S.l2y[li][ri][sw_][sh_] = (int16_t)(my + S.q_oy[qi]);
-                            }
-                }
-                __syncthreads();
             }
+        }
+        wg_multi_search(L.sh, nd, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, L.win, ME_WIN_DW);
+        if (go) {
+            int16_t mx = S.l2x[li][ri][sw_][sh_], my = S.l2y[li][ri][sw_][sh_];
+            decode_result(L.sh, tid, hme_sub, &S.l2s[li][ri][sw_][sh_], &mx, &my);
+            S.l2x[li][ri][sw_][sh_] = (int16_t)(mx + q_ox);
+            S.l2y[li][ri][sw_][sh_] = (int16_t)(my + q_oy);
+        }
+        __syncthreads();
     }
 
+    ME_PHASE(5);
     // ---- set_final_seach_centre_sb (:2252-2450) + hme_prune_ref_and_adjust_sr (:2547-2588) ----
     if (tid == 0) {
         int16_t  hx = 0, hy = 0, xc = 0, yc = 0;
@@ -875,6 +864,7 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
     }
     __syncthreads();
 
+    ME_PHASE(6);
     // ---- integer_search_b64 (motion_estimation.c:1249-1586) ----
     {
         const int16_t W = (int16_t)aw, H = (int16_t)ah, pad = 63;
@@ -1050,6 +1040,7 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
             }
     }
 
+    ME_PHASE(7);
     // ---- me_prune_ref (motion_estimation.c:1592-1635) ----
     if (p.enable_hme_flag && p.enable_me_hme_ref_pruning) {
         if (tid == 0) {
@@ -1076,6 +1067,7 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
         __syncthreads();
     }
 
+    ME_PHASE(8);
     // ---- candidates (motion_estimation.c:3196-3211) ----
     const SvtHipMeFrameOut &out    = job.out;
     const uint32_t          stored = p.enable_me_16x16 ? (p.enable_me_8x8 ? 85u : 21u) : 5u;
@@ -1097,6 +1089,7 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
     }
     __syncthreads();
 
+    ME_PHASE(9);
     // ---- compute_distortion (motion_estimation.c:3034-3077) + result write-back ----
     if (tid == 0) {
         uint32_t d64 = L.me_dist[0], d32 = 0, d16 = 0, d8 = 0;
@@ -1119,9 +1112,23 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
     }
     if (tid < NL * NR)
         out.search_results[(size_t)b64 * NL * NR + tid] = (&S.sr[0][0])[tid];
+    ME_PHASE(10);
 }
 
 }  // namespace
+
+#ifdef SVT_HIP_ME_PROFILE
+// tuning aid, only in PROF=1 builds: copies (and optionally clears) the phase counters
+extern "C" __attribute__((visibility("default"))) int32_t svt_hip_debug_me_profile(unsigned long long out[16], int32_t reset) {
+    SVT_HIP_CHECK(hipDeviceSynchronize());
+    SVT_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_prof), sizeof(unsigned long long) * 16));
+    if (reset) {
+        unsigned long long z[16] = {};
+        SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_me_prof), z, sizeof(z)));
+    }
+    return SVT_HIP_OK;
+}
+#endif
 
 extern "C" uint32_t svt_hip_me_b64_count(uint32_t width, uint32_t height) {
     const uint32_t aw = (width + 7u) & ~7u, ah = (height + 7u) & ~7u;

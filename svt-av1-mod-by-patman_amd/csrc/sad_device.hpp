@@ -19,7 +19,7 @@ namespace svthip {
 namespace dev {
 
 constexpr int      WG_THREADS = 256;
-constexpr int      MAX_SEARCH = 16;
+constexpr int      MAX_SEARCH = 32;
 constexpr uint64_t KEY_NONE   = ((uint64_t)0xffffffu << 32) | 0xffffffffu;  // best starts at 0xffffff
 
 struct SearchDesc {
@@ -35,6 +35,7 @@ struct SearchDesc {
     uint32_t n_srows;   // searched rows
     uint32_t pitch_dw;  // LDS row pitch of the staged window (dwords)
     uint32_t rows_per_pos;  // raw rows spanned by one search position: (bh-1)*k + 1
+    uint32_t inv_pitch, inv_nq;  // ceil(2^32 / x): exact quotients for the small dividends used here
 };
 
 struct SearchSeg {
@@ -49,12 +50,15 @@ struct SearchShared {
     SearchDesc desc[MAX_SEARCH];
     SearchSeg  seg[MAX_SEARCH];
     uint64_t   best[MAX_SEARCH];
-    uint32_t   nseg, nitems;
+    uint32_t   nseg, nitems, nstage_dw;
     uint32_t   next_d, next_j;  // continuation point of the planner
     uint32_t   slow_mask;       // descriptors that must take the slow (global memory) path
 };
 
 __device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+// n / d for n * d < 2^32 with inv = ceil(2^32 / d) (d >= 2; d == 1 is handled by the caller passing inv = 0)
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
+__device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? (uint32_t)((0x100000000ull + d - 1) / d) : 0u; }
 
 // SAD of 4 adjacent positions (window dword `w` onwards) against one block.  src rows are dwords in LDS.
 __device__ __forceinline__ void quad_sad(const uint32_t *__restrict__ w, uint32_t w_row_dw,
@@ -110,17 +114,37 @@ __device__ __forceinline__ void search_plan_desc(SearchDesc &d, uint32_t bw, uin
     }
     d.n_srows = d.skip ? (uint32_t)d.sa_h / 2u : (uint32_t)d.sa_h;
     d.nq      = ((uint32_t)d.sa_w + 3u) >> 2;
-    if (d.raw_stride != 0 && d.ref_stride % d.raw_stride == 0 && bw <= 256) {
-        d.k            = d.ref_stride / d.raw_stride;
-        d.rows_per_pos = (bh - 1) * d.k + 1;
-        d.pitch_dw     = (d.nq + ((bw + 3) >> 2) + 1) | 1u;  // odd pitch: rows land on different banks
-        d.fast         = (uint64_t)d.pitch_dw * d.rows_per_pos <= win_cap_dw;
+    if (d.raw_stride != 0 && bw <= 256) {
+        // the two strides the reference passes are either equal or 2:1 (sub-sampled SAD); anything else: slow path
+        d.k = d.ref_stride == d.raw_stride ? 1u : (d.ref_stride == 2 * d.raw_stride ? 2u : (d.ref_stride % d.raw_stride == 0 ? d.ref_stride / d.raw_stride : 0u));
+        if (d.k) {
+            d.rows_per_pos = (bh - 1) * d.k + 1;
+            d.pitch_dw     = (d.nq + ((bw + 3) >> 2) + 1) | 1u;  // odd pitch: rows land on different banks
+            d.fast         = (uint64_t)d.pitch_dw * d.rows_per_pos <= win_cap_dw && win_cap_dw <= 65536u;
+            d.inv_pitch    = make_inv(d.pitch_dw);
+            d.inv_nq       = make_inv(d.nq);
+        }
     }
+}
+
+// segment that contains flat index `v` of a monotonic per-segment base (lds_dw or item_base)
+template <bool ITEMS> __device__ __forceinline__ uint32_t find_seg(const SearchShared &sh, uint32_t nseg, uint32_t v) {
+    uint32_t lo = 0, hi = nseg;  // invariant: base[lo] <= v < base[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t b   = ITEMS ? sh.seg[mid].item_base : sh.seg[mid].lds_dw;
+        if (v >= b)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
 }
 
 // Exhaustive search of n descriptors (same bw x bh block, `src` = block rows as dwords in LDS).
 // On return sh.best[i] holds the winning key of descriptor i (KEY_NONE if nothing was searched).
-// Must be called by all WG_THREADS threads of the workgroup; contains barriers.
+// Must be called by all WG_THREADS threads of the workgroup; contains barriers.  Descriptor i must have been
+// written by thread i (or be visible through an earlier barrier).
 __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint32_t *__restrict__ src,
                                        uint32_t src_row_dw, uint32_t bw, uint32_t bh, uint32_t *__restrict__ win,
                                        uint32_t win_cap_dw) {
@@ -147,10 +171,10 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
                 const uint32_t step    = ds.skip ? 2u : 1u;
                 const uint32_t free_dw = win_cap_dw - used;
                 // rows staged for nj searched rows: (nj-1)*step + rows_per_pos
-                if ((uint64_t)ds.pitch_dw * ds.rows_per_pos > free_dw)
+                if (ds.pitch_dw * ds.rows_per_pos > free_dw)
                     break;
-                uint32_t max_rows = free_dw / ds.pitch_dw;
-                uint32_t nj       = (max_rows - ds.rows_per_pos) / step + 1;
+                const uint32_t max_rows = fast_div(free_dw, ds.inv_pitch);
+                uint32_t       nj       = (max_rows - ds.rows_per_pos) / step + 1;
                 if (nj > ds.n_srows - j)
                     nj = ds.n_srows - j;
                 SearchSeg &sg = sh.seg[nseg++];
@@ -161,49 +185,63 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
                 items += nj * ds.nq;
                 j += nj;
             }
-            sh.nseg = nseg, sh.nitems = items, sh.next_d = d, sh.next_j = j;
+            sh.nseg = nseg, sh.nitems = items, sh.nstage_dw = used, sh.next_d = d, sh.next_j = j;
         }
         __syncthreads();
         const uint32_t nseg = sh.nseg;
         if (nseg == 0)
             break;
-        // stage
-        for (uint32_t s = 0; s < nseg; s++) {
-            const SearchSeg  sg = sh.seg[s];
-            const SearchDesc ds = sh.desc[sg.d];
-            const uint32_t   sy0   = ds.skip ? 2 * sg.j0 + 1 : sg.j0;
-            const uint32_t   total = sg.nstage * ds.pitch_dw;
-            for (uint32_t idx = tid; idx < total; idx += WG_THREADS) {
-                const uint32_t  row = idx / ds.pitch_dw, i = idx - row * ds.pitch_dw;
-                const uint8_t  *g   = ds.ref + (size_t)(sy0 + row) * ds.raw_stride;
-                const uint32_t  a   = (uint32_t)((uintptr_t)g & 3u);
-                const uint32_t *gb  = (const uint32_t *)(g - a) + i;
-                const uint32_t  lo  = gb[0];
-                const uint32_t  hi  = a ? gb[1] : 0u;
-                win[sg.lds_dw + idx] = __builtin_amdgcn_alignbyte(hi, lo, a);
+        // stage: one flat index space over all segments, four independent loads in flight per thread
+        const uint32_t total = sh.nstage_dw;
+        for (uint32_t base = tid; base < total; base += 4 * WG_THREADS) {
+            uint32_t lo[4], hi[4], al[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t idx = base + u * WG_THREADS;
+                lo[u] = hi[u] = al[u] = 0;
+                if (idx < total) {
+                    const uint32_t   s   = find_seg<false>(sh, nseg, idx);
+                    const SearchSeg  sg  = sh.seg[s];
+                    const SearchDesc &ds = sh.desc[sg.d];
+                    const uint32_t   loc = idx - sg.lds_dw;
+                    const uint32_t   row = fast_div(loc, ds.inv_pitch), i = loc - row * ds.pitch_dw;
+                    const uint32_t   sy0 = ds.skip ? 2 * sg.j0 + 1 : sg.j0;
+                    const uint8_t   *g   = ds.ref + (size_t)(sy0 + row) * ds.raw_stride;
+                    const uint32_t   a   = (uint32_t)((uintptr_t)g & 3u);
+                    const uint32_t  *gb  = (const uint32_t *)(g - a) + i;
+                    lo[u] = gb[0];
+                    hi[u] = a ? gb[1] : 0u;
+                    al[u] = a;
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t idx = base + u * WG_THREADS;
+                if (idx < total)
+                    win[idx] = __builtin_amdgcn_alignbyte(hi[u], lo[u], al[u]);
             }
         }
         __syncthreads();
         // search
         const uint32_t nitems = sh.nitems;
         for (uint32_t item = tid; item < nitems; item += WG_THREADS) {
-            uint32_t s = 0;
-            while (s + 1 < nseg && item >= sh.seg[s + 1].item_base) s++;
+            const uint32_t   s  = find_seg<true>(sh, nseg, item);
             const SearchSeg  sg = sh.seg[s];
-            const SearchDesc ds = sh.desc[sg.d];
+            const SearchDesc &ds = sh.desc[sg.d];
             const uint32_t   li = item - sg.item_base;
-            const uint32_t   jl = li / ds.nq, q = li - jl * ds.nq;
+            const uint32_t   jl = fast_div(li, ds.inv_nq), q = li - jl * ds.nq;
             const uint32_t   step = ds.skip ? 2u : 1u;
             const uint32_t  *w    = win + sg.lds_dw + (jl * step) * ds.pitch_dw + q;
             uint32_t         sad[4];
             quad_sad(w, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad);
             const uint32_t sy = ds.skip ? 2 * (sg.j0 + jl) + 1 : (sg.j0 + jl);
+            const uint32_t saw = (uint32_t)ds.sa_w;
             uint64_t       key = KEY_NONE;
 #pragma unroll
             for (uint32_t p = 0; p < 4; p++) {
                 const uint32_t sx = 4 * q + p;
-                if (sx < (uint32_t)ds.sa_w) {
-                    const uint64_t kk = ((uint64_t)sad[p] << 32) | (sy * (uint32_t)ds.sa_w + sx);
+                if (sx < saw) {
+                    const uint64_t kk = ((uint64_t)sad[p] << 32) | (sy * saw + sx);
                     key               = kk < key ? kk : key;
                 }
             }

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Tuning aid: per-phase time breakdown of me_b64_kernel.  Needs a PROF=1 build of the library
+(make -C svt-av1-mod-by-patman_amd/csrc clean all PROF=1); runs the bench workload once and prints the
+share of each phase (sum over workgroups of lane-0 wall-clock ticks)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "svt-av1-mod-by-patman_amd"))
+PHASES = ["init+stage", "zz_sad", "pre-HME", "HME L0", "HME L1", "HME L2", "centre/prune", "full-pel", "me_prune", "candidates",
+          "distortion+writeback"]
+
+
+def main():
+    import torch  # noqa: F401  (bench imports it; keep the same process layout)
+    sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    sys.path.insert(0, ROOT)
+    from svtav1_hip import abi
+    lib = abi.load()
+    if not hasattr(lib, "svt_hip_debug_me_profile"):
+        raise SystemExit("library was not built with PROF=1")
+    import bench
+    out = (C.c_ulonglong * 16)()
+    bench.main()
+    lib.svt_hip_debug_me_profile(out, 1)
+    tot = sum(out[:11]) or 1
+    res = {n: round(100.0 * out[i] / tot, 2) for i, n in enumerate(PHASES)}
+    res["total_ticks_100MHz"] = int(tot)
+    print(json.dumps({"me_phase_percent": res}))
+
+
+if __name__ == "__main__":
+    main()
