@@ -31,7 +31,8 @@ namespace {
 #define MAX_SAD_VALUE_ (128 * 128 * 255) /* motion_estimation.h:85 */
 #define MAX_U32_ 0xFFFFFFFFu
 
-constexpr uint32_t ME_WIN_DW   = 2048;  // 8 KiB LDS window buffer (bigger windows are searched in several passes)
+constexpr uint32_t ME_WIN_DW   = 4096;  // 16 KiB LDS window buffer of the HME stages (bigger windows: several passes)
+constexpr uint32_t FP_WIN_DW   = 2048;  // full-pel: the first 8 KiB hold the window tile, the second 8 KiB the 8x8 SADs
 constexpr uint32_t TILE_MAXPOS = 64;    // full-pel positions per tile
 
 struct PreHme {
@@ -71,7 +72,6 @@ struct MeLds {
     uint32_t     src_full[64 * 16];
     uint32_t     src_q[32 * 8];
     uint32_t     src_s[16 * 4];
-    uint16_t     sad8[TILE_MAXPOS][64];
     uint64_t     bestkey[85];
     uint32_t     me_dist[85];
 };
@@ -90,13 +90,8 @@ __device__ __forceinline__ uint16_t pic_dist(const SvtHipMeParams &p, int li, in
 __device__ __forceinline__ const uint8_t *plane_at(const SvtHipPlane8 &pl, int x, int y) {
     return pl.buf + (ptrdiff_t)((int)pl.org_y + y) * (ptrdiff_t)pl.stride + (int)pl.org_x + x;
 }
-__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *g) {
-    const uint32_t  a  = (uint32_t)((uintptr_t)g & 3u);
-    const uint32_t *gb = (const uint32_t *)(g - a);
-    const uint32_t  lo = gb[0];
-    const uint32_t  hi = a ? gb[1] : 0u;
-    return __builtin_amdgcn_alignbyte(hi, lo, a);
-}
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *g) { return load_u32_any(g); }
+static_assert(FP_WIN_DW * 4 + TILE_MAXPOS * 64 * 2 <= ME_WIN_DW * 4, "full-pel tile + 8x8 SAD table must fit the window buffer");
 
 // Workgroup-wide SAD between the staged 64x64 source (rows 0,2,4.. when `sub`) and a global block.
 // Result in L.st.wg_sum (valid after the trailing barrier).  width must be a multiple of 4.
@@ -191,13 +186,26 @@ __device__ void best_quadrant(int16_t x[2][2], int16_t y[2][2], uint64_t s[2][2]
 __device__ void fullpel_tile(MeLds &L, const uint8_t *win_org, uint32_t stride, uint32_t tw, uint32_t th, uint32_t order0,
                              uint32_t order_pitch, bool sub) {
     const uint32_t tid = threadIdx.x;
+    uint16_t(*const sad8)[64] = (uint16_t(*)[64])(L.win + FP_WIN_DW);
     const uint32_t nq  = (tw + 3) >> 2;
     const uint32_t pitch = (nq + 16 + 1) | 1u;
     const uint32_t rows  = th + 63;
     // stage window
-    for (uint32_t idx = tid; idx < rows * pitch; idx += WG_THREADS) {
-        const uint32_t r = idx / pitch, i = idx - r * pitch;
-        L.win[idx]       = load_u32_unaligned(win_org + (size_t)r * stride + 4 * i);
+    {
+        const uint32_t total = rows * pitch, inv = make_inv(pitch);
+        for (uint32_t base = tid; base < total; base += 4 * WG_THREADS) {
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t idx = base + u * WG_THREADS;
+                const uint32_t r = fast_div(idx, inv), i = idx - r * pitch;
+                v[u]             = idx < total ? load_u32_unaligned(win_org + (size_t)r * stride + 4 * i) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (base + u * WG_THREADS < total)
+                    L.win[base + u * WG_THREADS] = v[u];
+        }
     }
     __syncthreads();
     // 8x8 SADs: item = (8x8 block b, quad q, row y)
@@ -228,7 +236,7 @@ __device__ void fullpel_tile(MeLds &L, const uint8_t *win_org, uint32_t stride, 
                 uint32_t v = (uint32_t)((acc >> (16 * pp)) & 0xffff);
                 if (sub)
                     v <<= 1;
-                L.sad8[y * tw + x][z] = (uint16_t)v;
+                sad8[y * tw + x][z] = (uint16_t)v;
             }
         }
     }
@@ -245,7 +253,7 @@ __device__ void fullpel_tile(MeLds &L, const uint8_t *win_org, uint32_t stride, 
         if (on) {
             const uint32_t y = pos / tw, x = pos - y * tw;
             ord              = order0 + y * order_pitch + x;
-            const uint2 v2   = *(const uint2 *)&L.sad8[pos][4 * z];
+            const uint2 v2   = *(const uint2 *)&sad8[pos][4 * z];
             const uint32_t c0 = v2.x & 0xffff, c1 = v2.x >> 16, c2 = v2.y & 0xffff, c3 = v2.y >> 16;
             atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 0], ((unsigned long long)c0 << 32) | ord);
             atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 1], ((unsigned long long)c1 << 32) | ord);
@@ -414,7 +422,7 @@ __device__ unsigned long long g_me_prof[16];
     } while (0)
 #endif
 
-__global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
+__global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
     __shared__ MeLds L;
 #ifdef SVT_HIP_ME_PROFILE
     unsigned long long prof_last = wall_clock64();
@@ -530,12 +538,16 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
 
     // ---- prehme_b64 (motion_estimation.c:1792-1866) ----
     if (p.prehme_enable) {
-        // list 1 reads list 0's results (l1 early exit :1771-1781, the tl == 0 mirror :1853-1860): one round per list
-        for (int li = 0; li < nlists; ++li) {
-            const int      nr   = li ? R1 : R0;
-            const int      ri   = (int)(tid >> 1), si = (int)(tid & 1);
-            const bool     mine = tid < 2u * (uint32_t)nr;
-            const bool     searching = tl > 0 || li == 0;  // uniform
+        // List 1 reads list 0's results for the l1 early exit (:1771-1781) and for the tl == 0 mirror (:1853-1860); only
+        // then does it need a round of its own — otherwise all references are searched by one call.
+        const bool split = nlists == 2 && (p.prehme_l1_early_exit || tl == 0);
+        for (int round = 0; round < (split ? 2 : 1); ++round) {
+            const int      f0 = split && round ? R0 : 0, f1 = split ? (round ? nref : R0) : nref;
+            const int      f  = f0 + (int)(tid >> 1), si = (int)(tid & 1);
+            const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+            const uint32_t nd = 2u * (uint32_t)(f1 - f0);
+            const bool     mine = tid < nd;
+            const bool     searching = tl > 0 || round == 0;  // uniform: a tl == 0 second round only mirrors
             int16_t        q_ox = 0, q_oy = 0;
             bool           go = false;
             if (mine) {
@@ -543,7 +555,7 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                 SearchDesc &sd = L.sh.desc[tid];
                 const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
                 sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
-                if (searching) {
+                if (tl > 0 || li == 0) {
                     const uint32_t factor = scaled_dist(pic_dist(p, li, ri));
                     const PreHme   o      = S.ph[0][ri][si];
                     // check_prehme_early_exit (:1763-1789)
@@ -586,8 +598,8 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                 }
             }
             if (searching) {
-                wg_multi_search(L.sh, 2u * (uint32_t)nr, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2),
-                                L.win, ME_WIN_DW);
+                wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
+                                ME_WIN_DW);
                 if (go) {
                     PreHme &d = S.ph[li][ri][si];
                     decode_result(L.sh, tid, hme_sub, &d.sad, &d.col, &d.row);
@@ -1001,8 +1013,8 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
                     // tile height: at most TILE_MAXPOS positions and a window that fits the LDS buffer
                     const uint32_t pitch_t = (((tw + 3) >> 2) + 17) | 1u;
                     uint32_t       th      = tw ? MINV(sh_, MAXV(1u, TILE_MAXPOS / tw)) : 0;
-                    if (th && (th + 63) * pitch_t > ME_WIN_DW)
-                        th = ME_WIN_DW / pitch_t - 63;
+                    if (th && (th + 63) * pitch_t > FP_WIN_DW)
+                        th = FP_WIN_DW / pitch_t - 63;
                     for (uint32_t ty = 0; th && ty < sh_; ty += th)
                         for (uint32_t tx = 0; tx < sw; tx += tw) {
                             const uint32_t cw = MINV(tw, sw - tx), ch = MINV(th, sh_ - ty);
@@ -1121,10 +1133,12 @@ __global__ __launch_bounds__(WG_THREADS) void me_b64_kernel(const SvtHipMeFrameJ
 // tuning aid, only in PROF=1 builds: copies (and optionally clears) the phase counters
 extern "C" __attribute__((visibility("default"))) int32_t svt_hip_debug_me_profile(unsigned long long out[16], int32_t reset) {
     SVT_HIP_CHECK(hipDeviceSynchronize());
-    SVT_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_prof), sizeof(unsigned long long) * 16));
+    SVT_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_prof), sizeof(unsigned long long) * 11));
+    SVT_HIP_CHECK(hipMemcpyFromSymbol(out + 11, HIP_SYMBOL(g_ms_prof), sizeof(unsigned long long) * 5));
     if (reset) {
         unsigned long long z[16] = {};
         SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_me_prof), z, sizeof(z)));
+        SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ms_prof), z, sizeof(unsigned long long) * 8));
     }
     return SVT_HIP_OK;
 }

@@ -20,6 +20,8 @@ namespace dev {
 
 constexpr int      WG_THREADS = 256;
 constexpr int      MAX_SEARCH = 32;
+constexpr uint32_t SEG_ALIGN  = 64;   // segments start on 64-dword boundaries: one wave stages one segment's chunk
+constexpr int      MAX_CHUNKS = 192;  // window buffers up to 48 KiB
 constexpr uint64_t KEY_NONE   = ((uint64_t)0xffffffu << 32) | 0xffffffffu;  // best starts at 0xffffff
 
 struct SearchDesc {
@@ -52,10 +54,30 @@ struct SearchShared {
     uint64_t   best[MAX_SEARCH];
     uint32_t   nseg, nitems, nstage_dw;
     uint32_t   next_d, next_j;  // continuation point of the planner
-    uint32_t   slow_mask;       // descriptors that must take the slow (global memory) path
+    uint8_t    chunk_seg[MAX_CHUNKS];  // segment owning each 64-dword chunk of the window buffer
 };
 
+#ifdef SVT_HIP_ME_PROFILE
+static __device__ unsigned long long g_ms_prof[8];  // plan, stage, search, slow-path/exit (per translation unit)
+#define MS_PHASE(i)                                                 \
+    do {                                                            \
+        if (threadIdx.x == 0) {                                     \
+            const unsigned long long t_ = wall_clock64();           \
+            atomicAdd(&g_ms_prof[i], t_ - ms_last);                 \
+            ms_last = t_;                                           \
+        }                                                           \
+    } while (0)
+#else
+#define MS_PHASE(i) \
+    do {            \
+    } while (0)
+#endif
+
 __device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+// One dword from any byte address: amdhsa runs the memory pipeline in unaligned-access mode, so this is a single
+// global_load_dword (window origins are arbitrary byte offsets into the padded planes).
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *g) { return *(const u32_unaligned *)g; }
 // n / d for n * d < 2^32 with inv = ceil(2^32 / d) (d >= 2; d == 1 is handled by the caller passing inv = 0)
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
 __device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? (uint32_t)((0x100000000ull + d - 1) / d) : 0u; }
@@ -149,6 +171,9 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
                                        uint32_t src_row_dw, uint32_t bw, uint32_t bh, uint32_t *__restrict__ win,
                                        uint32_t win_cap_dw) {
     const uint32_t tid = threadIdx.x;
+#ifdef SVT_HIP_ME_PROFILE
+    unsigned long long ms_last = wall_clock64();
+#endif
     if (tid < n) {
         search_plan_desc(sh.desc[tid], bw, bh, win_cap_dw);
         sh.best[tid] = KEY_NONE;
@@ -159,69 +184,113 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
     __syncthreads();
 
     // ---- fast path: passes of (stage -> search) until every descriptor row has been searched ----
+    bool first = true;
     for (;;) {
-        if (tid == 0) {
-            uint32_t nseg = 0, used = 0, items = 0, d = sh.next_d, j = sh.next_j;
-            while (d < n && nseg < MAX_SEARCH) {
-                const SearchDesc &ds = sh.desc[d];
-                if (!ds.fast || j >= ds.n_srows) {
-                    d++, j = 0;
-                    continue;
+        // plan.  Common case: everything fits the window buffer at once -> the first wave lays the segments out with a
+        // prefix sum (one lane per descriptor); otherwise lane 0 packs as many rows as fit, pass after pass.
+        bool planned = false;
+        if (first) {
+            if (tid < 64) {
+                uint32_t need = 0, items = 0, nstage = 0;
+                if (tid < n) {
+                    const SearchDesc &ds = sh.desc[tid];
+                    if (ds.fast && ds.n_srows) {
+                        nstage = (ds.n_srows - 1) * (ds.skip ? 2u : 1u) + ds.rows_per_pos;
+                        need   = (nstage * ds.pitch_dw + SEG_ALIGN - 1) & ~(SEG_ALIGN - 1);
+                        items  = ds.n_srows * ds.nq;
+                    }
                 }
-                const uint32_t step    = ds.skip ? 2u : 1u;
-                const uint32_t free_dw = win_cap_dw - used;
-                // rows staged for nj searched rows: (nj-1)*step + rows_per_pos
-                if (ds.pitch_dw * ds.rows_per_pos > free_dw)
-                    break;
-                const uint32_t max_rows = fast_div(free_dw, ds.inv_pitch);
-                uint32_t       nj       = (max_rows - ds.rows_per_pos) / step + 1;
-                if (nj > ds.n_srows - j)
-                    nj = ds.n_srows - j;
-                SearchSeg &sg = sh.seg[nseg++];
-                sg.d = d, sg.j0 = j, sg.nj = nj, sg.lds_dw = used;
-                sg.nstage    = (nj - 1) * step + ds.rows_per_pos;
-                sg.item_base = items;
-                used += sg.nstage * ds.pitch_dw;
-                items += nj * ds.nq;
-                j += nj;
+                uint32_t need_in = need, items_in = items, cnt_in = need ? 1u : 0u;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t a = __shfl_up(need_in, off, 64), b2 = __shfl_up(items_in, off, 64), c = __shfl_up(cnt_in, off, 64);
+                    if ((int)tid >= off)
+                        need_in += a, items_in += b2, cnt_in += c;
+                }
+                const uint32_t total = __shfl(need_in, 63, 64);
+                if (total <= win_cap_dw) {
+                    if (need) {
+                        const uint32_t sidx = cnt_in - 1, off0 = need_in - need;
+                        SearchSeg     &sg   = sh.seg[sidx];
+                        sg.d = tid, sg.j0 = 0, sg.nj = sh.desc[tid].n_srows, sg.lds_dw = off0, sg.nstage = nstage;
+                        sg.item_base = items_in - items;
+                        for (uint32_t c = off0 / SEG_ALIGN; c < (off0 + need) / SEG_ALIGN; c++) sh.chunk_seg[c] = (uint8_t)sidx;
+                    }
+                    if (tid == 63)
+                        sh.nseg = cnt_in, sh.nitems = items_in, sh.nstage_dw = total, sh.next_d = n, sh.next_j = 0;
+                    planned = true;  // wave-uniform
+                }
             }
-            sh.nseg = nseg, sh.nitems = items, sh.nstage_dw = used, sh.next_d = d, sh.next_j = j;
+            planned = __syncthreads_or(planned);
+            first   = false;
         }
-        __syncthreads();
+        const bool onepass = planned;
+        if (!planned) {
+            if (tid == 0) {
+                uint32_t nseg = 0, used = 0, items = 0, d = sh.next_d, j = sh.next_j;
+                while (d < n && nseg < MAX_SEARCH) {
+                    const SearchDesc &ds = sh.desc[d];
+                    if (!ds.fast || j >= ds.n_srows) {
+                        d++, j = 0;
+                        continue;
+                    }
+                    const uint32_t step    = ds.skip ? 2u : 1u;
+                    const uint32_t free_dw = win_cap_dw - used;
+                    // rows staged for nj searched rows: (nj-1)*step + rows_per_pos
+                    if (ds.pitch_dw * ds.rows_per_pos > free_dw)
+                        break;
+                    const uint32_t max_rows = fast_div(free_dw, ds.inv_pitch);
+                    uint32_t       nj       = (max_rows - ds.rows_per_pos) / step + 1;
+                    if (nj > ds.n_srows - j)
+                        nj = ds.n_srows - j;
+                    SearchSeg &sg = sh.seg[nseg];
+                    sg.d = d, sg.j0 = j, sg.nj = nj, sg.lds_dw = used;
+                    sg.nstage    = (nj - 1) * step + ds.rows_per_pos;
+                    sg.item_base = items;
+                    const uint32_t need = (sg.nstage * ds.pitch_dw + SEG_ALIGN - 1) & ~(SEG_ALIGN - 1);
+                    for (uint32_t c = used / SEG_ALIGN; c < (used + need) / SEG_ALIGN && c < (uint32_t)MAX_CHUNKS; c++)
+                        sh.chunk_seg[c] = (uint8_t)nseg;
+                    nseg++;
+                    used = used + need < win_cap_dw ? used + need : win_cap_dw;
+                    items += nj * ds.nq;
+                    j += nj;
+                }
+                sh.nseg = nseg, sh.nitems = items, sh.nstage_dw = used, sh.next_d = d, sh.next_j = j;
+            }
+            __syncthreads();
+        }
+        MS_PHASE(0);
         const uint32_t nseg = sh.nseg;
         if (nseg == 0)
             break;
-        // stage: one flat index space over all segments, four independent loads in flight per thread
+        // stage: one flat index space over the (64-dword aligned) segments; a wave always works inside one segment,
+        // so the descriptor reads are broadcasts; four independent loads in flight per thread
         const uint32_t total = sh.nstage_dw;
         for (uint32_t base = tid; base < total; base += 4 * WG_THREADS) {
-            uint32_t lo[4], hi[4], al[4];
+            uint32_t v[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
                 const uint32_t idx = base + u * WG_THREADS;
-                lo[u] = hi[u] = al[u] = 0;
+                v[u]               = 0;
                 if (idx < total) {
-                    const uint32_t   s   = find_seg<false>(sh, nseg, idx);
-                    const SearchSeg  sg  = sh.seg[s];
-                    const SearchDesc &ds = sh.desc[sg.d];
-                    const uint32_t   loc = idx - sg.lds_dw;
-                    const uint32_t   row = fast_div(loc, ds.inv_pitch), i = loc - row * ds.pitch_dw;
-                    const uint32_t   sy0 = ds.skip ? 2 * sg.j0 + 1 : sg.j0;
-                    const uint8_t   *g   = ds.ref + (size_t)(sy0 + row) * ds.raw_stride;
-                    const uint32_t   a   = (uint32_t)((uintptr_t)g & 3u);
-                    const uint32_t  *gb  = (const uint32_t *)(g - a) + i;
-                    lo[u] = gb[0];
-                    hi[u] = a ? gb[1] : 0u;
-                    al[u] = a;
+                    const SearchSeg  &sg  = sh.seg[sh.chunk_seg[idx / SEG_ALIGN]];
+                    const SearchDesc &ds  = sh.desc[sg.d];
+                    const uint32_t    loc = idx - sg.lds_dw;
+                    const uint32_t    row = fast_div(loc, ds.inv_pitch), i = loc - row * ds.pitch_dw;
+                    const uint32_t    sy0 = ds.skip ? 2 * sg.j0 + 1 : sg.j0;
+                    if (row < sg.nstage)
+                        v[u] = load_u32_any(ds.ref + (size_t)(sy0 + row) * ds.raw_stride + 4 * i);
                 }
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
                 const uint32_t idx = base + u * WG_THREADS;
                 if (idx < total)
-                    win[idx] = __builtin_amdgcn_alignbyte(hi[u], lo[u], al[u]);
+                    win[idx] = v[u];
             }
         }
         __syncthreads();
+        MS_PHASE(1);
         // search
         const uint32_t nitems = sh.nitems;
         for (uint32_t item = tid; item < nitems; item += WG_THREADS) {
@@ -249,6 +318,9 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
                 atomicMin((unsigned long long *)&sh.best[sg.d], (unsigned long long)key);
         }
         __syncthreads();
+        MS_PHASE(2);
+        if (onepass)
+            break;
     }
 
     // ---- slow path (window does not fit LDS, or strides are unrelated): straight from global memory ----

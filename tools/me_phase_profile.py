@@ -29,6 +29,7 @@ def main():
     tot = sum(out[:11]) or 1
     res = {n: round(100.0 * out[i] / tot, 2) for i, n in enumerate(PHASES)}
     res["total_ticks_100MHz"] = int(tot)
+    res["inside_wg_multi_search_percent_of_total"] = {n: round(100.0 * out[11 + i] / tot, 2) for i, n in enumerate(("plan", "stage", "search"))}
     print(json.dumps({"me_phase_percent": res}))
 
 
