@@ -32,8 +32,7 @@ namespace {
 #define MAX_U32_ 0xFFFFFFFFu
 
 constexpr uint32_t ME_WIN_DW   = 4096;  // 16 KiB LDS window buffer of the HME stages (bigger windows: several passes)
-constexpr uint32_t FP_WIN_DW   = 2048;  // full-pel: the first 8 KiB hold the window tile, the second 8 KiB the 8x8 SADs
-constexpr uint32_t TILE_MAXPOS = 64;    // full-pel positions per tile
+constexpr uint32_t FP_TILE_W   = 64;    // widest full-pel tile staged at once (positions)
 
 struct PreHme {
     uint64_t sad;
@@ -60,6 +59,8 @@ struct B64State {
     // integer search of the current reference
     int16_t  xc, yc, sw, sh, ox, oy;
     int32_t  do_centre, need_zero_sad, need_hme_sad;
+    int16_t  stx, sty, stw, sth;  // block of positions whose window is currently staged (full-pel)
+    int32_t  staged, restage;
     uint32_t zero_sad, hme_mv_sad;
     uint32_t first_ref_sad64;        // p_sb_best_sad[0][0][0] (read by later references, :1359)
     uint64_t me_sad_sum[NL][NR];     // sum of the 64 best 8x8 SADs per reference (me_prune_ref, :1605-1611)
@@ -68,8 +69,8 @@ struct B64State {
 struct MeLds {
     SearchShared sh;
     B64State     st;
-    uint32_t     win[ME_WIN_DW];
-    uint32_t     src_full[64 * 16];
+    alignas(16) uint32_t win[ME_WIN_DW];
+    alignas(16) uint32_t src_full[64 * 16];
     uint32_t     src_q[32 * 8];
     uint32_t     src_s[16 * 4];
     uint64_t     bestkey[85];
@@ -91,7 +92,6 @@ __device__ __forceinline__ const uint8_t *plane_at(const SvtHipPlane8 &pl, int x
     return pl.buf + (ptrdiff_t)((int)pl.org_y + y) * (ptrdiff_t)pl.stride + (int)pl.org_x + x;
 }
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *g) { return load_u32_any(g); }
-static_assert(FP_WIN_DW * 4 + TILE_MAXPOS * 64 * 2 <= ME_WIN_DW * 4, "full-pel tile + 8x8 SAD table must fit the window buffer");
 
 // Workgroup-wide SAD between the staged 64x64 source (rows 0,2,4.. when `sub`) and a global block.
 // Result in L.st.wg_sum (valid after the trailing barrier).  width must be a multiple of 4.
@@ -176,100 +176,125 @@ __device__ void best_quadrant(int16_t x[2][2], int16_t y[2][2], uint64_t s[2][2]
     if (s[1][1] < *bs) *bx = x[1][1], *by = y[1][1], *bs = s[1][1];
 }
 
+// Final search-window clamp of integer_search_b64 (motion_estimation.c:1442-1561): window of sw x sh positions centred
+// on (xc, yc), clipped to the padded reference; returns its origin relative to the b64 and the clipped size.
+__device__ void clamp_me_window(int16_t xc, int16_t yc, int16_t ox_b, int16_t oy_b, int16_t W, int16_t H, int16_t pad, int16_t *psw,
+                                int16_t *psh, int16_t *pox, int16_t *poy) {
+    int16_t sw = *psw, sh_ = *psh;
+    int16_t ox = (int16_t)(xc - (sw >> 1)), oy = (int16_t)(yc - (sh_ >> 1));
+    ox  = ((ox_b + ox) < -pad) ? (int16_t)(-pad - ox_b) : ox;
+    sw  = ((ox_b + ox) < -pad) ? (int16_t)(sw - (-pad - (ox_b + ox))) : sw;
+    ox  = ((ox_b + ox) > W - 1) ? (int16_t)(ox - ((ox_b + ox) - (W - 1))) : ox;
+    sw  = ((ox_b + ox + sw) > W) ? (int16_t)MAXV(1, sw - ((ox_b + ox + sw) - W)) : sw;
+    sw  = (sw < 8) ? sw : (int16_t)(sw & ~0x07);
+    oy  = ((oy_b + oy) < -pad) ? (int16_t)(-pad - oy_b) : oy;
+    sh_ = ((oy_b + oy) < -pad) ? (int16_t)(sh_ - (-pad - (oy_b + oy))) : sh_;
+    oy  = ((oy_b + oy) > H - 1) ? (int16_t)(oy - ((oy_b + oy) - (H - 1))) : oy;
+    sh_ = ((oy_b + oy + sh_) > H) ? (int16_t)MAXV(1, sh_ - ((oy_b + oy + sh_) - H)) : sh_;
+    *psw = sw, *psh = sh_, *pox = ox, *poy = oy;
+}
+
 // ------------------------------------------------------------------------------------------------
-// full-pel 85-PU search of one tile of positions (open_loop_me_fullpel_search_sblock semantics).
-//   win_org : global pointer of the window sample that tile position (0,0) puts under source (0,0)
-//   tw x th : tile size in positions (tw*th <= TILE_MAXPOS)
-//   order0, order_pitch : raster order key of tile position (x,y) = order0 + y*order_pitch + x
-// Updates L.bestkey[85] (sad<<32 | order) with atomic minima => first minimum in raster order wins.
+// full-pel 85-PU search (open_loop_me_fullpel_search_sblock semantics, motion_estimation.c:428-560 with the ext_*
+// SAD pyramids of :210-425).
+//
+// fp_stage puts the window of a tw x th block of search positions into L.win: (th + 63) rows of `fp_pitch(tw)` dwords,
+// row 0 / byte 0 = the sample that position (0,0) puts under source sample (0,0).
+// fp_search evaluates the cw x ch positions whose top-left one sits at (x0, y0) of the staged block (x0 % 4 == 0).
+// Work item = (quad of 4 horizontally adjacent positions, one 16x16 block of the source): the four 8x8 SADs of the
+// 16x16 are accumulated in registers with v_qsad_pk_u16_u8, the 16x16 / 32x32 / 64x64 sums come from shuffles over the
+// 16 lanes that share the quad, each lane keeps the minimum over its four positions and only then touches the 85
+// (sad << 32 | raster order) keys in LDS => first minimum in raster order wins, as in the reference.
 // ------------------------------------------------------------------------------------------------
-__device__ void fullpel_tile(MeLds &L, const uint8_t *win_org, uint32_t stride, uint32_t tw, uint32_t th, uint32_t order0,
-                             uint32_t order_pitch, bool sub) {
-    const uint32_t tid = threadIdx.x;
-    uint16_t(*const sad8)[64] = (uint16_t(*)[64])(L.win + FP_WIN_DW);
-    const uint32_t nq  = (tw + 3) >> 2;
-    const uint32_t pitch = (nq + 16 + 1) | 1u;
-    const uint32_t rows  = th + 63;
-    // stage window
-    {
-        const uint32_t total = rows * pitch, inv = make_inv(pitch);
-        for (uint32_t base = tid; base < total; base += 4 * WG_THREADS) {
-            uint32_t v[4];
+__device__ __forceinline__ uint32_t fp_pitch(uint32_t tw) { return (((tw + 3) >> 2) + 17) | 1u; }
+
+__device__ void fp_stage(MeLds &L, const uint8_t *win_org, uint32_t stride, uint32_t tw, uint32_t th) {
+    const uint32_t tid = threadIdx.x, pitch = fp_pitch(tw), total = (th + 63) * pitch, inv = make_inv(pitch);
+    for (uint32_t base = tid; base < total; base += 4 * WG_THREADS) {
+        uint32_t v[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t idx = base + u * WG_THREADS;
-                const uint32_t r = fast_div(idx, inv), i = idx - r * pitch;
-                v[u]             = idx < total ? load_u32_unaligned(win_org + (size_t)r * stride + 4 * i) : 0u;
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++)
-                if (base + u * WG_THREADS < total)
-                    L.win[base + u * WG_THREADS] = v[u];
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t idx = base + u * WG_THREADS;
+            const uint32_t r = fast_div(idx, inv), i = idx - r * pitch;
+            v[u]             = idx < total ? load_u32_unaligned(win_org + (size_t)r * stride + 4 * i) : 0u;
         }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+            if (base + u * WG_THREADS < total)
+                L.win[base + u * WG_THREADS] = v[u];
     }
     __syncthreads();
-    // 8x8 SADs: item = (8x8 block b, quad q, row y)
-    const uint8_t  z16[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
-    const uint32_t nitems  = 64 * nq * th;
-    const uint32_t rstep   = sub ? 2 : 1;
-    for (uint32_t item = tid; item < nitems; item += WG_THREADS) {
-        const uint32_t b = item & 63, rest = item >> 6;
-        const uint32_t q = rest % nq, y = rest / nq;
-        const uint32_t by = b >> 3, bx = b & 7;
-        const uint32_t *s = &L.src_full[(8 * by) * 16 + 2 * bx];
-        const uint32_t *w = &L.win[(y + 8 * by) * pitch + q + 2 * bx];
-        uint64_t        acc = 0;
+}
+
+__device__ void fp_search(MeLds &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint32_t cw, uint32_t ch, uint32_t order0,
+                          uint32_t order_pitch, bool sub) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nq = (cw + 3) >> 2, nitems = nq * ch * 16, inv_nq = make_inv(nq);
+    const uint32_t z = tid & 15, zy = z >> 2, zx = z & 3;                          // this lane's 16x16 block (raster)
+    const uint32_t zo = 4 * ((zy >> 1) * 2 + (zx >> 1)) + (zy & 1) * 2 + (zx & 1);  // its z-order index (A.1)
+    const uint32_t *s = &L.src_full[(16 * zy) * 16 + 4 * zx];
+    const uint64_t  none = ~(uint64_t)0;
+    for (uint32_t base = 0; base < nitems; base += WG_THREADS) {
+        const uint32_t item = base + tid;
+        const bool     on   = item < nitems;  // uniform over each group of 16 lanes
+        const uint32_t qi = on ? item >> 4 : 0, y = fast_div(qi, inv_nq), q = qi - y * nq;
+        const uint32_t *w = &L.win[(y0 + y + 16 * zy) * pitch + (x0 >> 2) + q + 4 * zx];
+        uint64_t        a00 = 0, a01 = 0, a10 = 0, a11 = 0;
 #pragma unroll
-        for (uint32_t r = 0; r < 8; r += 1) {
+        for (uint32_t r = 0; r < 16; r++) {
             if (sub && (r & 1))
                 continue;
-            const uint32_t d0 = w[r * pitch], d1 = w[r * pitch + 1], d2 = w[r * pitch + 2];
-            acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d0, d1), s[r * 16], acc);
-            acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d1, d2), s[r * 16 + 1], acc);
-        }
-        (void)rstep;
-        const uint32_t z = 4 * z16[4 * (by >> 1) + (bx >> 1)] + 2 * (by & 1) + (bx & 1);
-#pragma unroll
-        for (uint32_t pp = 0; pp < 4; pp++) {
-            const uint32_t x = 4 * q + pp;
-            if (x < tw) {
-                uint32_t v = (uint32_t)((acc >> (16 * pp)) & 0xffff);
-                if (sub)
-                    v <<= 1;
-                sad8[y * tw + x][z] = (uint16_t)v;
+            const uint32_t d0 = w[r * pitch], d1 = w[r * pitch + 1], d2 = w[r * pitch + 2], d3 = w[r * pitch + 3], d4 = w[r * pitch + 4];
+            const uint4    sv = *(const uint4 *)&s[r * 16];
+            if (r < 8) {
+                a00 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d0, d1), sv.x, a00);
+                a00 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d1, d2), sv.y, a00);
+                a01 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d2, d3), sv.z, a01);
+                a01 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d3, d4), sv.w, a01);
+            } else {
+                a10 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d0, d1), sv.x, a10);
+                a10 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d1, d2), sv.y, a10);
+                a11 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d2, d3), sv.z, a11);
+                a11 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d3, d4), sv.w, a11);
             }
         }
-    }
-    __syncthreads();
-    // pyramid sums + arg-min: item = (position, 16x16 slot); 16 lanes per position
-    const uint32_t npos = tw * th;
-    const uint32_t iters = (npos * 16 + WG_THREADS - 1) / WG_THREADS;
-    for (uint32_t it = 0; it < iters; it++) {
-        const uint32_t item = it * WG_THREADS + tid;
-        const uint32_t pos = item >> 4, z = item & 15;
-        const bool     on  = pos < npos;
-        uint32_t       s16 = 0;
-        uint64_t       ord = 0;
-        if (on) {
-            const uint32_t y = pos / tw, x = pos - y * tw;
-            ord              = order0 + y * order_pitch + x;
-            const uint2 v2   = *(const uint2 *)&sad8[pos][4 * z];
-            const uint32_t c0 = v2.x & 0xffff, c1 = v2.x >> 16, c2 = v2.y & 0xffff, c3 = v2.y >> 16;
-            atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 0], ((unsigned long long)c0 << 32) | ord);
-            atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 1], ((unsigned long long)c1 << 32) | ord);
-            atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 2], ((unsigned long long)c2 << 32) | ord);
-            atomicMin((unsigned long long *)&L.bestkey[21 + 4 * z + 3], ((unsigned long long)c3 << 32) | ord);
-            s16 = c0 + c1 + c2 + c3;
-            atomicMin((unsigned long long *)&L.bestkey[5 + z], ((unsigned long long)s16 << 32) | ord);
+        uint64_t k8[4] = {none, none, none, none}, k16 = none, k32 = none, k64 = none;
+#pragma unroll
+        for (uint32_t pp = 0; pp < 4; pp++) {
+            uint32_t c0 = (uint32_t)(a00 >> (16 * pp)) & 0xffff, c1 = (uint32_t)(a01 >> (16 * pp)) & 0xffff;
+            uint32_t c2 = (uint32_t)(a10 >> (16 * pp)) & 0xffff, c3 = (uint32_t)(a11 >> (16 * pp)) & 0xffff;
+            if (sub)
+                c0 <<= 1, c1 <<= 1, c2 <<= 1, c3 <<= 1;
+            const uint32_t s16 = c0 + c1 + c2 + c3;
+            uint32_t       s32 = s16 + __shfl_xor(s16, 1, 64);
+            s32 += __shfl_xor(s32, 4, 64);
+            uint32_t s64 = s32 + __shfl_xor(s32, 2, 64);
+            s64 += __shfl_xor(s64, 8, 64);
+            const uint32_t x = 4 * q + pp;
+            if (on && x < cw) {
+                const uint64_t ord = order0 + y * order_pitch + x;
+                uint64_t       k;
+                k = ((uint64_t)c0 << 32) | ord, k8[0] = k < k8[0] ? k : k8[0];
+                k = ((uint64_t)c1 << 32) | ord, k8[1] = k < k8[1] ? k : k8[1];
+                k = ((uint64_t)c2 << 32) | ord, k8[2] = k < k8[2] ? k : k8[2];
+                k = ((uint64_t)c3 << 32) | ord, k8[3] = k < k8[3] ? k : k8[3];
+                k = ((uint64_t)s16 << 32) | ord, k16 = k < k16 ? k : k16;
+                k = ((uint64_t)s32 << 32) | ord, k32 = k < k32 ? k : k32;
+                k = ((uint64_t)s64 << 32) | ord, k64 = k < k64 ? k : k64;
+            }
         }
-        uint32_t s32 = s16 + __shfl_xor(s16, 1, 64);
-        s32 += __shfl_xor(s32, 2, 64);
-        uint32_t s64 = s32 + __shfl_xor(s32, 4, 64);
-        s64 += __shfl_xor(s64, 8, 64);
-        if (on && (z & 3) == 0)
-            atomicMin((unsigned long long *)&L.bestkey[1 + (z >> 2)], ((unsigned long long)s32 << 32) | ord);
-        if (on && z == 0)
-            atomicMin((unsigned long long *)&L.bestkey[0], ((unsigned long long)s64 << 32) | ord);
+        if (on) {
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++)
+                if (k8[c] != none)
+                    atomicMin((unsigned long long *)&L.bestkey[21 + 4 * zo + c], (unsigned long long)k8[c]);
+            if (k16 != none)
+                atomicMin((unsigned long long *)&L.bestkey[5 + zo], (unsigned long long)k16);
+            if ((zo & 3) == 0 && k32 != none)
+                atomicMin((unsigned long long *)&L.bestkey[1 + (zo >> 2)], (unsigned long long)k32);
+            if (z == 0 && k64 != none)
+                atomicMin((unsigned long long *)&L.bestkey[0], (unsigned long long)k64);
+        }
     }
     __syncthreads();
 }
@@ -958,69 +983,81 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
                     }
                     S.sw = sw, S.sh = sh_;
                     S.do_centre = p.me_8x8_var_enabled && (sw * sh_ > 24);
+                    S.staged    = 0;
+                    if (S.do_centre) {
+                        // Stage once for the centre probe AND the search: the block of positions spanned by the centre and by
+                        // the window these settings give (the 8x8-variance rule below can only shrink it around the same
+                        // centre).  Origin congruent to the centre mod 4 keeps both dword-aligned in the staged tile.
+                        int16_t cw_ = sw, chh = sh_, cx0, cy0;
+                        clamp_me_window(S.xc, S.yc, ox_b, oy_b, W, H, pad, &cw_, &chh, &cx0, &cy0);
+                        int x0 = MINV((int)S.xc, (int)cx0), x1 = MAXV((int)S.xc + 1, (int)cx0 + (cw_ > 0 ? cw_ : 0));
+                        int y0 = MINV((int)S.yc, (int)cy0), y1 = MAXV((int)S.yc + 1, (int)cy0 + (chh > 0 ? chh : 0));
+                        x0 -= (x0 - (int)S.xc) & 3;
+                        if (x1 - x0 > (int)FP_TILE_W || (uint32_t)(y1 - y0 + 63) * fp_pitch((uint32_t)(x1 - x0)) > ME_WIN_DW)
+                            x0 = S.xc, x1 = S.xc + 1, y0 = S.yc, y1 = S.yc + 1;  // does not fit: the centre alone
+                        S.stx = (int16_t)x0, S.sty = (int16_t)y0, S.stw = (int16_t)(x1 - x0), S.sth = (int16_t)(y1 - y0);
+                        S.staged = 1;
+                    }
                 }
                 if (tid < 85)
                     L.bestkey[tid] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
                 __syncthreads();
                 if (S.do_centre) {
-                    fullpel_tile(L, plane_at(rp, ox_b + S.xc, oy_b + S.yc), rp.stride, 1, 1, 0, 1, me_sub);
-                    if (tid == 0) {
-                        int16_t        sw = S.sw, sh_ = S.sh;
+                    fp_stage(L, plane_at(rp, ox_b + S.stx, oy_b + S.sty), rp.stride, (uint32_t)S.stw, (uint32_t)S.sth);
+                    fp_search(L, fp_pitch((uint32_t)S.stw), (uint32_t)(S.xc - S.stx), (uint32_t)(S.yc - S.sty), 1, 1, 0, 1, me_sub);
+                    if (tid < 64) {  // variance of the 64 8x8 SADs at the centre (:1393-1441)
+                        const uint32_t v    = (uint32_t)(L.bestkey[21 + tid] >> 32);
                         const uint32_t mean = (uint32_t)(L.bestkey[0] >> 32) / 64;
-                        uint32_t       ssq  = 0;
-                        for (int i = 0; i < 64; i++) {
-                            const int32_t d = (int32_t)(uint32_t)(L.bestkey[21 + i] >> 32) - (int32_t)mean;
-                            ssq += (uint32_t)(d * d);
+                        const int32_t  dv   = (int32_t)v - (int32_t)mean;
+                        const uint32_t ssq  = wave_sum((uint32_t)(dv * dv));
+                        if (tid == 0) {
+                            int16_t        sw = S.sw, sh_ = S.sh;
+                            const uint32_t var = ssq / 64;
+                            if (var > p.me_sr_mult2_th) {
+                                sw  = (int16_t)((MAXV(1, sw * 3 / 2) + 7) & ~0x7);
+                                sh_ = (int16_t)MAXV(1, sh_ * 3 / 2);
+                            }
+                            if (var < p.me_sr_div4_th) {
+                                sw  = (int16_t)((MAXV(1, sw >> 2) + 7) & ~0x7);
+                                sh_ = (int16_t)MAXV(1, sh_ >> 2);
+                                sh_ = (int16_t)MAXV(3, sh_);
+                            } else if (var < p.me_sr_div2_th) {
+                                sw  = (int16_t)((MINV(sw, sw >> 1) + 7) & ~0x7);
+                                sh_ = (int16_t)MINV(sh_, sh_ >> 1);
+                                sh_ = (int16_t)MAXV(3, sh_);
+                            }
+                            S.sw = sw, S.sh = sh_;
                         }
-                        const uint32_t var = ssq / 64;
-                        if (var > p.me_sr_mult2_th) {
-                            sw  = (int16_t)((MAXV(1, sw * 3 / 2) + 7) & ~0x7);
-                            sh_ = (int16_t)MAXV(1, sh_ * 3 / 2);
-                        }
-                        if (var < p.me_sr_div4_th) {
-                            sw  = (int16_t)((MAXV(1, sw >> 2) + 7) & ~0x7);
-                            sh_ = (int16_t)MAXV(1, sh_ >> 2);
-                            sh_ = (int16_t)MAXV(3, sh_);
-                        } else if (var < p.me_sr_div2_th) {
-                            sw  = (int16_t)((MINV(sw, sw >> 1) + 7) & ~0x7);
-                            sh_ = (int16_t)MINV(sh_, sh_ >> 1);
-                            sh_ = (int16_t)MAXV(3, sh_);
-                        }
-                        S.sw = sw, S.sh = sh_;
                     }
                     __syncthreads();
                 }
                 // part 3: final window (:1442-1561)
                 if (tid == 0) {
-                    int16_t sw = S.sw, sh_ = S.sh;
-                    int16_t ox = (int16_t)(S.xc - (sw >> 1)), oy = (int16_t)(S.yc - (sh_ >> 1));
-                    ox  = ((ox_b + ox) < -pad) ? (int16_t)(-pad - ox_b) : ox;
-                    sw  = ((ox_b + ox) < -pad) ? (int16_t)(sw - (-pad - (ox_b + ox))) : sw;
-                    ox  = ((ox_b + ox) > W - 1) ? (int16_t)(ox - ((ox_b + ox) - (W - 1))) : ox;
-                    sw  = ((ox_b + ox + sw) > W) ? (int16_t)MAXV(1, sw - ((ox_b + ox + sw) - W)) : sw;
-                    sw  = (sw < 8) ? sw : (int16_t)(sw & ~0x07);
-                    oy  = ((oy_b + oy) < -pad) ? (int16_t)(-pad - oy_b) : oy;
-                    sh_ = ((oy_b + oy) < -pad) ? (int16_t)(sh_ - (-pad - (oy_b + oy))) : sh_;
-                    oy  = ((oy_b + oy) > H - 1) ? (int16_t)(oy - ((oy_b + oy) - (H - 1))) : oy;
-                    sh_ = ((oy_b + oy + sh_) > H) ? (int16_t)MAXV(1, sh_ - ((oy_b + oy + sh_) - H)) : sh_;
+                    int16_t sw = S.sw, sh_ = S.sh, ox, oy;
+                    clamp_me_window(S.xc, S.yc, ox_b, oy_b, W, H, pad, &sw, &sh_, &ox, &oy);
                     S.sw = sw, S.sh = sh_, S.ox = ox, S.oy = oy;
+                    // reuse the staged block if the final window lies inside it, dword-aligned
+                    S.restage = !(S.staged && ox >= S.stx && oy >= S.sty && ox + (sw > 0 ? sw : 0) <= S.stx + S.stw &&
+                                  oy + (sh_ > 0 ? sh_ : 0) <= S.sty + S.sth && ((ox - S.stx) & 3) == 0);
                 }
                 __syncthreads();
                 {
                     const int      ox = S.ox, oy = S.oy;
                     const uint32_t sw = (uint32_t)(S.sw > 0 ? S.sw : 0), sh_ = (uint32_t)(S.sh > 0 ? S.sh : 0);
-                    const uint32_t tw = sw < 32 ? sw : 32;
-                    // tile height: at most TILE_MAXPOS positions and a window that fits the LDS buffer
-                    const uint32_t pitch_t = (((tw + 3) >> 2) + 17) | 1u;
-                    uint32_t       th      = tw ? MINV(sh_, MAXV(1u, TILE_MAXPOS / tw)) : 0;
-                    if (th && (th + 63) * pitch_t > FP_WIN_DW)
-                        th = FP_WIN_DW / pitch_t - 63;
-                    for (uint32_t ty = 0; th && ty < sh_; ty += th)
-                        for (uint32_t tx = 0; tx < sw; tx += tw) {
-                            const uint32_t cw = MINV(tw, sw - tx), ch = MINV(th, sh_ - ty);
-                            fullpel_tile(L, plane_at(rp, ox_b + ox + (int)tx, oy_b + oy + (int)ty), rp.stride, cw, ch,
-                                         1 + ty * sw + tx, sw, me_sub);
-                        }
+                    if (!S.restage) {
+                        fp_search(L, fp_pitch((uint32_t)S.stw), (uint32_t)(ox - S.stx), (uint32_t)(oy - S.sty), sw, sh_, 1, sw, me_sub);
+                    } else {
+                        // tiles that fit the window buffer
+                        const uint32_t tw = sw < FP_TILE_W ? sw : FP_TILE_W;
+                        const uint32_t pitch_t = fp_pitch(tw);
+                        uint32_t       th      = tw ? MINV(sh_, ME_WIN_DW / pitch_t - 63) : 0;
+                        for (uint32_t ty = 0; th && ty < sh_; ty += th)
+                            for (uint32_t tx = 0; tx < sw; tx += tw) {
+                                const uint32_t cw = MINV(tw, sw - tx), ch = MINV(th, sh_ - ty);
+                                fp_stage(L, plane_at(rp, ox_b + ox + (int)tx, oy_b + oy + (int)ty), rp.stride, cw, ch);
+                                fp_search(L, fp_pitch(cw), 0, 0, cw, ch, 1 + ty * sw + tx, sw, me_sub);
+                            }
+                    }
                     // keys -> p_sb_best_sad / p_sb_best_mv of this reference
                     uint32_t my_sad = 0;
                     if (tid < 85) {
