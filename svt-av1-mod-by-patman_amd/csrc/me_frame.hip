@@ -71,8 +71,8 @@ struct MeLds {
     B64State     st;
     alignas(16) uint32_t win[ME_WIN_DW];
     alignas(16) uint32_t src_full[64 * 16];
-    uint32_t     src_q[32 * 8];
-    uint32_t     src_s[16 * 4];
+    alignas(16) uint32_t src_q[32 * 8];
+    alignas(16) uint32_t src_s[16 * 4];
     uint64_t     bestkey[85];
     uint32_t     me_dist[85];
 };
@@ -226,14 +226,20 @@ __device__ void fp_stage(MeLds &L, const uint8_t *win_org, uint32_t stride, uint
     __syncthreads();
 }
 
+// v + (v of the lane selected by a DPP control); all lanes of the 16-lane row take part
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
 __device__ void fp_search(MeLds &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint32_t cw, uint32_t ch, uint32_t order0,
                           uint32_t order_pitch, bool sub) {
     const uint32_t tid = threadIdx.x;
     const uint32_t nq = (cw + 3) >> 2, nitems = nq * ch * 16, inv_nq = make_inv(nq);
-    const uint32_t z = tid & 15, zy = z >> 2, zx = z & 3;                          // this lane's 16x16 block (raster)
-    const uint32_t zo = 4 * ((zy >> 1) * 2 + (zx >> 1)) + (zy & 1) * 2 + (zx & 1);  // its z-order index (A.1)
+    // lane (tid & 15) = z-order index of this lane's 16x16 block (Appendix A.1): the four 16x16 of a 32x32 are the four
+    // lanes of a DPP quad, the four 32x32 are the four quads of a DPP row
+    const uint32_t zo = tid & 15;
+    const uint32_t zy = 2 * (zo >> 3) + ((zo >> 1) & 1), zx = 2 * ((zo >> 2) & 1) + (zo & 1);
     const uint32_t *s = &L.src_full[(16 * zy) * 16 + 4 * zx];
-    const uint64_t  none = ~(uint64_t)0;
     for (uint32_t base = 0; base < nitems; base += WG_THREADS) {
         const uint32_t item = base + tid;
         const bool     on   = item < nitems;  // uniform over each group of 16 lanes
@@ -258,42 +264,43 @@ __device__ void fp_search(MeLds &L, uint32_t pitch, uint32_t x0, uint32_t y0, ui
                 a11 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d3, d4), sv.w, a11);
             }
         }
-        uint64_t k8[4] = {none, none, none, none}, k16 = none, k32 = none, k64 = none;
+        // running minima over this lane's four positions: positions are visited in raster order, so a strict '<' on the
+        // SAD keeps the first minimum; the 64-bit (sad, order) keys are only built for the LDS update
+        uint32_t m8[4] = {~0u, ~0u, ~0u, ~0u}, o8[4] = {0, 0, 0, 0}, m16 = ~0u, o16 = 0, m32 = ~0u, o32 = 0, m64 = ~0u, o64 = 0;
+        const uint32_t ord_row = order0 + y * order_pitch + 4 * q;
 #pragma unroll
         for (uint32_t pp = 0; pp < 4; pp++) {
-            uint32_t c0 = (uint32_t)(a00 >> (16 * pp)) & 0xffff, c1 = (uint32_t)(a01 >> (16 * pp)) & 0xffff;
-            uint32_t c2 = (uint32_t)(a10 >> (16 * pp)) & 0xffff, c3 = (uint32_t)(a11 >> (16 * pp)) & 0xffff;
-            if (sub)
-                c0 <<= 1, c1 <<= 1, c2 <<= 1, c3 <<= 1;
+            const uint32_t lo_hi_shift = 16 * (pp & 1);
+            const uint32_t c0 = ((pp < 2 ? (uint32_t)a00 : (uint32_t)(a00 >> 32)) >> lo_hi_shift) & 0xffff;
+            const uint32_t c1 = ((pp < 2 ? (uint32_t)a01 : (uint32_t)(a01 >> 32)) >> lo_hi_shift) & 0xffff;
+            const uint32_t c2 = ((pp < 2 ? (uint32_t)a10 : (uint32_t)(a10 >> 32)) >> lo_hi_shift) & 0xffff;
+            const uint32_t c3 = ((pp < 2 ? (uint32_t)a11 : (uint32_t)(a11 >> 32)) >> lo_hi_shift) & 0xffff;
             const uint32_t s16 = c0 + c1 + c2 + c3;
-            uint32_t       s32 = s16 + __shfl_xor(s16, 1, 64);
-            s32 += __shfl_xor(s32, 4, 64);
-            uint32_t s64 = s32 + __shfl_xor(s32, 2, 64);
-            s64 += __shfl_xor(s64, 8, 64);
-            const uint32_t x = 4 * q + pp;
-            if (on && x < cw) {
-                const uint64_t ord = order0 + y * order_pitch + x;
-                uint64_t       k;
-                k = ((uint64_t)c0 << 32) | ord, k8[0] = k < k8[0] ? k : k8[0];
-                k = ((uint64_t)c1 << 32) | ord, k8[1] = k < k8[1] ? k : k8[1];
-                k = ((uint64_t)c2 << 32) | ord, k8[2] = k < k8[2] ? k : k8[2];
-                k = ((uint64_t)c3 << 32) | ord, k8[3] = k < k8[3] ? k : k8[3];
-                k = ((uint64_t)s16 << 32) | ord, k16 = k < k16 ? k : k16;
-                k = ((uint64_t)s32 << 32) | ord, k32 = k < k32 ? k : k32;
-                k = ((uint64_t)s64 << 32) | ord, k64 = k < k64 ? k : k64;
+            uint32_t       s32 = dpp_add<0xB1>(s16);   // quad_perm [1,0,3,2]
+            s32                = dpp_add<0x4E>(s32);   // quad_perm [2,3,0,1]
+            uint32_t s64       = dpp_add<0x124>(s32);  // row_ror:4
+            s64                = dpp_add<0x128>(s64);  // row_ror:8
+            if (4 * q + pp < cw) {
+                const uint32_t ord = ord_row + pp;
+                if (c0 < m8[0]) m8[0] = c0, o8[0] = ord;
+                if (c1 < m8[1]) m8[1] = c1, o8[1] = ord;
+                if (c2 < m8[2]) m8[2] = c2, o8[2] = ord;
+                if (c3 < m8[3]) m8[3] = c3, o8[3] = ord;
+                if (s16 < m16) m16 = s16, o16 = ord;
+                if (s32 < m32) m32 = s32, o32 = ord;
+                if (s64 < m64) m64 = s64, o64 = ord;
             }
         }
-        if (on) {
+        if (on && m16 != ~0u) {
+            const uint32_t sh1 = sub ? 1 : 0;  // sub-sampled rows: SAD x 2 (motion_estimation.c:520-530)
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++)
-                if (k8[c] != none)
-                    atomicMin((unsigned long long *)&L.bestkey[21 + 4 * zo + c], (unsigned long long)k8[c]);
-            if (k16 != none)
-                atomicMin((unsigned long long *)&L.bestkey[5 + zo], (unsigned long long)k16);
-            if ((zo & 3) == 0 && k32 != none)
-                atomicMin((unsigned long long *)&L.bestkey[1 + (zo >> 2)], (unsigned long long)k32);
-            if (z == 0 && k64 != none)
-                atomicMin((unsigned long long *)&L.bestkey[0], (unsigned long long)k64);
+                atomicMin((unsigned long long *)&L.bestkey[21 + 4 * zo + c], ((unsigned long long)(m8[c] << sh1) << 32) | o8[c]);
+            atomicMin((unsigned long long *)&L.bestkey[5 + zo], ((unsigned long long)(m16 << sh1) << 32) | o16);
+            if ((zo & 3) == 0)
+                atomicMin((unsigned long long *)&L.bestkey[1 + (zo >> 2)], ((unsigned long long)(m32 << sh1) << 32) | o32);
+            if (zo == 0)
+                atomicMin((unsigned long long *)&L.bestkey[0], ((unsigned long long)(m64 << sh1) << 32) | o64);
         }
     }
     __syncthreads();

@@ -127,6 +127,38 @@ __device__ __forceinline__ void quad_sad(const uint32_t *__restrict__ w, uint32_
     out[0] = a0, out[1] = a1, out[2] = a2, out[3] = a3;
 }
 
+// Same result for a block of exactly BW = 16 / 32 / 64 samples per row whose source rows are 16-byte aligned in LDS:
+// the row body is fully unrolled (b128 source reads, no per-dword loop control).
+template <uint32_t BW>
+__device__ __forceinline__ void quad_sad_fixed(const uint32_t *__restrict__ w, uint32_t w_row_dw, const uint32_t *__restrict__ s,
+                                               uint32_t s_row_dw, uint32_t bh, uint32_t out[4]) {
+    constexpr uint32_t NF = BW / 4, FLUSH = 64 / NF;  // rows before a 16-bit lane of the packed accumulator could overflow
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (uint32_t r0 = 0; r0 < bh; r0 += FLUSH) {
+        uint64_t       acc = 0;
+        const uint32_t r1  = r0 + FLUSH < bh ? r0 + FLUSH : bh;
+#pragma unroll 1
+        for (uint32_t r = r0; r < r1; r++) {
+            const uint32_t *wr = w + r * w_row_dw;
+            const uint32_t *sr = s + r * s_row_dw;
+            uint32_t        d[NF + 1];
+#pragma unroll
+            for (uint32_t i = 0; i <= NF; i++) d[i] = wr[i];
+#pragma unroll
+            for (uint32_t i = 0; i < NF; i += 4) {
+                const uint4 sv = *(const uint4 *)&sr[i];
+                acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i], d[i + 1]), sv.x, acc);
+                acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 1], d[i + 2]), sv.y, acc);
+                acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 2], d[i + 3]), sv.z, acc);
+                acc = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 3], d[i + 4]), sv.w, acc);
+            }
+        }
+        a0 += (uint32_t)(acc & 0xffff), a1 += (uint32_t)((acc >> 16) & 0xffff);
+        a2 += (uint32_t)((acc >> 32) & 0xffff), a3 += (uint32_t)(acc >> 48);
+    }
+    out[0] = a0, out[1] = a1, out[2] = a2, out[3] = a3;
+}
+
 __device__ __forceinline__ void search_plan_desc(SearchDesc &d, uint32_t bw, uint32_t bh, uint32_t win_cap_dw) {
     d.fast = 0;
     d.k    = 0;
@@ -171,6 +203,8 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
                                        uint32_t src_row_dw, uint32_t bw, uint32_t bh, uint32_t *__restrict__ win,
                                        uint32_t win_cap_dw) {
     const uint32_t tid = threadIdx.x;
+    // b128 source reads need 16-byte aligned rows (LDS addresses are 32-bit offsets: test the low bits)
+    const bool src_aligned = (((uint32_t)(uintptr_t)src) & 15u) == 0 && (src_row_dw & 3u) == 0;
 #ifdef SVT_HIP_ME_PROFILE
     unsigned long long ms_last = wall_clock64();
 #endif
@@ -302,7 +336,16 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
             const uint32_t   step = ds.skip ? 2u : 1u;
             const uint32_t  *w    = win + sg.lds_dw + (jl * step) * ds.pitch_dw + q;
             uint32_t         sad[4];
-            quad_sad(w, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad);
+#ifndef SVT_HIP_NO_QSAD
+            if (src_aligned && bw == 16)
+                quad_sad_fixed<16>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+            else if (src_aligned && bw == 32)
+                quad_sad_fixed<32>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+            else if (src_aligned && bw == 64)
+                quad_sad_fixed<64>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+            else
+#endif
+                quad_sad(w, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad);
             const uint32_t sy = ds.skip ? 2 * (sg.j0 + jl) + 1 : (sg.j0 + jl);
             const uint32_t saw = (uint32_t)ds.sa_w;
             uint64_t       key = KEY_NONE;
