@@ -463,8 +463,12 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
     const SvtHipMeParams   &p   = job.prm;
     const uint32_t          aw = (job.src.full.width + 7u) & ~7u, ah = (job.src.full.height + 7u) & ~7u;
     const uint32_t          bw64 = (aw + 63) / 64, bh64 = (ah + 63) / 64;
-    const uint32_t          b64 = blockIdx.x;
-    if (b64 >= bw64 * bh64)
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup x goes to XCD
+    // x % 8 (the grid's x extent is a multiple of 8).  Give every XCD one contiguous band of b64 rows of the picture:
+    // neighbouring b64 share most of their search windows, which then hit in that XCD's L2.
+    const uint32_t nb64 = bw64 * bh64, band = (nb64 + 7) / 8;
+    const uint32_t b64  = (blockIdx.x & 7) * band + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= band || b64 >= nb64)
         return;
     const uint32_t tid = threadIdx.x;
     B64State      &S   = L.st;
@@ -1263,7 +1267,7 @@ extern "C" int32_t svt_hip_me_frames_dev(const SvtHipMeFrameJob *d_jobs, uint32_
     }
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
-    hipLaunchKernelGGL(me_b64_kernel, dim3(max_b64, n_jobs), dim3(WG_THREADS), 0, resolve_stream(stream), d_jobs);
+    hipLaunchKernelGGL(me_b64_kernel, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, resolve_stream(stream), d_jobs);
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }
@@ -1305,7 +1309,7 @@ extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jo
     }
     memcpy(js.pinned, jobs, bytes);
     SVT_HIP_CHECK(hipMemcpyAsync(js.dev, js.pinned, bytes, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(me_b64_kernel, dim3(max_b64, n_jobs), dim3(WG_THREADS), 0, st, (const SvtHipMeFrameJob *)js.dev);
+    hipLaunchKernelGGL(me_b64_kernel, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, st, (const SvtHipMeFrameJob *)js.dev);
     SVT_HIP_CHECK(hipGetLastError());
     SVT_HIP_CHECK(hipEventRecord(js.done, st));
     js.pending = true;
