@@ -26,6 +26,29 @@ ORC_API void   orc_lpf(void *s, int32_t pitch, int blimit, int limit, int thresh
 ORC_API void   orc_lf_thresholds(int level, int sharpness, int *lim, int *mblim, int *hev_thr);
 ORC_API void   orc_loop_filter_frame(const SvtHipLfFrame *f, int sb_size); /* f->plane / f->mi are HOST pointers here */
 ORC_API size_t orc_sizeof_lf_frame(void);
+/* self-guided restoration (orc_sgr.c) */
+ORC_API extern const int32_t orc_sgr_params[16][4];
+ORC_API void    orc_selfguided_restoration(const void *dgd, int32_t width, int32_t height, int32_t stride, int32_t *flt0, int32_t *flt1,
+                                           int32_t flt_stride, int32_t ep, int32_t bit_depth, int32_t is16);
+ORC_API void    orc_sgr_decode_xq(const int32_t *xqd, int32_t *xq, int32_t ep);
+ORC_API void    orc_sgr_encode_xq(const int32_t *xq, int32_t *xqd, int32_t ep);
+ORC_API void    orc_apply_selfguided_restoration(const void *dat, int32_t width, int32_t height, int32_t stride, int32_t ep,
+                                                 const int32_t *xqd, void *dst, int32_t dst_stride, int32_t bit_depth, int32_t is16);
+ORC_API int64_t orc_sgr_pixel_proj_error(const void *src, int32_t width, int32_t height, int32_t src_stride, const void *dat,
+                                         int32_t dat_stride, const int32_t *flt0, int32_t flt0_stride, const int32_t *flt1,
+                                         int32_t flt1_stride, const int32_t *xq, int32_t ep, int32_t is16);
+ORC_API void    orc_sgr_proj_sums(const void *src, int32_t width, int32_t height, int32_t src_stride, const void *dat, int32_t dat_stride,
+                                  const int32_t *flt0, int32_t flt0_stride, const int32_t *flt1, int32_t flt1_stride, int32_t ep,
+                                  int32_t is16, int64_t sums[5]);
+ORC_API void    orc_sgr_solve_subspace(const int64_t sums[5], int32_t size, int32_t ep, int32_t *xq);
+ORC_API void    orc_get_proj_subspace(const void *src, int32_t width, int32_t height, int32_t src_stride, const void *dat,
+                                      int32_t dat_stride, int32_t is16, const int32_t *flt0, int32_t flt0_stride, const int32_t *flt1,
+                                      int32_t flt1_stride, int32_t *xq, int32_t ep);
+ORC_API void    orc_sgr_filter_unit(const void *dat, int32_t width, int32_t height, int32_t dat_stride, int32_t is16, int32_t bit_depth,
+                                    int32_t pu_w, int32_t pu_h, int32_t ep, int32_t *flt0, int32_t *flt1, int32_t flt_stride);
+ORC_API int64_t orc_sgr_search_unit(const void *dat, int32_t width, int32_t height, int32_t dat_stride, const void *src,
+                                    int32_t src_stride, int32_t is16, int32_t bit_depth, int32_t pu_w, int32_t pu_h, int32_t start_ep,
+                                    int32_t end_ep, int32_t ep_inc, int32_t do_refine, int32_t out[3]);
 #ifdef __cplusplus
 }
 #endif
