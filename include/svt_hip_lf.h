@@ -145,6 +145,61 @@ typedef struct SvtHipLfFrame {
  * the reference never enables it (resource_coordination_process.c:410-412). */
 SVT_HIP_API int32_t svt_hip_loop_filter_frame(const SvtHipLfFrame *frame, void *stream);
 
+/* =============================================================================================
+ * Self-guided restoration
+ *   Source/Lib/Codec/common_dsp_rtcd.h:181,185   svt_apply_selfguided_restoration, svt_av1_selfguided_restoration
+ *   Source/Lib/Codec/aom_dsp_rtcd.h:79,81,212    svt_av1_{lowbd,highbd}_pixel_proj_error, svt_get_proj_subspace
+ *   Source/Lib/Codec/restoration_pick.c:523-652  apply_sgr, search_selfguided_restoration (Tier B: svt_hip_sgr_*)
+ * ============================================================================================= */
+typedef struct SvtHipSgrParams { /* SgrParamsType, definitions.h:1758-1761 */
+    int32_t r[2], s[2];
+} SvtHipSgrParams;
+
+/* Tier A: RTCD signatures.  For highbd != 0 the uint8_t pointers carry the reference's CONVERT_TO_BYTEPTR encoding
+ * (address >> 1 of a uint16 buffer, definitions.h:953-954), exactly as the callers pass them. */
+SVT_HIP_API void    svt_av1_selfguided_restoration_hip(const uint8_t *dgd8, int32_t width, int32_t height, int32_t dgd_stride,
+                                                       int32_t *flt0, int32_t *flt1, int32_t flt_stride, int32_t sgr_params_idx,
+                                                       int32_t bit_depth, int32_t highbd);
+SVT_HIP_API void    svt_apply_selfguided_restoration_hip(const uint8_t *dat, int32_t width, int32_t height, int32_t stride, int32_t eps,
+                                                         const int32_t *xqd, uint8_t *dst, int32_t dst_stride, int32_t *tmpbuf,
+                                                         int32_t bit_depth, int32_t highbd);
+SVT_HIP_API int64_t svt_av1_lowbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride,
+                                                       const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride,
+                                                       int32_t *flt1, int32_t flt1_stride, int32_t xq[2],
+                                                       const SvtHipSgrParams *params);
+SVT_HIP_API int64_t svt_av1_highbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride,
+                                                        const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride,
+                                                        int32_t *flt1, int32_t flt1_stride, int32_t xq[2],
+                                                        const SvtHipSgrParams *params);
+SVT_HIP_API void    svt_get_proj_subspace_hip(const uint8_t *src8, int width, int height, int src_stride, const uint8_t *dat8,
+                                              int dat_stride, int use_highbitdepth, int32_t *flt0, int flt0_stride, int32_t *flt1,
+                                              int flt1_stride, int *xq, const SvtHipSgrParams *params);
+
+/* Tier B: one restoration unit (<= 384 x 384 samples), device pointers.  `dat` = the degraded picture (after
+ * deblocking + CDEF) at the unit's top-left sample, readable 3 samples beyond the unit on every side (the extended
+ * frame the reference searches on); `src` = the original. */
+typedef struct SvtHipSgrUnit {
+    const void *dat, *src;
+    uint32_t    dat_stride, src_stride; /* in samples */
+    uint32_t    width, height;
+    uint8_t     is_16bit, bit_depth;
+    uint8_t     pu_w, pu_h; /* processing-unit size: 64 (luma) or 32 (4:2:0 chroma), restoration_pick.c:561-562 */
+} SvtHipSgrUnit;
+
+/* apply_sgr (restoration_pick.c:523-548): flt0 / flt1 = int32 [height][flt_stride] */
+SVT_HIP_API int32_t svt_hip_sgr_filter_unit(const SvtHipSgrUnit *unit, int32_t ep, int32_t *d_flt0, int32_t *d_flt1,
+                                            uint32_t flt_stride, void *stream);
+/* svt_apply_selfguided_restoration over the unit, filter and projection fused (no flt arrays); d_dst has the
+ * sample type of `dat`.  Stripe-boundary handling of the final loop-restoration pass stays with the caller. */
+SVT_HIP_API int32_t svt_hip_sgr_apply_unit(const SvtHipSgrUnit *unit, int32_t ep, const int32_t xqd[2], void *d_dst,
+                                           uint32_t dst_stride, void *stream);
+/* search_selfguided_restoration (restoration_pick.c:550-652) for ep = start_ep, start_ep + ep_inc, ... < end_ep:
+ * filter, projection (get_proj_subspace + encode_xq) and the finer search all run on the device; the call returns
+ * after reading back out = {ep, xqd[0], xqd[1]} and the winning error.  d_work: svt_hip_sgr_search_work_bytes(). */
+SVT_HIP_API size_t  svt_hip_sgr_search_work_bytes(uint32_t width, uint32_t height, int32_t n_ep);
+SVT_HIP_API int32_t svt_hip_sgr_search_unit(const SvtHipSgrUnit *unit, int32_t start_ep, int32_t end_ep, int32_t ep_inc,
+                                            int32_t do_refine, void *d_work, int32_t out[3], int64_t *best_err, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,18 @@ class LfFrame(C.Structure):       # SvtHipLfFrame
 
 
 LF_MI_DTYPE = [(n, "u1") for n in ("bsize", "tx_size_y", "tx_size_uv", "skip_inter", "segment_id", "ref_frame0", "mode_lf", "reserved")]
+
+
+class SgrParams(C.Structure):     # SvtHipSgrParams == SgrParamsType
+    _fields_ = [("r", C.c_int32 * 2), ("s", C.c_int32 * 2)]
+
+
+class SgrUnit(C.Structure):       # SvtHipSgrUnit
+    _fields_ = [("dat", C.c_void_p), ("src", C.c_void_p), ("dat_stride", C.c_uint32), ("src_stride", C.c_uint32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("is_16bit", C.c_uint8), ("bit_depth", C.c_uint8),
+                ("pu_w", C.c_uint8), ("pu_h", C.c_uint8)]
+
+
+SGR_PARAMS = [(2, 1, 140, 3236), (2, 1, 112, 2158), (2, 1, 93, 1618), (2, 1, 80, 1438), (2, 1, 70, 1295), (2, 1, 58, 1177),
+              (2, 1, 47, 1079), (2, 1, 37, 996), (2, 1, 30, 925), (2, 1, 25, 863), (0, 1, -1, 2589), (0, 1, -1, 1618),
+              (0, 1, -1, 1177), (0, 1, -1, 925), (2, 0, 56, -1), (2, 0, 22, -1)]   # r0, r1, s0, s1 (AV1 Sgr_Params)

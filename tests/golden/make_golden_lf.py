@@ -45,3 +45,30 @@ for key, w, h, bd, is16, variant, sb, seed in L.GOLDEN_DLF:
         store[f"{key}_in{i}"], store[f"{key}_out{i}"] = planes[i], out[i]
 np.savez_compressed(os.path.join(HERE, "dlf.npz"), **store)
 print("dlf.npz:", len(store), "arrays", os.path.getsize(os.path.join(HERE, "dlf.npz")), "bytes")
+
+# ---- self-guided restoration: the REAL search driver (through oracle/ref_harness_sgr.c), filter and apply
+import ctypes as C  # noqa: E402
+import sgr_cases as G  # noqa: E402
+from lf_cases import P, V  # noqa: E402
+
+store = {}
+filt = L.rtcd(ref, "svt_av1_selfguided_restoration", None, V, C.c_int32, C.c_int32, C.c_int32, V, V, C.c_int32, C.c_int32, C.c_int32, C.c_int32)
+appl = L.rtcd(ref, "svt_apply_selfguided_restoration", None, V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, V, V, C.c_int32, V, C.c_int32, C.c_int32)
+tmp = np.zeros(2 * 161 * 1024, np.int32)
+for key, w, h, bd, is16, kind, pu, (s0, s1, inc, refine), seed in G.GOLDEN_SGR:
+    rng = np.random.default_rng(seed)
+    dat, src = G.sgr_plane(rng, w, h, bd, is16, kind)
+    enc = (lambda a: V(a >> 1)) if is16 else V
+    out = np.zeros(3, np.int32)
+    assert ref.ref_sgr_search_unit(enc(G.at(dat)), w, h, dat.shape[1], enc(G.at(src)), src.shape[1], is16, bd, pu, pu, s0, s1, inc, refine, P(out)) == 0
+    # filter + apply of the winning candidate on the first processing unit
+    pw, ph = min(pu, w), min(pu, h)
+    f0, f1 = np.zeros((ph, pw), np.int32), np.zeros((ph, pw), np.int32)
+    filt(enc(G.at(dat)), pw, ph, dat.shape[1], P(f0), P(f1), pw, int(out[0]), bd, is16)
+    rec = np.zeros((ph, pw), dat.dtype)
+    xqd = np.array([out[1], out[2]], np.int32)
+    appl(enc(G.at(dat)), pw, ph, dat.shape[1], int(out[0]), P(xqd), enc(rec.ctypes.data), pw, P(tmp), bd, is16)
+    store[key + "_dat"], store[key + "_src"], store[key + "_best"] = dat, src, out
+    store[key + "_flt0"], store[key + "_flt1"], store[key + "_rec"] = f0, f1, rec
+np.savez_compressed(os.path.join(HERE, "sgr.npz"), **store)
+print("sgr.npz:", len(store), "arrays", os.path.getsize(os.path.join(HERE, "sgr.npz")), "bytes")

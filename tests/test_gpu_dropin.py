@@ -180,3 +180,25 @@ def test_transform_drivers_with_hip_leaves(dropin, ref, orc):
     assert len(got[0]) > 100
     for a, b in zip(*got):
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+
+
+def test_sgr_search_with_hip_leaves(dropin, ref):
+    """search_selfguided_restoration (restoration_pick.c:550-652, reached through oracle/ref_harness_sgr.c) with its five
+    RTCD leaves — filter, apply, both projection errors, subspace — replaced by the HIP functions."""
+    import sgr_cases as G
+    got = []
+    for phase in ("c", "hip"):
+        if phase == "hip":
+            dropin.install()
+        out = []
+        for bd, is16, (w, h), pu in ((8, 0, (96, 80), 64), (10, 1, (72, 40), 32)):
+            rng = np.random.default_rng(600 + bd)
+            dat, src = G.sgr_plane(rng, w, h, bd, is16, 0)
+            e = (lambda a: V(a >> 1)) if is16 else V
+            o = np.zeros(3, np.int32)
+            assert ref.ref_sgr_search_unit(e(G.at(dat)), w, h, dat.shape[1], e(G.at(src)), src.shape[1], is16, bd, pu, pu, 0, 16, 3, 1, P(o)) == 0
+            out.append(o)
+        got.append(out)
+    dropin.restore()
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)

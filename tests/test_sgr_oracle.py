@@ -14,23 +14,16 @@ class SgrParams(C.Structure):           # SgrParamsType (definitions.h:1758-1761
     _fields_ = [("r", C.c_int32 * 2), ("s", C.c_int32 * 2)]
 
 
+from sgr_cases import sgr_plane as _sgr_plane, at as _at, B as _B  # noqa: E402
+
+
 def sgr_plane(rng, w, h, bd, is16, kind):
-    """Degraded picture + original: smooth content with noise (kind 0), flat (1), random (2)."""
-    B = 8
-    dt = np.uint16 if is16 else np.uint8
-    if kind == 1:
-        dat = np.full((h + 2 * B, w + 2 * B), int(rng.integers(0, 1 << bd)))
-    elif kind == 2:
-        dat = rng.integers(0, 1 << bd, size=(h + 2 * B, w + 2 * B))
-    else:
-        dat = L.smooth_plane(rng, w + 2 * B, h + 2 * B, bd) + rng.integers(-3, 4, size=(h + 2 * B, w + 2 * B)) * (1 << (bd - 8))
-    dat = np.clip(dat, 0, (1 << bd) - 1).astype(dt)
-    src = np.clip(dat.astype(np.int32) + rng.integers(-5, 6, size=dat.shape) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(dt)
-    return dat, src, B
+    dat, src = _sgr_plane(rng, w, h, bd, is16, kind)
+    return dat, src, _B
 
 
 def at(a, B):
-    return a.ctypes.data + (B * a.shape[1] + B) * a.itemsize
+    return _at(a)
 
 
 def refptr(addr, is16):
@@ -119,3 +112,24 @@ def test_search_unit_vs_real_driver(orc, ref, bd, is16):
         orc.orc_sgr_search_unit(V(at(dat, B)), w, h, dat.shape[1], V(at(src, B)), src.shape[1], is16, bd, pu, pu, start, end, inc, refine,
                                 P(o2))
         assert np.array_equal(o1, o2), (trial, o1, o2)
+
+
+def test_sgr_oracle_vs_golden(orc):
+    """No reference needed: tests/golden/sgr.npz (search driver, filter and apply by the reference) pins the oracle."""
+    import os
+    import sgr_cases as G
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sgr.npz"))
+    orc.orc_sgr_search_unit.restype = I64
+    for key, w, h, bd, is16, kind, pu, (s0, s1, inc, refine), seed in G.GOLDEN_SGR:
+        dat, src, best = g[key + "_dat"].copy(), g[key + "_src"].copy(), g[key + "_best"]
+        out = np.zeros(3, np.int32)
+        orc.orc_sgr_search_unit(V(G.at(dat)), w, h, dat.shape[1], V(G.at(src)), src.shape[1], is16, bd, pu, pu, s0, s1, inc, refine, P(out))
+        assert np.array_equal(out, best), key
+        pw, ph = min(pu, w), min(pu, h)
+        f0, f1 = np.zeros((ph, pw), np.int32), np.zeros((ph, pw), np.int32)
+        orc.orc_selfguided_restoration(V(G.at(dat)), pw, ph, dat.shape[1], P(f0), P(f1), pw, int(best[0]), bd, is16)
+        assert np.array_equal(f0, g[key + "_flt0"]) and np.array_equal(f1, g[key + "_flt1"]), key
+        rec = np.zeros((ph, pw), dat.dtype)
+        xqd = np.array([best[1], best[2]], np.int32)
+        orc.orc_apply_selfguided_restoration(V(G.at(dat)), pw, ph, dat.shape[1], int(best[0]), P(xqd), P(rec), pw, bd, is16)
+        assert np.array_equal(rec, g[key + "_rec"]), key
