@@ -149,6 +149,28 @@ __device__ __forceinline__ uint16_t clip_pixel_add(uint32_t dest, int32_t trans,
     return (uint16_t)(v < 0 ? 0 : (v > hi ? hi : v));
 }
 
+// Store the IW x IH coefficient tile held in LDS (row pitch PW) to a dense global array with all L lanes of the
+// transform block: consecutive lanes write consecutive 16-byte chunks, so every wave-level store covers whole cache
+// lines (a lane-per-row store touches 16 bytes of L different lines and amplifies the HBM write traffic ~4x).
+template <int IW, int IH, int L, int PW>
+__device__ __forceinline__ void coop_store_tile(const int32_t *__restrict__ lds, int32_t *__restrict__ g, int t) {
+    constexpr int NCH = IW * IH / 4;
+    if ((((uintptr_t)g) & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < (NCH + L - 1) / L; k++) {
+            const int q = k * L + t;
+            if (q < NCH) {
+                const int e = 4 * q, r = e / IW, c = e % IW;
+                int4      v;
+                v.x = lds[r * PW + c], v.y = lds[r * PW + c + 1], v.z = lds[r * PW + c + 2], v.w = lds[r * PW + c + 3];
+                ((int4 *)g)[q] = v;
+            }
+        }
+    } else {
+        for (int e = t; e < IW * IH; e += L) g[e] = lds[(e / IW) * PW + e % IW];
+    }
+}
+
 template <int W, int H>
 __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(uint8_t *__restrict__ base,
                                                                             const SvtHipTxfmDesc *__restrict__ descs,
@@ -227,8 +249,6 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
             QP q;
             load_qp(q, d, base);
             const int16_t *iscan = (const int16_t *)(base + d.iscan_off);
-            int32_t       *qo = d.qcoeff_off == SVT_HIP_NO_OFFSET ? nullptr : (int32_t *)(base + d.qcoeff_off) + t * IW;
-            int32_t       *dqo = d.dqcoeff_off == SVT_HIP_NO_OFFSET ? nullptr : (int32_t *)(base + d.dqcoeff_off) + t * IW;
             if (!do_fwd) {  // quantise coefficients that already live in memory
                 const int32_t *ci = (const int32_t *)(base + d.coeff_off) + t * IW;
 #pragma unroll
@@ -243,9 +263,8 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
                     const uint32_t pos = (uint32_t)(uint16_t)iscan[rc] + 1u;
                     eob                = pos > eob ? pos : eob;
                 }
-                if (qo) qo[c] = qc;
-                if (dqo) dqo[c] = dqc;
-                row[c] = dqc;
+                lds[t * PW + c] = qc;  // staged for the coalesced store below
+                row[c]          = dqc;
             }
         } else if (do_inv && !do_fwd) {
             const int32_t *dqi = (const int32_t *)(base + d.dqcoeff_off) + t * IW;
@@ -254,6 +273,20 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
         }
     }
     eob = group_max<L>(eob);
+    {   // qcoeff / dqcoeff leave through LDS so that the stores are line-coalesced (all L lanes of the block take part)
+        const bool quant = live && d.quant_mode != SVT_HIP_QUANT_NONE;
+        __syncthreads();
+        if (quant && d.qcoeff_off != SVT_HIP_NO_OFFSET)
+            coop_store_tile<IW, IH, L, PW>(lds, (int32_t *)(base + d.qcoeff_off), t);
+        __syncthreads();
+        if (quant && t < IH) {
+#pragma unroll
+            for (int c = 0; c < IW; c++) lds[t * PW + c] = row[c];
+        }
+        __syncthreads();
+        if (quant && d.dqcoeff_off != SVT_HIP_NO_OFFSET)
+            coop_store_tile<IW, IH, L, PW>(lds, (int32_t *)(base + d.dqcoeff_off), t);
+    }
     if (live && t == 0) {
         SvtHipTxfmResult r;
         r.three_quad_energy = energy;

@@ -13,7 +13,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         k = r.get("Kernel_Name", "")
         if pat and pat not in k:
             continue
-        k = k.split("(")[0][-60:]
+        k = k.split("(")[0][-70:] or "kernel"
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[k].add(r.get("Dispatch_Id"))
 out = {k: {"dispatches": len(launches[k]), **{c: v for c, v in sorted(v.items())}} for k, v in acc.items()}

@@ -1,7 +1,9 @@
 #!/bin/bash
-# PMC passes over the ME bench (separate passes; no trace domains besides kernel-trace).  Writes gpurun_out/pmc_me_*.json
+# PMC passes over a bench workload (separate passes; no trace domains besides kernel-trace).
+#   tools/run_pmc.sh <tag> <kernel-name-substring> <bench.py args...>   -> gpurun_out/pmc_<tag>_<pass>.json
 set -e
 REPO=$PWD
+TAG=$1; PAT=$2; shift 2
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -10,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_IFETCH SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_FLAT"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_$i -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/pmc_run_$i.log 2>&1 || echo "pass $i failed"
-  python3 $REPO/tools/pmc_summary.py /tmp/pmc_$i me_b64 > $REPO/gpurun_out/pmc_me_$i.json || true
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_$i -- python3 $REPO/bench.py "$@" > $REPO/gpurun_out/pmc_run_$i.log 2>&1 || echo "pass $i failed"
+  python3 $REPO/tools/pmc_summary.py /tmp/pmc_$i "$PAT" > $REPO/gpurun_out/pmc_${TAG}_$i.json || true
 done
-cat $REPO/gpurun_out/pmc_me_*.json
+cat $REPO/gpurun_out/pmc_${TAG}_*.json
