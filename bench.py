@@ -134,8 +134,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=16, help="pictures per step and rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=("me", "txfm"), default="me",
-                    help="me: BASELINE.json configs[1] (default, the N=1 workload); txfm: configs[2] kernel-level measurement")
+    ap.add_argument("--workload", choices=("me", "txfm", "lf"), default="me",
+                    help="me: BASELINE.json configs[1] (default, the N=1 workload); txfm: configs[2] kernel-level measurement; "
+                         "lf: in-loop filters (deblock, CDEF, self-guided) on one 4K 10-bit picture, kernel-level")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,8 +154,8 @@ def main():
     rc = lib.svt_hip_init(local_rank)
     assert rc == 0, lib.svt_hip_last_error().decode()
 
-    if args.workload == "txfm":
-        bench_txfm(lib, dev, args, world, rank)
+    if args.workload in ("txfm", "lf"):
+        (bench_txfm if args.workload == "txfm" else bench_lf)(lib, dev, args, world, rank)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -361,6 +362,56 @@ def bench_txfm(lib, dev, args, world, rank):
                          "frac": round(k16["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(14 * 256 * k16["blocks"]), "launch_ms": k16["launch_ms"],
                          "best_size": best[0], "worst_size": worst[0]},
+        }))
+
+
+def bench_lf(lib, dev, args, world, rank):
+    """In-loop filters on one synthetic 4K 10-bit 4:2:0 picture resident in HBM (SURVEY 8d batch size "whole 4K frames"):
+    deblocking (3 planes, random 8x8..64x64 partition), CDEF search (8 strengths, luma + both chroma) and apply, and the
+    self-guided filter over all luma restoration units.  Reports per-stage time and algorithmic GB/s (8d formulas)."""
+    from svtav1_hip import lf_bench_inputs as LB
+    W4, H4, bd = 3840, 2160, 10
+    rng = np.random.default_rng(11 + rank)
+    stream = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(stream.cuda_stream)
+    inp = LB.build(lib, dev, rng, W4, H4, bd, torch)
+    stages = {}
+
+    def timed(name, fn, alg_bytes):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in evs:
+            a.record(stream)
+            fn()
+            b.record(stream)
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        stages[name] = {"ms": round(ms, 4), "GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes": int(alg_bytes)}
+        return ms
+
+    P, d = W4 * H4, 2
+    total = 0.0
+    total += timed("deblock_frame", lambda: LB.run_deblock(lib, inp, sp), 2 * 2 * 1.5 * P * d + (P // 16) * 8)
+    total += timed("cdef_search_3planes_8strengths", lambda: LB.run_cdef_search(lib, inp, sp), 2 * 1.5 * P * d + inp["n_fb"] * 3 * 8 * 8)
+    total += timed("cdef_apply_3planes", lambda: LB.run_cdef_apply(lib, inp, sp), 2 * 1.5 * P * d)
+    timed("sgr_filter_luma_one_eps", lambda: LB.run_sgr_filter(lib, inp, sp), P * d + 8 * P)
+    timed("sgr_apply_luma", lambda: LB.run_sgr_apply(lib, inp, sp), 2 * P * d)
+    shard.barrier()
+    if rank == 0:
+        worst = min(stages.items(), key=lambda kv: kv[1]["GBps"])
+        print(json.dumps({
+            "metric": "encoded fps (4K 10-bit preset 8) + ME+txfm HBM GB/s vs roofline, 1/2/4/8 GPU",
+            "value": round(world * 1.0 / (total * 1e-3), 2), "unit": "fps",
+            "value_scope": "4K 10-bit pictures per second through deblocking + CDEF search + CDEF apply (kernel-level, not a whole encode)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "4K 10-bit 4:2:0 in-loop filters: deblock frame, CDEF search (8 strengths) + apply, self-guided filter/apply",
+                       "width": W4, "height": H4, "stages": stages},
+            "roofline": {"bound": "hbm", "kernel": worst[0], "achieved": worst[1]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(worst[1]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": worst[1]["algorithmic_bytes"], "launch_ms": worst[1]["ms"]},
         }))
 
 

@@ -175,7 +175,8 @@ SVT_HIP_API void    svt_get_proj_subspace_hip(const uint8_t *src8, int width, in
                                               int dat_stride, int use_highbitdepth, int32_t *flt0, int flt0_stride, int32_t *flt1,
                                               int flt1_stride, int *xq, const SvtHipSgrParams *params);
 
-/* Tier B: one restoration unit (<= 384 x 384 samples), device pointers.  `dat` = the degraded picture (after
+/* Tier B: one restoration unit (<= 384 x 384 samples for the search; filter / apply take any region up to a whole
+ * plane whose origin lies on the processing-unit grid), device pointers.  `dat` = the degraded picture (after
  * deblocking + CDEF) at the unit's top-left sample, readable 3 samples beyond the unit on every side (the extended
  * frame the reference searches on); `src` = the original. */
 typedef struct SvtHipSgrUnit {

@@ -141,7 +141,6 @@ struct FbLds {
     SvtHipCdefList dl[64];
     uint8_t        dir[64];
     int32_t        var[64];
-    uint32_t       sums[64][5];
     unsigned long long total;
     int            n;
 };
@@ -199,8 +198,26 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
     }
     __syncthreads();
     const size_t soff  = (size_t)(fby * (64 >> pl.ydec)) * pl.source_stride + fbx * (64 >> pl.xdec);
-    const int    rows  = bh / sub;  // filtered rows per block
-    const int    items = n * rows * bw;
+    const int    rows  = bh / sub;  // filtered rows per block (power of two)
+    const int    nitem = n * rows;  // work item = one filtered row of one block; the rows of a block sit in adjacent lanes
+    constexpr int KMAX = 2;         // 64 blocks x 8 rows / 256 threads
+    // this thread's items and their source samples stay in registers across all strengths
+    int      it_by[KMAX], it_bx[KMAX], it_i[KMAX], it_bi[KMAX];
+    bool     it_on[KMAX];
+    uint16_t srcpx[KMAX][8];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int item = threadIdx.x + k * 256;
+        it_on[k]       = item < nitem;
+        const int bi = it_on[k] ? item / rows : 0, r = item - (item / rows) * rows;
+        it_bi[k] = bi, it_by[k] = S.dl[bi].by, it_bx[k] = S.dl[bi].bx, it_i[k] = r * sub;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            srcpx[k][j] = (it_on[k] && j < bw)
+                ? (uint16_t)load_px(pl.source, soff + (size_t)((it_by[k] << bhl) + it_i[k]) * pl.source_stride + (it_bx[k] << bwl) + j, pl.is_16bit)
+                : (uint16_t)0;
+    }
+    const bool luma8 = bsize == 3 && pl.pli == 0;
     for (int gi = 0; gi < prm.n_strengths; gi++) {
         if (prm.strengths[gi] < 0)
             continue;
@@ -208,40 +225,50 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
         sec += sec == 3;
         const int pri_s = pri << prm.coeff_shift, sec_s = sec << prm.coeff_shift;
         const int pd = prm.pri_damping + prm.coeff_shift - (pl.pli != 0), sd = prm.sec_damping + prm.coeff_shift - (pl.pli != 0);
-        for (int i = threadIdx.x; i < 64 * 5; i += blockDim.x) (&S.sums[0][0])[i] = 0;
         if (threadIdx.x == 0)
             S.total = 0;
         __syncthreads();
         unsigned long long acc = 0;
-        for (int it = threadIdx.x; it < items; it += blockDim.x) {
-            const int bi = it / (rows * bw), rem = it - bi * rows * bw;
-            const int i = (rem / bw) * sub, j = rem - (rem / bw) * bw;
-            const int by = S.dl[bi].by, bx = S.dl[bi].bx;
-            const uint16_t *p = in + ((by << bhl) + i) * BS + (bx << bwl) + j;
-            int32_t         y;
-            if (pri_s == 0 && sec_s == 0) {
-                y = pl.is_16bit ? p[0] : (uint8_t)p[0];
-            } else {
-                const int t = pl.pli ? pri_s : adjust_strength(pri_s, S.var[by * 8 + bx]);
-                y           = cdef_pixel(p, t, sec_s, pri_s ? S.dir[by * 8 + bx] : 0, pd, sd, prm.coeff_shift);
-                y           = pl.is_16bit ? (uint16_t)(int16_t)y : (uint8_t)(int16_t)y;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            if (k * 256 >= nitem)  // uniform
+                break;
+            uint32_t s_y = 0, s_o = 0, s_yy = 0, s_oo = 0, s_yo = 0;  // luma: the five sums; otherwise s_yy = sum of e^2
+            if (it_on[k]) {
+                const int       by = it_by[k], bx = it_bx[k];
+                const uint16_t *p  = in + ((by << bhl) + it_i[k]) * BS + (bx << bwl);
+                const int       t  = pl.pli ? pri_s : adjust_strength(pri_s, S.var[by * 8 + bx]);
+                const int       dd = pri_s ? S.dir[by * 8 + bx] : 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (j >= bw)
+                        break;
+                    int32_t y;
+                    if (pri_s == 0 && sec_s == 0) {
+                        y = pl.is_16bit ? p[j] : (uint8_t)p[j];
+                    } else {
+                        y = cdef_pixel(p + j, t, sec_s, dd, pd, sd, prm.coeff_shift);
+                        y = pl.is_16bit ? (uint16_t)(int16_t)y : (uint8_t)(int16_t)y;
+                    }
+                    const int32_t o = srcpx[k][j];
+                    if (luma8) {
+                        s_y += (uint32_t)y, s_o += (uint32_t)o, s_yy += (uint32_t)(y * y), s_oo += (uint32_t)(o * o), s_yo += (uint32_t)(y * o);
+                    } else {
+                        const int32_t e = o - y;
+                        s_yy += (uint32_t)(e * e);
+                    }
+                }
             }
-            const int32_t o = (int32_t)load_px(pl.source, soff + (size_t)((by << bhl) + i) * pl.source_stride + (bx << bwl) + j, pl.is_16bit);
-            if (bsize == 3 && pl.pli == 0) {
-                atomicAdd(&S.sums[bi][0], (uint32_t)y);
-                atomicAdd(&S.sums[bi][1], (uint32_t)o);
-                atomicAdd(&S.sums[bi][2], (uint32_t)(y * y));
-                atomicAdd(&S.sums[bi][3], (uint32_t)(o * o));
-                atomicAdd(&S.sums[bi][4], (uint32_t)(y * o));
-            } else {
-                const int32_t e = o - y;
-                acc += (unsigned long long)(int64_t)(e * e);
+            // sum over the rows of the block: `rows` adjacent lanes (groups are aligned: 256 % rows == 0)
+            for (int off = rows >> 1; off > 0; off >>= 1) {
+                s_yy += __shfl_down(s_yy, off, 64);
+                if (luma8) {
+                    s_y += __shfl_down(s_y, off, 64), s_o += __shfl_down(s_o, off, 64);
+                    s_oo += __shfl_down(s_oo, off, 64), s_yo += __shfl_down(s_yo, off, 64);
+                }
             }
-        }
-        __syncthreads();
-        if (bsize == 3 && pl.pli == 0 && (int)threadIdx.x < n) {
-            const uint32_t *s = S.sums[threadIdx.x];
-            acc = dist_8xn(s[0], s[1], s[2], s[3], s[4], prm.coeff_shift);  // src = filtered (packed), dst = source picture
+            if (it_on[k] && it_i[k] == 0)
+                acc += luma8 ? dist_8xn(s_y, s_o, s_yy, s_oo, s_yo, prm.coeff_shift) : (unsigned long long)s_yy;
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if ((threadIdx.x & 63) == 0)
@@ -249,7 +276,6 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
         __syncthreads();
         if (threadIdx.x == 0)
             mse[(size_t)fb * prm.n_strengths + gi] = ((uint64_t)S.total >> 2 * prm.coeff_shift) * (uint64_t)sub;
-        __syncthreads();
     }
 }
 

@@ -364,8 +364,11 @@ __global__ void sgr_solve_kernel(const long long *sums, int size, int r0, int r1
     }
 }
 
+// The search works on one restoration unit (<= 384 x 384, restoration.h:80-84); filter / apply accept any region whose
+// origin lies on the processing-unit grid, e.g. a whole plane in one launch.
 bool unit_ok(const SvtHipSgrUnit *u, bool need_src) {
-    return u && u->dat && (!need_src || u->src) && u->width && u->height && u->width <= 384 && u->height <= 384 &&
+    const uint32_t lim = need_src ? 384u : 16384u;
+    return u && u->dat && (!need_src || u->src) && u->width && u->height && u->width <= lim && u->height <= lim &&
         (u->pu_w == 64 || u->pu_w == 32) && (u->pu_h == 64 || u->pu_h == 32) && (u->bit_depth == 8 || u->bit_depth == 10 || u->bit_depth == 12) &&
         (u->bit_depth == 8 || u->is_16bit);
 }
