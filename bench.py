@@ -207,14 +207,12 @@ def main():
     pyr_descs = [p.desc() for p in dpyr]
     ev_me = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    ajobs = (abi.AnalysisJob * n_clip)(*[abi.AnalysisJob(pyr_descs[i], var_out[i].data_ptr(), mean_out[i].data_ptr()) for i in range(n_clip)])
+
     def step(k=None):
-        # pyramid + variance of the F pictures of this step (+ the 4 boundary pictures they reference)
-        for i in range(n_clip):
-            d = pyr_descs[i]
-            rc = lib.svt_hip_pyramid_frame(C.byref(d.full), C.byref(d.quarter), C.byref(d.sixteenth), 1, sp)
-            assert rc == 0, lib.svt_hip_last_error().decode()
-            rc = lib.svt_hip_variance_frame(C.byref(d.full), C.c_void_p(var_out[i].data_ptr()), C.c_void_p(mean_out[i].data_ptr()), 0, sp)
-            assert rc == 0, lib.svt_hip_last_error().decode()
+        # pyramid + variance of the F pictures of this step (+ the 4 boundary pictures they reference): three launches
+        rc = lib.svt_hip_analysis_frames(ajobs, C.c_uint32(n_clip), 1, 0, sp)
+        assert rc == 0, lib.svt_hip_last_error().decode()
         if k is not None:
             ev_me[k][0].record(stream)
         rc = lib.svt_hip_me_frames_dev(C.c_void_p(d_jobs.data_ptr()), C.c_uint32(F), max_b64, sp)

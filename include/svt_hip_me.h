@@ -182,6 +182,17 @@ typedef struct SvtHipPyramid8 {
     SvtHipPlane8 full, quarter, sixteenth; /* input_padded_pic, quarter_/sixteenth_downsampled_picture_ptr */
 } SvtHipPyramid8;
 
+/* Batched picture analysis: svt_hip_pyramid_frame + svt_hip_variance_frame for n pictures in three launches
+ * (the picture-analysis kernel's per-picture work, pic_analysis_process.c:2126,2137, for a whole mini-GOP at once).
+ * `jobs` is a HOST array; the planes and output arrays it names are device memory. */
+typedef struct SvtHipAnalysisJob {
+    SvtHipPyramid8 pyr;
+    uint16_t      *variance; /* [n_b64][85] */
+    uint64_t      *mean;     /* [n_b64][85] or NULL */
+} SvtHipAnalysisJob;
+SVT_HIP_API int32_t svt_hip_analysis_frames(const SvtHipAnalysisJob *jobs, uint32_t n_jobs, int32_t hme_level1_enabled,
+                                            int32_t full_precision, void *stream);
+
 /* Per-reference HME / pruning state kept by the reference in MeContext::search_results. */
 typedef struct SvtHipMeSearchResult {
     uint64_t hme_sad;

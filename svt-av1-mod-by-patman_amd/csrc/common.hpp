@@ -28,6 +28,13 @@ Scratch &tls_scratch();
 
 bool ensure_init();
 
+// Small descriptor arrays that a Tier B entry point receives in HOST memory travel to the device through a per-thread
+// ring of pinned + device staging slots.  stage_descriptors() copies and returns the device address (nullptr + error
+// set on failure); stage_commit() must be called after the kernels that read it have been launched: it records the
+// event that guards the slot against reuse.  No allocation happens on the launch path once the slots have grown.
+void *stage_descriptors(const void *host, size_t bytes, hipStream_t st);
+void  stage_commit(hipStream_t st);
+
 }  // namespace svthip
 
 #define SVT_HIP_CHECK(expr)                                                                        \

@@ -1280,39 +1280,13 @@ extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jo
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
     hipStream_t st = resolve_stream(stream);
-    // Job descriptors travel through a per-thread pinned + device staging pair.  An event recorded behind the
-    // kernel guards the pair against reuse by the next call of this thread while the kernel may still read it.
-    struct JobStage {
-        SvtHipMeFrameJob *dev = nullptr, *pinned = nullptr;
-        size_t            cap = 0;
-        hipEvent_t        done = nullptr;
-        bool              pending = false;
-    };
-    static thread_local JobStage js;
-    const size_t                 bytes = sizeof(SvtHipMeFrameJob) * n_jobs;
-    if (js.pending) {
-        SVT_HIP_CHECK(hipEventSynchronize(js.done));
-        js.pending = false;
-    }
-    if (!js.done)
-        SVT_HIP_CHECK(hipEventCreateWithFlags(&js.done, hipEventDisableTiming));
-    if (bytes > js.cap) {
-        if (js.dev)
-            SVT_HIP_CHECK(hipFree(js.dev));
-        if (js.pinned)
-            SVT_HIP_CHECK(hipHostFree(js.pinned));
-        js.dev = nullptr, js.pinned = nullptr, js.cap = 0;
-        const size_t cap = bytes < 65536 ? 65536 : bytes * 2;
-        SVT_HIP_CHECK(hipMalloc((void **)&js.dev, cap));
-        SVT_HIP_CHECK(hipHostMalloc((void **)&js.pinned, cap, hipHostMallocDefault));
-        js.cap = cap;
-    }
-    memcpy(js.pinned, jobs, bytes);
-    SVT_HIP_CHECK(hipMemcpyAsync(js.dev, js.pinned, bytes, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(me_b64_kernel, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, st, (const SvtHipMeFrameJob *)js.dev);
+    // Job descriptors travel through the per-thread staging ring (common.hpp): no allocation on the launch path.
+    const SvtHipMeFrameJob *d_jobs = (const SvtHipMeFrameJob *)stage_descriptors(jobs, sizeof(SvtHipMeFrameJob) * n_jobs, st);
+    if (!d_jobs)
+        return SVT_HIP_ERR_RUNTIME;
+    hipLaunchKernelGGL(me_b64_kernel, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, st, d_jobs);
+    stage_commit(st);
     SVT_HIP_CHECK(hipGetLastError());
-    SVT_HIP_CHECK(hipEventRecord(js.done, st));
-    js.pending = true;
     return SVT_HIP_OK;
 }
 

@@ -18,12 +18,11 @@ namespace {
 // exactly what downsample followed by svt_aom_generate_padding produces.
 // STEP = 2: mean of in(2i..2i+1, 2j..2j+1).  STEP = 4: mean of in(4i+1..4i+2, 4j+1..4j+2).
 template <int STEP>
-__global__ __launch_bounds__(256) void downsample_pad_kernel(const uint8_t *__restrict__ in, uint32_t in_stride,
-                                                             uint8_t *__restrict__ out, uint32_t out_stride,
-                                                             uint32_t out_w, uint32_t out_h, uint32_t pad) {
+__device__ __forceinline__ void downsample_pad_body(const uint8_t *__restrict__ in, uint32_t in_stride, uint8_t *__restrict__ out,
+                                                    uint32_t out_stride, uint32_t out_w, uint32_t out_h, uint32_t pad) {
     const uint32_t X4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;  // first padded column of this dword
     const uint32_t Y  = blockIdx.y;
-    if (X4 >= out_stride)
+    if (X4 >= out_stride || Y >= out_h + 2 * pad)
         return;
     int yi = (int)Y - (int)pad;
     yi     = yi < 0 ? 0 : (yi > (int)out_h - 1 ? (int)out_h - 1 : yi);
@@ -62,6 +61,25 @@ __global__ __launch_bounds__(256) void downsample_pad_kernel(const uint8_t *__re
     }
 }
 
+template <int STEP>
+__global__ __launch_bounds__(256) void downsample_pad_kernel(const uint8_t *__restrict__ in, uint32_t in_stride,
+                                                             uint8_t *__restrict__ out, uint32_t out_stride,
+                                                             uint32_t out_w, uint32_t out_h, uint32_t pad) {
+    downsample_pad_body<STEP>(in, in_stride, out, out_stride, out_w, out_h, pad);
+}
+
+// Batched form: blockIdx.z = picture.  level 0: full -> quarter (STEP 2), 1: quarter -> sixteenth (STEP 2),
+// 2: full -> sixteenth (STEP 4, HME level 1 off).
+__global__ __launch_bounds__(256) void downsample_pad_batch_kernel(const SvtHipAnalysisJob *__restrict__ jobs, int level) {
+    const SvtHipPyramid8 &y = jobs[blockIdx.z].pyr;
+    const SvtHipPlane8   &i = level == 1 ? y.quarter : y.full, &o = level == 0 ? y.quarter : y.sixteenth;
+    const uint8_t        *in = i.buf + i.org_x + (size_t)i.org_y * i.stride;
+    if (level == 2)
+        downsample_pad_body<4>(in, i.stride, o.buf, o.stride, o.width, o.height, o.org_x);
+    else
+        downsample_pad_body<2>(in, i.stride, o.buf, o.stride, o.width, o.height, o.org_x);
+}
+
 // Edge replication of a plane in place (svt_aom_generate_padding); interior untouched.
 __global__ __launch_bounds__(256) void pad_plane_kernel(uint8_t *__restrict__ buf, uint32_t stride, uint32_t w,
                                                         uint32_t h, uint32_t pad_x, uint32_t pad_y) {
@@ -78,10 +96,9 @@ __global__ __launch_bounds__(256) void pad_plane_kernel(uint8_t *__restrict__ bu
 }
 
 // One wave64 per 64x64 block, one lane per 8x8 sub-block; 4 blocks per workgroup.
-__global__ __launch_bounds__(256) void variance_kernel(const uint8_t *__restrict__ pic /* at (org_x, org_y) */,
-                                                       uint32_t stride, uint32_t b64_w, uint32_t n_b64,
-                                                       uint16_t *__restrict__ variance, uint64_t *__restrict__ mean,
-                                                       int full_precision) {
+__device__ __forceinline__ void variance_body(const uint8_t *__restrict__ pic /* at (org_x, org_y) */, uint32_t stride, uint32_t b64_w,
+                                              uint32_t n_b64, uint16_t *__restrict__ variance, uint64_t *__restrict__ mean,
+                                              int full_precision) {
     __shared__ uint64_t m8[4][64], q8[4][64], m16[4][16], q16[4][16], m32[4][4], q32[4][4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t b  = blockIdx.x * 4 + wv;
@@ -137,6 +154,17 @@ __global__ __launch_bounds__(256) void variance_kernel(const uint8_t *__restrict
         if (mo)
             mo[i] = m;
     }
+}
+
+__global__ __launch_bounds__(256) void variance_kernel(const uint8_t *__restrict__ pic, uint32_t stride, uint32_t b64_w, uint32_t n_b64,
+                                                       uint16_t *__restrict__ variance, uint64_t *__restrict__ mean, int full_precision) {
+    variance_body(pic, stride, b64_w, n_b64, variance, mean, full_precision);
+}
+__global__ __launch_bounds__(256) void variance_batch_kernel(const SvtHipAnalysisJob *__restrict__ jobs, int full_precision) {
+    const SvtHipAnalysisJob &j = jobs[blockIdx.y];
+    const SvtHipPlane8      &f = j.pyr.full;
+    const uint32_t           bw = (f.width + 63u) / 64u, bh = (f.height + 63u) / 64u;
+    variance_body(f.buf + f.org_x + (size_t)f.org_y * f.stride, f.stride, bw, bw * bh, j.variance, j.mean, full_precision);
 }
 
 bool plane_ok(const SvtHipPlane8 *p) {
@@ -207,6 +235,46 @@ extern "C" int32_t svt_hip_variance_frame(const SvtHipPlane8 *full, uint16_t *d_
     hipLaunchKernelGGL(variance_kernel, dim3((nb + 3) / 4), dim3(256), 0, resolve_stream(stream),
                        (const uint8_t *)(full->buf + full->org_x + (size_t)full->org_y * full->stride), full->stride, bw,
                        nb, d_variance, d_mean, (int)full_precision);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+// Batched picture analysis: pyramids + variances of n pictures in three launches (blockIdx.z / .y = picture).
+extern "C" int32_t svt_hip_analysis_frames(const SvtHipAnalysisJob *jobs, uint32_t n_jobs, int32_t hme_level1_enabled,
+                                           int32_t full_precision, void *stream) {
+    if (!jobs || n_jobs == 0 || n_jobs > 65535) {
+        set_error("svt_hip_analysis_frames: bad job count");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    uint32_t max_q_stride = 0, max_q_rows = 0, max_s_stride = 0, max_s_rows = 0, max_nb = 0;
+    for (uint32_t i = 0; i < n_jobs; i++) {
+        const SvtHipPyramid8 &y = jobs[i].pyr;
+        if (!plane_ok(&y.full) || !plane_ok(&y.sixteenth) || (hme_level1_enabled && !plane_ok(&y.quarter)) || !jobs[i].variance ||
+            y.sixteenth.org_x != y.sixteenth.org_y || (hme_level1_enabled && y.quarter.org_x != y.quarter.org_y)) {
+            set_error("svt_hip_analysis_frames: job %u: bad plane descriptor / missing output", i);
+            return SVT_HIP_ERR_BAD_PARAMETER;
+        }
+        max_q_stride = y.quarter.stride > max_q_stride ? y.quarter.stride : max_q_stride;
+        max_q_rows   = y.quarter.height + 2u * y.quarter.org_y > max_q_rows ? y.quarter.height + 2u * y.quarter.org_y : max_q_rows;
+        max_s_stride = y.sixteenth.stride > max_s_stride ? y.sixteenth.stride : max_s_stride;
+        max_s_rows   = y.sixteenth.height + 2u * y.sixteenth.org_y > max_s_rows ? y.sixteenth.height + 2u * y.sixteenth.org_y : max_s_rows;
+        const uint32_t nb = ((y.full.width + 63u) / 64u) * ((y.full.height + 63u) / 64u);
+        max_nb            = nb > max_nb ? nb : max_nb;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    hipStream_t st = resolve_stream(stream);
+    const SvtHipAnalysisJob *d_jobs = (const SvtHipAnalysisJob *)stage_descriptors(jobs, (size_t)n_jobs * sizeof(SvtHipAnalysisJob), st);
+    if (!d_jobs)
+        return SVT_HIP_ERR_RUNTIME;
+    if (hme_level1_enabled) {
+        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_q_stride / 4 + 1 + 255) / 256, max_q_rows, n_jobs), dim3(256), 0, st, d_jobs, 0);
+        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_s_stride / 4 + 1 + 255) / 256, max_s_rows, n_jobs), dim3(256), 0, st, d_jobs, 1);
+    } else {
+        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_s_stride / 4 + 1 + 255) / 256, max_s_rows, n_jobs), dim3(256), 0, st, d_jobs, 2);
+    }
+    hipLaunchKernelGGL(variance_batch_kernel, dim3((max_nb + 3) / 4, n_jobs), dim3(256), 0, st, d_jobs, (int)full_precision);
+    stage_commit(st);
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }

@@ -56,6 +56,65 @@ hipStream_t resolve_stream(void *stream) {
     return t.s;
 }
 
+namespace {
+struct StageSlot {
+    uint8_t   *dev = nullptr, *pinned = nullptr;
+    size_t     cap = 0;
+    hipEvent_t done = nullptr;
+    bool       pending = false;
+};
+struct StageRing {
+    StageSlot slot[4];
+    int       next = 0, last = -1;
+};
+thread_local StageRing g_ring;
+}  // namespace
+
+void *stage_descriptors(const void *host, size_t bytes, hipStream_t st) {
+    StageRing &r = g_ring;
+    StageSlot &s = r.slot[r.next];
+    auto       fail = [&](hipError_t e, const char *what) {
+        set_error("stage_descriptors: %s: %s", what, hipGetErrorString(e));
+        return (void *)nullptr;
+    };
+    hipError_t e;
+    if (s.pending) {
+        if ((e = hipEventSynchronize(s.done)) != hipSuccess)
+            return fail(e, "hipEventSynchronize");
+        s.pending = false;
+    }
+    if (!s.done && (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess)
+        return fail(e, "hipEventCreate");
+    if (bytes > s.cap) {
+        if (s.dev)
+            (void)hipFree(s.dev);
+        if (s.pinned)
+            (void)hipHostFree(s.pinned);
+        s.dev = s.pinned = nullptr, s.cap = 0;
+        const size_t cap = bytes < 65536 ? 65536 : bytes * 2;
+        if ((e = hipMalloc((void **)&s.dev, cap)) != hipSuccess)
+            return fail(e, "hipMalloc");
+        if ((e = hipHostMalloc((void **)&s.pinned, cap, hipHostMallocDefault)) != hipSuccess)
+            return fail(e, "hipHostMalloc");
+        s.cap = cap;
+    }
+    memcpy(s.pinned, host, bytes);
+    if ((e = hipMemcpyAsync(s.dev, s.pinned, bytes, hipMemcpyHostToDevice, st)) != hipSuccess)
+        return fail(e, "hipMemcpyAsync");
+    r.last = r.next;
+    r.next = (r.next + 1) % 4;
+    return s.dev;
+}
+void stage_commit(hipStream_t st) {
+    StageRing &r = g_ring;
+    if (r.last < 0)
+        return;
+    StageSlot &s = r.slot[r.last];
+    if (hipEventRecord(s.done, st) == hipSuccess)
+        s.pending = true;
+    r.last = -1;
+}
+
 uint8_t *Scratch::device(size_t bytes) {
     if (bytes > dev_cap) {
         if (dev)

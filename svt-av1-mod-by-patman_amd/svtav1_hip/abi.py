@@ -215,3 +215,7 @@ class SgrUnit(C.Structure):       # SvtHipSgrUnit
 SGR_PARAMS = [(2, 1, 140, 3236), (2, 1, 112, 2158), (2, 1, 93, 1618), (2, 1, 80, 1438), (2, 1, 70, 1295), (2, 1, 58, 1177),
               (2, 1, 47, 1079), (2, 1, 37, 996), (2, 1, 30, 925), (2, 1, 25, 863), (0, 1, -1, 2589), (0, 1, -1, 1618),
               (0, 1, -1, 1177), (0, 1, -1, 925), (2, 0, 56, -1), (2, 0, 22, -1)]   # r0, r1, s0, s1 (AV1 Sgr_Params)
+
+
+class AnalysisJob(C.Structure):   # SvtHipAnalysisJob
+    _fields_ = [("pyr", Pyramid8), ("variance", C.c_void_p), ("mean", C.c_void_p)]

@@ -189,6 +189,35 @@ def test_pyramid_and_variance_frame(hip, orc, w, h):
     assert np.array_equal(dq.download(), hq.buf)
 
 
+@pytest.mark.parametrize("l1,fp", [(1, 0), (0, 1)])
+def test_analysis_frames_batch(hip, orc, l1, fp):
+    """svt_hip_analysis_frames: pyramids + variances of several pictures of different sizes in three launches."""
+    sizes = [(200, 136), (648, 360), (328, 200), (200, 136)]
+    hosts, devs, outs, jobs = [], [], [], (abi.AnalysisJob * len(sizes))()
+    for i, (w, h) in enumerate(sizes):
+        clip = me_cases.make_clip("pan", w, h, 1, seed=20 + i)
+        hp = frames.HostPyramid(clip[0])
+        d = hp.desc()
+        orc.orc_pyramid_frame(C.byref(d.full), C.byref(d.quarter), C.byref(d.sixteenth), l1)
+        nb = frames.b64_count(w, h)
+        v1, m1 = np.zeros((nb, 85), np.uint16), np.zeros((nb, 85), np.uint64)
+        orc.orc_variance_frame(C.byref(d.full), v1.ctypes.data_as(C.c_void_p), m1.ctypes.data_as(C.c_void_p), fp)
+        dp = device.DevicePyramid(hip, frames.HostPyramid(clip[0]))
+        dv, dm = device.DeviceBuffer(hip, v1.nbytes), device.DeviceBuffer(hip, m1.nbytes)
+        jobs[i] = abi.AnalysisJob(dp.desc(), dv.ptr, dm.ptr if i % 2 == 0 else None)
+        hosts.append((hp, v1, m1)), devs.append(dp), outs.append((dv, dm))
+    device.check(hip, hip.svt_hip_analysis_frames(jobs, len(sizes), l1, fp, None), "svt_hip_analysis_frames")
+    hip.svt_hip_stream_sync(None)
+    for i, ((hp, v1, m1), dp, (dv, dm)) in enumerate(zip(hosts, devs, outs)):
+        if l1:
+            assert np.array_equal(dp.quarter.download(), hp.quarter.buf), i
+        assert np.array_equal(dp.sixteenth.download(), hp.sixteenth.buf), i
+        assert np.array_equal(dv.download(np.uint16, v1.shape), v1), i
+        if i % 2 == 0:
+            assert np.array_equal(dm.download(np.uint64, m1.shape), m1), i
+    assert hip.svt_hip_analysis_frames(None, 0, 1, 0, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+
+
 def run_hip_me(hip, prm, pyrs, cur, l0, l1, w, h, n_copies=1):
     nb = frames.b64_count(w, h)
     dpyr = {i: device.DevicePyramid(hip, pyrs[i]) for i in set([cur] + l0 + l1)}
