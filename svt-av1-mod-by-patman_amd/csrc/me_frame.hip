@@ -102,7 +102,7 @@ __device__ void wg_block_sad(MeLds &L, const uint8_t *ref, uint32_t ref_stride, 
     __syncthreads();
     const uint32_t ndw = width >> 2;
     uint32_t       acc = 0;
-    for (uint32_t idx = threadIdx.x; idx < ndw * rows; idx += WG_THREADS) {
+    for (uint32_t idx = threadIdx.x; idx < ndw * rows; idx += blockDim.x) {
         const uint32_t r = idx / ndw, i = idx - r * ndw;
         const uint32_t s = L.src_full[(r * row_step) * 16 + i];
         const uint32_t v = load_u32_unaligned(ref + (size_t)(r * row_step) * ref_stride + 4 * i);
@@ -210,18 +210,18 @@ __device__ __forceinline__ uint32_t fp_pitch(uint32_t tw) { return (((tw + 3) >>
 
 __device__ void fp_stage(MeLds &L, const uint8_t *win_org, uint32_t stride, uint32_t tw, uint32_t th) {
     const uint32_t tid = threadIdx.x, pitch = fp_pitch(tw), total = (th + 63) * pitch, inv = make_inv(pitch);
-    for (uint32_t base = tid; base < total; base += 4 * WG_THREADS) {
+    for (uint32_t base = tid; base < total; base += 4 * blockDim.x) {
         uint32_t v[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t idx = base + u * WG_THREADS;
+            const uint32_t idx = base + u * blockDim.x;
             const uint32_t r = fast_div(idx, inv), i = idx - r * pitch;
             v[u]             = idx < total ? load_u32_unaligned(win_org + (size_t)r * stride + 4 * i) : 0u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++)
-            if (base + u * WG_THREADS < total)
-                L.win[base + u * WG_THREADS] = v[u];
+            if (base + u * blockDim.x < total)
+                L.win[base + u * blockDim.x] = v[u];
     }
     __syncthreads();
 }
@@ -240,7 +240,7 @@ __device__ void fp_search(MeLds &L, uint32_t pitch, uint32_t x0, uint32_t y0, ui
     const uint32_t zo = tid & 15;
     const uint32_t zy = 2 * (zo >> 3) + ((zo >> 1) & 1), zx = 2 * ((zo >> 2) & 1) + (zo & 1);
     const uint32_t *s = &L.src_full[(16 * zy) * 16 + 4 * zx];
-    for (uint32_t base = 0; base < nitems; base += WG_THREADS) {
+    for (uint32_t base = 0; base < nitems; base += blockDim.x) {
         const uint32_t item = base + tid;
         const bool     on   = item < nitems;  // uniform over each group of 16 lanes
         const uint32_t qi = on ? item >> 4 : 0, y = fast_div(qi, inv_nq), q = qi - y * nq;
@@ -454,48 +454,76 @@ __device__ unsigned long long g_me_prof[16];
     } while (0)
 #endif
 
-__global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
-    __shared__ MeLds L;
-#ifdef SVT_HIP_ME_PROFILE
-    unsigned long long prof_last = wall_clock64();
-#endif
-    const SvtHipMeFrameJob &job = jobs[blockIdx.y];
-    const SvtHipMeParams   &p   = job.prm;
-    const uint32_t          aw = (job.src.full.width + 7u) & ~7u, ah = (job.src.full.height + 7u) & ~7u;
-    const uint32_t          bw64 = (aw + 63) / 64, bh64 = (ah + 63) / 64;
+
+// ------------------------------------------------------------------------------------------------
+// Stage functions.  Every stage of svt_aom_motion_estimation_b64 is a device function over the per-b64 state in LDS
+// (B64State) so that the same code serves the one-launch kernel (all stages of one b64 in one workgroup) and the staged
+// pipeline (one workgroup per b64 x reference for the search stages).  `Ctx` carries the uniform geometry.
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    const SvtHipMeFrameJob *job;
+    uint32_t  b64, org_x, org_y, b64_w, b64_h, aw, ah;
+    bool      hme_sub, me_sub;
+    int       tl, nlists, R0, R1, nref;
+    uint32_t *gs, *gm;  // p_sb_best_sad / p_sb_best_mv of this b64 (in the output arrays)
+};
+#define ME_CTX_LOCALS(c)                                                                                                      \
+    const SvtHipMeFrameJob &job = *(c).job;                                                                                   \
+    const SvtHipMeParams   &p   = job.prm;                                                                                    \
+    B64State               &S   = L.st;                                                                                       \
+    const uint32_t tid = threadIdx.x, org_x = (c).org_x, org_y = (c).org_y, b64_w = (c).b64_w, b64_h = (c).b64_h;             \
+    const uint32_t aw = (c).aw, ah = (c).ah;                                                                                  \
+    const bool     hme_sub = (c).hme_sub, me_sub = (c).me_sub;                                                                \
+    const int      tl = (c).tl, nlists = (c).nlists, R0 = (c).R0, R1 = (c).R1, nref = (c).nref;                               \
+    uint32_t *const gs = (c).gs, *const gm = (c).gm;                                                                          \
+    (void)job, (void)p, (void)S, (void)tid, (void)org_x, (void)org_y, (void)b64_w, (void)b64_h, (void)aw, (void)ah;           \
+    (void)hme_sub, (void)me_sub, (void)tl, (void)nlists, (void)R0, (void)R1, (void)nref, (void)gs, (void)gm
+
+__device__ bool make_ctx(Ctx &c, const SvtHipMeFrameJob &job, uint32_t bx) {
+    const SvtHipMeParams &p = job.prm;
+    c.job = &job;
+    c.aw = (job.src.full.width + 7u) & ~7u, c.ah = (job.src.full.height + 7u) & ~7u;
+    const uint32_t bw64 = (c.aw + 63) / 64, bh64 = (c.ah + 63) / 64;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup x goes to XCD
     // x % 8 (the grid's x extent is a multiple of 8).  Give every XCD one contiguous band of b64 rows of the picture:
     // neighbouring b64 share most of their search windows, which then hit in that XCD's L2.
     const uint32_t nb64 = bw64 * bh64, band = (nb64 + 7) / 8;
-    const uint32_t b64  = (blockIdx.x & 7) * band + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= band || b64 >= nb64)
-        return;
-    const uint32_t tid = threadIdx.x;
-    B64State      &S   = L.st;
-    const uint32_t org_x = (b64 % bw64) * 64, org_y = (b64 / bw64) * 64;
-    const uint32_t b64_w = (aw - org_x) < 64 ? aw - org_x : 64, b64_h = (ah - org_y) < 64 ? ah - org_y : 64;
-    const bool     hme_sub = p.hme_search_method == 0, me_sub = p.me_search_method == 0;
-    const int      tl      = p.temporal_layer_index;
+    c.b64 = (bx & 7) * band + (bx >> 3);
+    if ((bx >> 3) >= band || c.b64 >= nb64)
+        return false;
+    c.org_x = (c.b64 % bw64) * 64, c.org_y = (c.b64 / bw64) * 64;
+    c.b64_w = (c.aw - c.org_x) < 64 ? c.aw - c.org_x : 64, c.b64_h = (c.ah - c.org_y) < 64 ? c.ah - c.org_y : 64;
+    c.hme_sub = p.hme_search_method == 0, c.me_sub = p.me_search_method == 0;
+    c.tl = p.temporal_layer_index, c.nlists = p.num_of_list_to_search;
+    c.R0 = p.num_of_ref_pic_to_search[0], c.R1 = c.nlists > 1 ? p.num_of_ref_pic_to_search[1] : 0, c.nref = c.R0 + c.R1;
+    c.gs = job.out.best_sad + (size_t)c.b64 * NL * NR * 85, c.gm = job.out.best_mv + (size_t)c.b64 * NL * NR * 85;
+    return true;
+}
 
-    // ---- stage the three source blocks (me_process.c:183-214) ----
-    for (uint32_t idx = tid; idx < 64 * 16; idx += WG_THREADS) {
-        const uint32_t r = idx >> 4, i = idx & 15;
-        L.src_full[idx]  = load_u32_unaligned(plane_at(job.src.full, (int)org_x, (int)org_y) + (size_t)r * job.src.full.stride + 4 * i);
-    }
-    for (uint32_t idx = tid; idx < 32 * 8; idx += WG_THREADS) {
-        const uint32_t r = idx >> 3, i = idx & 7;
-        L.src_q[idx] = load_u32_unaligned(plane_at(job.src.quarter, (int)(org_x >> 1), (int)(org_y >> 1)) +
-                                          (size_t)r * job.src.quarter.stride + 4 * i);
-    }
-    for (uint32_t idx = tid; idx < 16 * 4; idx += WG_THREADS) {
-        const uint32_t r = idx >> 2, i = idx & 3;
-        L.src_s[idx] = load_u32_unaligned(plane_at(job.src.sixteenth, (int)(org_x >> 2), (int)(org_y >> 2)) +
-                                          (size_t)r * job.src.sixteenth.stride + 4 * i);
-    }
-    // ---- init_me_hme_data (motion_estimation.c:3080-3140) ----
-    uint32_t *const gs = job.out.best_sad + (size_t)b64 * NL * NR * 85;  // p_sb_best_sad / p_sb_best_mv of this b64
-    uint32_t *const gm = job.out.best_mv + (size_t)b64 * NL * NR * 85;   // live in the (L2-resident) output arrays
-    for (uint32_t i = tid; i < NL * NR * 85; i += WG_THREADS) gs[i] = 0, gm[i] = 0;
+
+// source blocks of this b64 (me_process.c:183-214): which = 1 full | 2 quarter | 4 sixteenth
+__device__ void stage_sources(MeLds &L, const Ctx &c, int which) {
+    ME_CTX_LOCALS(c);
+    if (which & 1)
+        for (uint32_t idx = tid; idx < 64 * 16; idx += blockDim.x) {
+            const uint32_t r = idx >> 4, i = idx & 15;
+            L.src_full[idx]  = load_u32_unaligned(plane_at(job.src.full, (int)org_x, (int)org_y) + (size_t)r * job.src.full.stride + 4 * i);
+        }
+    if (which & 2)
+        for (uint32_t idx = tid; idx < 32 * 8; idx += blockDim.x) {
+            const uint32_t r = idx >> 3, i = idx & 7;
+            L.src_q[idx] = load_u32_unaligned(plane_at(job.src.quarter, (int)(org_x >> 1), (int)(org_y >> 1)) + (size_t)r * job.src.quarter.stride + 4 * i);
+        }
+    if (which & 4)
+        for (uint32_t idx = tid; idx < 16 * 4; idx += blockDim.x) {
+            const uint32_t r = idx >> 2, i = idx & 3;
+            L.src_s[idx] = load_u32_unaligned(plane_at(job.src.sixteenth, (int)(org_x >> 2), (int)(org_y >> 2)) + (size_t)r * job.src.sixteenth.stride + 4 * i);
+        }
+}
+
+// init_me_hme_data (motion_estimation.c:3080-3140); lane 0 only
+__device__ void init_state_lane0(MeLds &L, const Ctx &c) {
+    ME_CTX_LOCALS(c);
     if (tid == 0) {
         S.first_ref_sad64 = 0;
         for (int i = 0; i < NL; i++)
@@ -519,353 +547,335 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
                 set_quadrants(S.l2x[i][j], S.l2y[i][j], S.l2s[i][j], 0, 0, 0);
             }
     }
+}
+
+// zero-MV SAD of one reference (init_zz_sad, motion_estimation.c:2452-2470); all threads, ends with a barrier
+__device__ void zz_sad_ref(MeLds &L, const Ctx &c, int li, int ri) {
+    ME_CTX_LOCALS(c);
+    const SvtHipPlane8 &rp = job.ref[li][ri].full;
+    wg_block_sad(L, plane_at(rp, (int16_t)org_x, (int16_t)org_y), rp.stride, b64_w, b64_h >> 1, 2);
+    if (tid == 0) {
+        uint32_t z = S.wg_sum << 1;
+        z          = (z * 64 * 64) / (b64_w * b64_h);
+        S.zz_sad[li][ri] = z;
+    }
     __syncthreads();
+}
 
-    ME_PHASE(0);
-    const int nlists = p.num_of_list_to_search;
-
-    // ---- init_zz_sad (motion_estimation.c:2452-2507) ----
-    if (p.me_early_exit_th || p.me_safe_limit_zz_th) {
+// zz-SAD based reference pruning (init_zz_sad, motion_estimation.c:2471-2504); lane 0 only
+__device__ void zz_prune_lane0(MeLds &L, const Ctx &c) {
+    ME_CTX_LOCALS(c);
+    if (tid == 0) {
+        uint32_t best = MAX_U32_;
         for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                if (!(tl > 0 || li == 0))
-                    continue;
-                const SvtHipPlane8 &rp = job.ref[li][ri].full;
-                wg_block_sad(L, plane_at(rp, (int16_t)org_x, (int16_t)org_y), rp.stride, b64_w, b64_h >> 1, 2);
-                if (tid == 0) {
-                    uint32_t z = S.wg_sum << 1;
-                    z          = (z * 64 * 64) / (b64_w * b64_h);
-                    S.zz_sad[li][ri] = z;
-                }
-                __syncthreads();
-            }
-        if (tid == 0) {
-            uint32_t best = MAX_U32_;
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
+                if (tl > 0 || li == 0)
+                    best = MINV(best, S.zz_sad[li][ri]);
+        if (tl > 0 && best < p.zz_sad_th) {
             for (int li = 0; li < nlists; ++li)
-                for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
-                    if (tl > 0 || li == 0)
-                        best = MINV(best, S.zz_sad[li][ri]);
-            if (tl > 0 && best < p.zz_sad_th) {
+                for (int ri = 1; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                    const uint32_t pct = p.zz_sad_pct;
+                    if ((uint32_t)((S.zz_sad[li][ri] - best) * 100u) > (uint32_t)(pct * best))
+                        S.sr[li][ri].do_ref = 0;
+                }
+        }
+        if (p.me_safe_limit_zz_th) {
+            const int lim = p.hierarchical_levels > 0 && nlists == 2 && tl >= p.hierarchical_levels &&
+                p.similar_brightness_refs && S.zz_sad[0][0] < p.me_safe_limit_zz_th &&
+                S.zz_sad[1][0] < p.me_safe_limit_zz_th;
+            if (lim)
                 for (int li = 0; li < nlists; ++li)
-                    for (int ri = 1; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                        const uint32_t pct = p.zz_sad_pct;
-                        if ((uint32_t)((S.zz_sad[li][ri] - best) * 100u) > (uint32_t)(pct * best))
-                            S.sr[li][ri].do_ref = 0;
-                    }
-            }
-            if (p.me_safe_limit_zz_th) {
-                const int lim = p.hierarchical_levels > 0 && nlists == 2 && tl >= p.hierarchical_levels &&
-                    p.similar_brightness_refs && S.zz_sad[0][0] < p.me_safe_limit_zz_th &&
-                    S.zz_sad[1][0] < p.me_safe_limit_zz_th;
-                if (lim)
-                    for (int li = 0; li < nlists; ++li)
-                        for (int ri = 1; ri < p.num_of_ref_pic_to_search[li]; ++ri) S.sr[li][ri].do_ref = 0;
-            }
-        }
-        __syncthreads();
-    }
-
-    ME_PHASE(1);
-    // The HME stages below are descriptor-parallel: every (reference, quadrant) — or (reference, pre-HME region) —
-    // is set up by its own lane, all of them are searched by ONE wg_multi_search call, and the same lane decodes its
-    // result.  f in [0, nref) numbers the references: list 0 first.
-    const int R0 = p.num_of_ref_pic_to_search[0], R1 = nlists > 1 ? p.num_of_ref_pic_to_search[1] : 0;
-    const int nref = R0 + R1;
-
-    // ---- prehme_b64 (motion_estimation.c:1792-1866) ----
-    if (p.prehme_enable) {
-        // List 1 reads list 0's results for the l1 early exit (:1771-1781) and for the tl == 0 mirror (:1853-1860); only
-        // then does it need a round of its own — otherwise all references are searched by one call.
-        const bool split = nlists == 2 && (p.prehme_l1_early_exit || tl == 0);
-        for (int round = 0; round < (split ? 2 : 1); ++round) {
-            const int      f0 = split && round ? R0 : 0, f1 = split ? (round ? nref : R0) : nref;
-            const int      f  = f0 + (int)(tid >> 1), si = (int)(tid & 1);
-            const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
-            const uint32_t nd = 2u * (uint32_t)(f1 - f0);
-            const bool     mine = tid < nd;
-            const bool     searching = tl > 0 || round == 0;  // uniform: a tl == 0 second round only mirrors
-            int16_t        q_ox = 0, q_oy = 0;
-            bool           go = false;
-            if (mine) {
-                PreHme     &d  = S.ph[li][ri][si];
-                SearchDesc &sd = L.sh.desc[tid];
-                const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
-                sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
-                if (tl > 0 || li == 0) {
-                    const uint32_t factor = scaled_dist(pic_dist(p, li, ri));
-                    const PreHme   o      = S.ph[0][ri][si];
-                    // check_prehme_early_exit (:1763-1789)
-                    if (p.me_early_exit_th && S.zz_sad[li][ri] < p.me_early_exit_th) {
-                        d.col = d.row = 0, d.sad = 0, d.valid = 1;
-                    } else if (p.prehme_l1_early_exit && li == 1 && o.valid &&
-                               ((o.sad < (32 * 32)) || ((ABSV(o.col) < 16) && (ABSV(o.row) < 16)))) {
-                        d.col = (int16_t)-o.col, d.row = (int16_t)-o.row, d.sad = o.sad, d.valid = 1;
-                    } else if (!S.sr[li][ri].do_ref) {
-                        d.col = d.row = 0, d.sad = MAX_U32_;
-                    } else {
-                        d.sa_w = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].width * factor), (uint32_t)p.prehme_sa_max[si].width);
-                        d.sa_h = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].height * factor), (uint32_t)p.prehme_sa_max[si].height);
-                        // prehme_core (:1638-1736)
-                        const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
-                        int16_t pad_w = (int16_t)rp.org_x - 1, pad_h = (int16_t)rp.org_y - 1;
-                        int16_t sa_w = (int16_t)d.sa_w, sa_h = (int16_t)d.sa_h;
-                        int16_t ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
-                        const int16_t W = (int16_t)rp.width, H = (int16_t)rp.height;
-                        ox   = ((ox16 + ox) < -pad_w) ? (int16_t)(-pad_w - ox16) : ox;
-                        sa_w = ((ox16 + ox) < -pad_w) ? (int16_t)(sa_w - (-pad_w - (ox16 + ox))) : sa_w;
-                        ox   = ((ox16 + ox) > W - 1) ? (int16_t)(ox - ((ox16 + ox) - (W - 1))) : ox;
-                        sa_w = ((ox16 + ox + sa_w) > W) ? (int16_t)MAXV(1, sa_w - ((ox16 + ox + sa_w) - W)) : sa_w;
-                        oy   = ((oy16 + oy) < -pad_h) ? (int16_t)(-pad_h - oy16) : oy;
-                        sa_h = ((oy16 + oy) < -pad_h) ? (int16_t)(sa_h - (-pad_h - (oy16 + oy))) : sa_h;
-                        oy   = ((oy16 + oy) > H - 1) ? (int16_t)(oy - ((oy16 + oy) - (H - 1))) : oy;
-                        sa_h = ((oy16 + oy + sa_h) > H) ? (int16_t)MAXV(1, sa_h - ((oy16 + oy + sa_h) - H)) : sa_h;
-                        const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
-                        const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
-                        const uint32_t bw = b64_w >> 2, bh = hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2);
-                        set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, p.prehme_skip_search_line && bw == 16 && bh <= 16);
-                        q_ox = ox, q_oy = oy;
-                        S.performed_phme[li][ri][si] = 1;
-                        go = true;
-                    }
-                } else {
-                    d.col = (int16_t)-S.ph[0][ri][si].col;
-                    d.row = (int16_t)-S.ph[0][ri][si].row;
-                    d.sad = S.ph[0][ri][si].sad;
-                }
-            }
-            if (searching) {
-                wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
-                                ME_WIN_DW);
-                if (go) {
-                    PreHme &d = S.ph[li][ri][si];
-                    decode_result(L.sh, tid, hme_sub, &d.sad, &d.col, &d.row);
-                    d.col = (int16_t)(d.col + q_ox);
-                    d.col = (int16_t)(d.col * 4);
-                    d.row = (int16_t)(d.row + q_oy);
-                    d.row = (int16_t)(d.row * 4);
-                    d.valid = 1;
-                }
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            uint32_t best_sad = MAX_U32_;
-            for (int li = 0; li < nlists; ++li)
-                for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
-                    if (tl > 0 || li == 0) {
-                        const uint32_t m = (uint32_t)MINV(S.ph[li][ri][0].sad, S.ph[li][ri][1].sad);
-                        best_sad         = MINV(best_sad, m);
-                    }
-            if (tl > 0 && best_sad < p.phme_sad_th) {
-                for (int li = 0; li < nlists; ++li)
-                    for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                        if (!S.sr[li][ri].do_ref || ri == 0)
-                            continue;
-                        const uint32_t th  = p.phme_sad_pct;
-                        const uint32_t sad = (uint32_t)MINV(S.ph[li][ri][0].sad, S.ph[li][ri][1].sad);
-                        if ((uint32_t)((sad - best_sad) * 100u) > (uint32_t)(th * best_sad))
-                            S.sr[li][ri].do_ref = 0;
-                    }
-            }
-        }
-        __syncthreads();
-    }
-
-    ME_PHASE(2);
-    // ---- HME level 0 (motion_estimation.c:1976-2106) ----
-    if (p.enable_hme_flag && p.enable_hme_level0_flag) {
-        // With distance-based resizing, references other than the first read the first one's quadrant-(0,0) vector
-        // (get_hme_l0_search_area, :1881-1890): the first reference then gets a round of its own.
-        const bool dep = p.enable_me_sr_adjustment && p.distance_based_hme_resizing && p.reduce_hme_l0_sr_th_min &&
-            p.reduce_hme_l0_sr_th_max && nref > 1;
-        for (int f0 = 0; f0 < nref;) {
-            const int      f1   = (dep && f0 == 0) ? 1 : nref;
-            const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
-            const bool     mine = tid < nd;
-            const int      f    = f0 + (int)(tid >> 2);
-            const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
-            const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
-            int16_t        q_ox = 0, q_oy = 0;
-            bool           go = false;
-            if (mine) {
-                SearchDesc         &sd = L.sh.desc[tid];
-                const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
-                sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
-                const int psi = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
-                if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
-                    S.l0x[li][ri][sw_][sh_] = 0, S.l0y[li][ri][sw_][sh_] = 0, S.l0s[li][ri][sw_][sh_] = 0;
-                } else if (p.prev_me_stage_based_exit_th && S.performed_phme[li][ri][psi] &&
-                           S.ph[li][ri][psi].sad < (p.prev_me_stage_based_exit_th >> 4)) {
-                    S.l0x[li][ri][sw_][sh_] = S.ph[li][ri][psi].col, S.l0y[li][ri][sw_][sh_] = S.ph[li][ri][psi].row;
-                    S.l0s[li][ri][sw_][sh_] = S.ph[li][ri][psi].sad;
-                } else if (!S.sr[li][ri].do_ref) {
-                    S.l0x[li][ri][sw_][sh_] = 0, S.l0y[li][ri][sw_][sh_] = 0, S.l0s[li][ri][sw_][sh_] = MAX_U32_;
-                } else if (tl > 0 || li == 0) {
-                    // get_hme_l0_search_area (:1870-1937); hme_l0_sa is restored right after use (:2069-2073)
-                    SvtHipSearchArea mn = S.l0_min, mx = S.l0_max;
-                    if (p.enable_me_sr_adjustment && p.distance_based_hme_resizing) {
-                        uint8_t is_hor = 1, is_ver = 1, is_still = 0;
-                        if (p.reduce_hme_l0_sr_th_min && p.reduce_hme_l0_sr_th_max && (li || ri)) {
-                            const int16_t mvx = S.l0x[0][0][0][0], mvy = S.l0y[0][0][0][0];
-                            is_ver   = (ABSV(mvx) < p.reduce_hme_l0_sr_th_min) && (ABSV(mvy) > p.reduce_hme_l0_sr_th_max);
-                            is_hor   = (ABSV(mvx) > p.reduce_hme_l0_sr_th_max) && (ABSV(mvy) < p.reduce_hme_l0_sr_th_min);
-                            is_still = (ABSV(mvx) < (p.reduce_hme_l0_sr_th_min * 3)) && (ABSV(mvy) < (p.reduce_hme_l0_sr_th_min * 3));
-                        }
-                        uint8_t xo = 1, yo = 1;
-                        if (!is_ver) yo = 2;
-                        if (!is_hor) xo = 2;
-                        if (p.enable_me_sr_adjustment == 2 && is_still) xo = yo = 4;
-                        mn.width  = (uint16_t)(mn.width / (xo + ri));
-                        mn.height = (uint16_t)(mn.height / (yo + ri));
-                        mx.width  = (uint16_t)(mx.width / (xo + ri));
-                        mx.height = (uint16_t)(mx.height / (yo + ri));
-                    }
-                    const int32_t factor = scaled_dist(pic_dist(p, li, ri));
-                    int16_t       w      = (int16_t)(mn.width / p.num_hme_sa_w);
-                    w = (int16_t)MINV((((w * factor) + 15) & ~0x0F), (((mx.width / p.num_hme_sa_w) + 15) & ~0x0F));
-                    int16_t h = (int16_t)(mn.height / p.num_hme_sa_h);
-                    h         = (int16_t)MINV((h * factor), (mx.height / p.num_hme_sa_h));
-                    const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
-                    // hme_level_0 (:820-920)
-                    int16_t       sa_w = (int16_t)((w + 7) & ~0x07), sa_h = h;
-                    const int16_t xd = (int16_t)(sa_w * sw_), yd = (int16_t)(sa_h * sh_);
-                    int16_t       ox = (int16_t)(-(int16_t)((sa_w * p.num_hme_sa_w) >> 1) + xd);
-                    int16_t       oy = (int16_t)(-(int16_t)((sa_h * p.num_hme_sa_h) >> 1) + yd);
-                    hme_clamp(ox16, oy16, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width, (int16_t)rp.height, &ox,
-                              &oy, &sa_w, &sa_h);
-                    const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
-                    const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
-                    set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-                    q_ox = ox, q_oy = oy;
-                    go   = true;
-                }
-            }
-            wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
-                            ME_WIN_DW);
-            if (go) {
-                int16_t mx = S.l0x[li][ri][sw_][sh_], my = S.l0y[li][ri][sw_][sh_];
-                decode_result(L.sh, tid, hme_sub, &S.l0s[li][ri][sw_][sh_], &mx, &my);
-                mx = (int16_t)(mx + q_ox), mx = (int16_t)(mx * 4);
-                my = (int16_t)(my + q_oy), my = (int16_t)(my * 4);
-                S.l0x[li][ri][sw_][sh_] = mx, S.l0y[li][ri][sw_][sh_] = my;
-            }
-            __syncthreads();
-            // the pre-HME vector replaces the worst quadrant if it is better (:2086-2104): one lane per reference
-            if (go && qi == 0 && p.prehme_enable) {
-                uint8_t  bw_ = 0, bh_ = 0;
-                uint64_t mx = 0;
-                if (S.l0s[li][ri][0][0] > mx) mx = S.l0s[li][ri][0][0], bw_ = 0, bh_ = 0;
-                if (S.l0s[li][ri][1][0] > mx) mx = S.l0s[li][ri][1][0], bw_ = 1, bh_ = 0;
-                if (S.l0s[li][ri][0][1] > mx) mx = S.l0s[li][ri][0][1], bw_ = 0, bh_ = 1;
-                if (S.l0s[li][ri][1][1] > mx) bw_ = 1, bh_ = 1;
-                const int si = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
-                if (S.ph[li][ri][si].sad < S.l0s[li][ri][bw_][bh_]) {
-                    S.l0s[li][ri][bw_][bh_] = S.ph[li][ri][si].sad;
-                    S.l0x[li][ri][bw_][bh_] = S.ph[li][ri][si].col;
-                    S.l0y[li][ri][bw_][bh_] = S.ph[li][ri][si].row;
-                }
-            }
-            __syncthreads();
-            f0 = f1;
+                    for (int ri = 1; ri < p.num_of_ref_pic_to_search[li]; ++ri) S.sr[li][ri].do_ref = 0;
         }
     }
+}
 
-    ME_PHASE(3);
-    // ---- HME level 1 (motion_estimation.c:2111-2192) ----
-    if (p.enable_hme_flag && p.enable_hme_level1_flag) {
-        const uint32_t nd   = (uint32_t)nref * 4u;
-        const bool     mine = tid < nd;
-        const int      f    = (int)(tid >> 2);
-        const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
-        const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
-        int16_t        q_ox = 0, q_oy = 0;
-        bool           go = false;
-        if (mine) {
-            SearchDesc         &sd = L.sh.desc[tid];
-            const SvtHipPlane8 &rp = job.ref[li][ri].quarter;
-            sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
-            if (tl > 0 || li == 0) {
-                if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
-                    S.l1x[li][ri][sw_][sh_] = 0, S.l1y[li][ri][sw_][sh_] = 0, S.l1s[li][ri][sw_][sh_] = 0;
-                } else if (!S.sr[li][ri].do_ref) {
-                    S.l1x[li][ri][sw_][sh_] = 0, S.l1y[li][ri][sw_][sh_] = 0, S.l1s[li][ri][sw_][sh_] = MAX_U32_;
-                } else if (p.prev_me_stage_based_exit_th && S.l0s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 5)) {
-                    S.l1x[li][ri][sw_][sh_] = S.l0x[li][ri][sw_][sh_];
-                    S.l1y[li][ri][sw_][sh_] = S.l0y[li][ri][sw_][sh_];
-                    S.l1s[li][ri][sw_][sh_] = S.l0s[li][ri][sw_][sh_];
-                } else {
-                    // hme_level_1 (:923-1022)
-                    const int16_t ox4 = (int16_t)(((int16_t)org_x) >> 1), oy4 = (int16_t)(((int16_t)org_y) >> 1);
-                    int16_t sa_w = (int16_t)(((int16_t)p.hme_l1_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l1_sa.height;
-                    int16_t ox = (int16_t)(-(sa_w >> 1) + (int16_t)(S.l0x[li][ri][sw_][sh_] >> 1));
-                    int16_t oy = (int16_t)(-(sa_h >> 1) + (int16_t)(S.l0y[li][ri][sw_][sh_] >> 1));
-                    hme_clamp(ox4, oy4, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width, (int16_t)rp.height, &ox,
-                              &oy, &sa_w, &sa_h);
-                    const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox4) + ox);
-                    const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy4) + oy);
-                    set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-                    q_ox = ox, q_oy = oy;
-                    go   = true;
-                }
+// prehme_b64 (motion_estimation.c:1792-1866) for references [f0, f1): one lane per (reference, region) sets its
+// descriptor up, ONE wg_multi_search call searches them all, the same lane decodes.  Ends with a barrier.
+__device__ void prehme_round(MeLds &L, const Ctx &c, int f0, int f1, bool searching) {
+    ME_CTX_LOCALS(c);
+    const int      f  = f0 + (int)(tid >> 1), si = (int)(tid & 1);
+    const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+    const uint32_t nd = 2u * (uint32_t)(f1 - f0);
+    const bool     mine = tid < nd;
+    int16_t        q_ox = 0, q_oy = 0;
+    bool           go = false;
+    if (mine) {
+        PreHme     &d  = S.ph[li][ri][si];
+        SearchDesc &sd = L.sh.desc[tid];
+        const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
+        sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+        if (tl > 0 || li == 0) {
+            const uint32_t factor = scaled_dist(pic_dist(p, li, ri));
+            const PreHme   o      = S.ph[0][ri][si];
+            // check_prehme_early_exit (:1763-1789)
+            if (p.me_early_exit_th && S.zz_sad[li][ri] < p.me_early_exit_th) {
+                d.col = d.row = 0, d.sad = 0, d.valid = 1;
+            } else if (p.prehme_l1_early_exit && li == 1 && o.valid &&
+                       ((o.sad < (32 * 32)) || ((ABSV(o.col) < 16) && (ABSV(o.row) < 16)))) {
+                d.col = (int16_t)-o.col, d.row = (int16_t)-o.row, d.sad = o.sad, d.valid = 1;
+            } else if (!S.sr[li][ri].do_ref) {
+                d.col = d.row = 0, d.sad = MAX_U32_;
+            } else {
+                d.sa_w = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].width * factor), (uint32_t)p.prehme_sa_max[si].width);
+                d.sa_h = (uint16_t)MINV((uint32_t)(p.prehme_sa_min[si].height * factor), (uint32_t)p.prehme_sa_max[si].height);
+                // prehme_core (:1638-1736)
+                const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
+                int16_t pad_w = (int16_t)rp.org_x - 1, pad_h = (int16_t)rp.org_y - 1;
+                int16_t sa_w = (int16_t)d.sa_w, sa_h = (int16_t)d.sa_h;
+                int16_t ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
+                const int16_t W = (int16_t)rp.width, H = (int16_t)rp.height;
+                ox   = ((ox16 + ox) < -pad_w) ? (int16_t)(-pad_w - ox16) : ox;
+                sa_w = ((ox16 + ox) < -pad_w) ? (int16_t)(sa_w - (-pad_w - (ox16 + ox))) : sa_w;
+                ox   = ((ox16 + ox) > W - 1) ? (int16_t)(ox - ((ox16 + ox) - (W - 1))) : ox;
+                sa_w = ((ox16 + ox + sa_w) > W) ? (int16_t)MAXV(1, sa_w - ((ox16 + ox + sa_w) - W)) : sa_w;
+                oy   = ((oy16 + oy) < -pad_h) ? (int16_t)(-pad_h - oy16) : oy;
+                sa_h = ((oy16 + oy) < -pad_h) ? (int16_t)(sa_h - (-pad_h - (oy16 + oy))) : sa_h;
+                oy   = ((oy16 + oy) > H - 1) ? (int16_t)(oy - ((oy16 + oy) - (H - 1))) : oy;
+                sa_h = ((oy16 + oy + sa_h) > H) ? (int16_t)MAXV(1, sa_h - ((oy16 + oy + sa_h) - H)) : sa_h;
+                const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
+                const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
+                const uint32_t bw = b64_w >> 2, bh = hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2);
+                set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, p.prehme_skip_search_line && bw == 16 && bh <= 16);
+                q_ox = ox, q_oy = oy;
+                S.performed_phme[li][ri][si] = 1;
+                go = true;
             }
+        } else {
+            d.col = (int16_t)-S.ph[0][ri][si].col;
+            d.row = (int16_t)-S.ph[0][ri][si].row;
+            d.sad = S.ph[0][ri][si].sad;
         }
-        wg_multi_search(L.sh, nd, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1), L.win,
+    }
+    if (searching) {
+        wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
                         ME_WIN_DW);
         if (go) {
-            int16_t mx = S.l1x[li][ri][sw_][sh_], my = S.l1y[li][ri][sw_][sh_];
-            decode_result(L.sh, tid, hme_sub, &S.l1s[li][ri][sw_][sh_], &mx, &my);
-            mx = (int16_t)(mx + q_ox), mx = (int16_t)(mx * 2);
-            my = (int16_t)(my + q_oy), my = (int16_t)(my * 2);
-            S.l1x[li][ri][sw_][sh_] = mx, S.l1y[li][ri][sw_][sh_] = my;
+            PreHme &d = S.ph[li][ri][si];
+            decode_result(L.sh, tid, hme_sub, &d.sad, &d.col, &d.row);
+            d.col = (int16_t)(d.col + q_ox);
+            d.col = (int16_t)(d.col * 4);
+            d.row = (int16_t)(d.row + q_oy);
+            d.row = (int16_t)(d.row * 4);
+            d.valid = 1;
         }
-        __syncthreads();
     }
+    __syncthreads();
+}
 
-    ME_PHASE(4);
-    // ---- HME level 2 (motion_estimation.c:2197-2247) ----
-    if (p.enable_hme_flag && p.enable_hme_level2_flag) {
-        const uint32_t nd   = (uint32_t)nref * 4u;
-        const bool     mine = tid < nd;
-        const int      f    = (int)(tid >> 2);
-        const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
-        const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
-        int16_t        q_ox = 0, q_oy = 0;
-        bool           go = false;
-        if (mine) {
-            SearchDesc         &sd = L.sh.desc[tid];
-            const SvtHipPlane8 &rp = job.ref[li][ri].full;
-            sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
-            if (tl > 0 || li == 0) {
-                if (p.prev_me_stage_based_exit_th && S.l1s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 2)) {
-                    S.l2x[li][ri][sw_][sh_] = S.l1x[li][ri][sw_][sh_];
-                    S.l2y[li][ri][sw_][sh_] = S.l1y[li][ri][sw_][sh_];
-                    S.l2s[li][ri][sw_][sh_] = S.l1s[li][ri][sw_][sh_];
-                } else {
-                    // hme_level_2 (:1025-1113)
-                    int16_t sa_w = (int16_t)(((int16_t)p.hme_l2_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l2_sa.height;
-                    int16_t ox = (int16_t)(-(sa_w >> 1) + S.l1x[li][ri][sw_][sh_]);
-                    int16_t oy = (int16_t)(-(sa_h >> 1) + S.l1y[li][ri][sw_][sh_]);
-                    hme_clamp((int16_t)org_x, (int16_t)org_y, 63, 63, (int16_t)rp.width, (int16_t)rp.height, &ox, &oy, &sa_w, &sa_h);
-                    const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + (int16_t)org_x) + ox);
-                    const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + (int16_t)org_y) + oy);
-                    set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-                    q_ox = ox, q_oy = oy;
-                    go   = true;
+// pre-HME based reference pruning (:1851-1865); lane 0 only
+__device__ void phme_prune_lane0(MeLds &L, const Ctx &c) {
+    ME_CTX_LOCALS(c);
+    if (tid == 0) {
+        uint32_t best_sad = MAX_U32_;
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
+                if (tl > 0 || li == 0) {
+                    const uint32_t m = (uint32_t)MINV(S.ph[li][ri][0].sad, S.ph[li][ri][1].sad);
+                    best_sad         = MINV(best_sad, m);
                 }
+        if (tl > 0 && best_sad < p.phme_sad_th) {
+            for (int li = 0; li < nlists; ++li)
+                for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                    if (!S.sr[li][ri].do_ref || ri == 0)
+                        continue;
+                    const uint32_t th  = p.phme_sad_pct;
+                    const uint32_t sad = (uint32_t)MINV(S.ph[li][ri][0].sad, S.ph[li][ri][1].sad);
+                    if ((uint32_t)((sad - best_sad) * 100u) > (uint32_t)(th * best_sad))
+                        S.sr[li][ri].do_ref = 0;
+                }
+        }
+    }
+}
+
+// HME level 0 (motion_estimation.c:1976-2106) for references [f0, f1); one lane per (reference, quadrant).  Ends with a barrier.
+__device__ void hme_l0_round(MeLds &L, const Ctx &c, int f0, int f1) {
+    ME_CTX_LOCALS(c);
+    const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
+    const bool     mine = tid < nd;
+    const int      f    = f0 + (int)(tid >> 2);
+    const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
+    const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+    int16_t        q_ox = 0, q_oy = 0;
+    bool           go = false;
+    if (mine) {
+        SearchDesc         &sd = L.sh.desc[tid];
+        const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
+        sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+        const int psi = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
+        if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
+            S.l0x[li][ri][sw_][sh_] = 0, S.l0y[li][ri][sw_][sh_] = 0, S.l0s[li][ri][sw_][sh_] = 0;
+        } else if (p.prev_me_stage_based_exit_th && S.performed_phme[li][ri][psi] &&
+                   S.ph[li][ri][psi].sad < (p.prev_me_stage_based_exit_th >> 4)) {
+            S.l0x[li][ri][sw_][sh_] = S.ph[li][ri][psi].col, S.l0y[li][ri][sw_][sh_] = S.ph[li][ri][psi].row;
+            S.l0s[li][ri][sw_][sh_] = S.ph[li][ri][psi].sad;
+        } else if (!S.sr[li][ri].do_ref) {
+            S.l0x[li][ri][sw_][sh_] = 0, S.l0y[li][ri][sw_][sh_] = 0, S.l0s[li][ri][sw_][sh_] = MAX_U32_;
+        } else if (tl > 0 || li == 0) {
+            // get_hme_l0_search_area (:1870-1937); hme_l0_sa is restored right after use (:2069-2073)
+            SvtHipSearchArea mn = S.l0_min, mx = S.l0_max;
+            if (p.enable_me_sr_adjustment && p.distance_based_hme_resizing) {
+                uint8_t is_hor = 1, is_ver = 1, is_still = 0;
+                if (p.reduce_hme_l0_sr_th_min && p.reduce_hme_l0_sr_th_max && (li || ri)) {
+                    const int16_t mvx = S.l0x[0][0][0][0], mvy = S.l0y[0][0][0][0];
+                    is_ver   = (ABSV(mvx) < p.reduce_hme_l0_sr_th_min) && (ABSV(mvy) > p.reduce_hme_l0_sr_th_max);
+                    is_hor   = (ABSV(mvx) > p.reduce_hme_l0_sr_th_max) && (ABSV(mvy) < p.reduce_hme_l0_sr_th_min);
+                    is_still = (ABSV(mvx) < (p.reduce_hme_l0_sr_th_min * 3)) && (ABSV(mvy) < (p.reduce_hme_l0_sr_th_min * 3));
+                }
+                uint8_t xo = 1, yo = 1;
+                if (!is_ver) yo = 2;
+                if (!is_hor) xo = 2;
+                if (p.enable_me_sr_adjustment == 2 && is_still) xo = yo = 4;
+                mn.width  = (uint16_t)(mn.width / (xo + ri));
+                mn.height = (uint16_t)(mn.height / (yo + ri));
+                mx.width  = (uint16_t)(mx.width / (xo + ri));
+                mx.height = (uint16_t)(mx.height / (yo + ri));
+            }
+            const int32_t factor = scaled_dist(pic_dist(p, li, ri));
+            int16_t       w      = (int16_t)(mn.width / p.num_hme_sa_w);
+            w = (int16_t)MINV((((w * factor) + 15) & ~0x0F), (((mx.width / p.num_hme_sa_w) + 15) & ~0x0F));
+            int16_t h = (int16_t)(mn.height / p.num_hme_sa_h);
+            h         = (int16_t)MINV((h * factor), (mx.height / p.num_hme_sa_h));
+            const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
+            // hme_level_0 (:820-920)
+            int16_t       sa_w = (int16_t)((w + 7) & ~0x07), sa_h = h;
+            const int16_t xd = (int16_t)(sa_w * sw_), yd = (int16_t)(sa_h * sh_);
+            int16_t       ox = (int16_t)(-(int16_t)((sa_w * p.num_hme_sa_w) >> 1) + xd);
+            int16_t       oy = (int16_t)(-(int16_t)((sa_h * p.num_hme_sa_h) >> 1) + yd);
+            hme_clamp(ox16, oy16, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width, (int16_t)rp.height, &ox,
+                      &oy, &sa_w, &sa_h);
+            const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
+            const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
+            set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+            q_ox = ox, q_oy = oy;
+            go   = true;
+        }
+    }
+    wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
+                    ME_WIN_DW);
+    if (go) {
+        int16_t mx = S.l0x[li][ri][sw_][sh_], my = S.l0y[li][ri][sw_][sh_];
+        decode_result(L.sh, tid, hme_sub, &S.l0s[li][ri][sw_][sh_], &mx, &my);
+        mx = (int16_t)(mx + q_ox), mx = (int16_t)(mx * 4);
+        my = (int16_t)(my + q_oy), my = (int16_t)(my * 4);
+        S.l0x[li][ri][sw_][sh_] = mx, S.l0y[li][ri][sw_][sh_] = my;
+    }
+    __syncthreads();
+    // the pre-HME vector replaces the worst quadrant if it is better (:2086-2104): one lane per reference
+    if (go && qi == 0 && p.prehme_enable) {
+        uint8_t  bw_ = 0, bh_ = 0;
+        uint64_t mx = 0;
+        if (S.l0s[li][ri][0][0] > mx) mx = S.l0s[li][ri][0][0], bw_ = 0, bh_ = 0;
+        if (S.l0s[li][ri][1][0] > mx) mx = S.l0s[li][ri][1][0], bw_ = 1, bh_ = 0;
+        if (S.l0s[li][ri][0][1] > mx) mx = S.l0s[li][ri][0][1], bw_ = 0, bh_ = 1;
+        if (S.l0s[li][ri][1][1] > mx) bw_ = 1, bh_ = 1;
+        const int si = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
+        if (S.ph[li][ri][si].sad < S.l0s[li][ri][bw_][bh_]) {
+            S.l0s[li][ri][bw_][bh_] = S.ph[li][ri][si].sad;
+            S.l0x[li][ri][bw_][bh_] = S.ph[li][ri][si].col;
+            S.l0y[li][ri][bw_][bh_] = S.ph[li][ri][si].row;
+        }
+    }
+    __syncthreads();
+}
+
+// HME level 1 (motion_estimation.c:2111-2192) for references [f0, f1).  Ends with a barrier.
+__device__ void hme_l1_round(MeLds &L, const Ctx &c, int f0, int f1) {
+    ME_CTX_LOCALS(c);
+    const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
+    const bool     mine = tid < nd;
+    const int      f    = f0 + (int)(tid >> 2);
+    const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
+    const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+    int16_t        q_ox = 0, q_oy = 0;
+    bool           go = false;
+    if (mine) {
+        SearchDesc         &sd = L.sh.desc[tid];
+        const SvtHipPlane8 &rp = job.ref[li][ri].quarter;
+        sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+        if (tl > 0 || li == 0) {
+            if (p.me_early_exit_th && S.zz_sad[li][ri] < (p.me_early_exit_th >> 2)) {
+                S.l1x[li][ri][sw_][sh_] = 0, S.l1y[li][ri][sw_][sh_] = 0, S.l1s[li][ri][sw_][sh_] = 0;
+            } else if (!S.sr[li][ri].do_ref) {
+                S.l1x[li][ri][sw_][sh_] = 0, S.l1y[li][ri][sw_][sh_] = 0, S.l1s[li][ri][sw_][sh_] = MAX_U32_;
+            } else if (p.prev_me_stage_based_exit_th && S.l0s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 5)) {
+                S.l1x[li][ri][sw_][sh_] = S.l0x[li][ri][sw_][sh_];
+                S.l1y[li][ri][sw_][sh_] = S.l0y[li][ri][sw_][sh_];
+                S.l1s[li][ri][sw_][sh_] = S.l0s[li][ri][sw_][sh_];
+            } else {
+                // hme_level_1 (:923-1022)
+                const int16_t ox4 = (int16_t)(((int16_t)org_x) >> 1), oy4 = (int16_t)(((int16_t)org_y) >> 1);
+                int16_t sa_w = (int16_t)(((int16_t)p.hme_l1_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l1_sa.height;
+                int16_t ox = (int16_t)(-(sa_w >> 1) + (int16_t)(S.l0x[li][ri][sw_][sh_] >> 1));
+                int16_t oy = (int16_t)(-(sa_h >> 1) + (int16_t)(S.l0y[li][ri][sw_][sh_] >> 1));
+                hme_clamp(ox4, oy4, (int16_t)(rp.org_x - 1), (int16_t)(rp.org_y - 1), (int16_t)rp.width, (int16_t)rp.height, &ox,
+                          &oy, &sa_w, &sa_h);
+                const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox4) + ox);
+                const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy4) + oy);
+                set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+                q_ox = ox, q_oy = oy;
+                go   = true;
             }
         }
-        wg_multi_search(L.sh, nd, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, L.win, ME_WIN_DW);
-        if (go) {
-            int16_t mx = S.l2x[li][ri][sw_][sh_], my = S.l2y[li][ri][sw_][sh_];
-            decode_result(L.sh, tid, hme_sub, &S.l2s[li][ri][sw_][sh_], &mx, &my);
-            S.l2x[li][ri][sw_][sh_] = (int16_t)(mx + q_ox);
-            S.l2y[li][ri][sw_][sh_] = (int16_t)(my + q_oy);
-        }
-        __syncthreads();
     }
+    wg_multi_search(L.sh, nd, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1), L.win,
+                    ME_WIN_DW);
+    if (go) {
+        int16_t mx = S.l1x[li][ri][sw_][sh_], my = S.l1y[li][ri][sw_][sh_];
+        decode_result(L.sh, tid, hme_sub, &S.l1s[li][ri][sw_][sh_], &mx, &my);
+        mx = (int16_t)(mx + q_ox), mx = (int16_t)(mx * 2);
+        my = (int16_t)(my + q_oy), my = (int16_t)(my * 2);
+        S.l1x[li][ri][sw_][sh_] = mx, S.l1y[li][ri][sw_][sh_] = my;
+    }
+    __syncthreads();
+}
 
-    ME_PHASE(5);
-    // ---- set_final_seach_centre_sb (:2252-2450) + hme_prune_ref_and_adjust_sr (:2547-2588) ----
+// HME level 2 (motion_estimation.c:2197-2247) for references [f0, f1).  Ends with a barrier.
+__device__ void hme_l2_round(MeLds &L, const Ctx &c, int f0, int f1) {
+    ME_CTX_LOCALS(c);
+    const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
+    const bool     mine = tid < nd;
+    const int      f    = f0 + (int)(tid >> 2);
+    const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
+    const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+    int16_t        q_ox = 0, q_oy = 0;
+    bool           go = false;
+    if (mine) {
+        SearchDesc         &sd = L.sh.desc[tid];
+        const SvtHipPlane8 &rp = job.ref[li][ri].full;
+        sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
+        if (tl > 0 || li == 0) {
+            if (p.prev_me_stage_based_exit_th && S.l1s[li][ri][sw_][sh_] < (p.prev_me_stage_based_exit_th >> 2)) {
+                S.l2x[li][ri][sw_][sh_] = S.l1x[li][ri][sw_][sh_];
+                S.l2y[li][ri][sw_][sh_] = S.l1y[li][ri][sw_][sh_];
+                S.l2s[li][ri][sw_][sh_] = S.l1s[li][ri][sw_][sh_];
+            } else {
+                // hme_level_2 (:1025-1113)
+                int16_t sa_w = (int16_t)(((int16_t)p.hme_l2_sa.width + 7) & ~0x07), sa_h = (int16_t)p.hme_l2_sa.height;
+                int16_t ox = (int16_t)(-(sa_w >> 1) + S.l1x[li][ri][sw_][sh_]);
+                int16_t oy = (int16_t)(-(sa_h >> 1) + S.l1y[li][ri][sw_][sh_]);
+                hme_clamp((int16_t)org_x, (int16_t)org_y, 63, 63, (int16_t)rp.width, (int16_t)rp.height, &ox, &oy, &sa_w, &sa_h);
+                const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + (int16_t)org_x) + ox);
+                const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + (int16_t)org_y) + oy);
+                set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
+                q_ox = ox, q_oy = oy;
+                go   = true;
+            }
+        }
+    }
+    wg_multi_search(L.sh, nd, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, L.win, ME_WIN_DW);
+    if (go) {
+        int16_t mx = S.l2x[li][ri][sw_][sh_], my = S.l2y[li][ri][sw_][sh_];
+        decode_result(L.sh, tid, hme_sub, &S.l2s[li][ri][sw_][sh_], &mx, &my);
+        S.l2x[li][ri][sw_][sh_] = (int16_t)(mx + q_ox);
+        S.l2y[li][ri][sw_][sh_] = (int16_t)(my + q_oy);
+    }
+    __syncthreads();
+}
+
+// set_final_seach_centre_sb (:2252-2450) + hme_prune_ref_and_adjust_sr (:2547-2588); lane 0 only
+__device__ void centre_prune_lane0(MeLds &L, const Ctx &c) {
+    ME_CTX_LOCALS(c);
     if (tid == 0) {
         int16_t  hx = 0, hy = 0, xc = 0, yc = 0;
         uint64_t hsad = 0;
@@ -910,224 +920,222 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
             }
         }
     }
-    __syncthreads();
+}
 
-    ME_PHASE(6);
-    // ---- integer_search_b64 (motion_estimation.c:1249-1586) ----
-    {
-        const int16_t W = (int16_t)aw, H = (int16_t)ah, pad = 63;
-        const int16_t ox_b = (int16_t)org_x, oy_b = (int16_t)org_y;
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                if (S.sr[li][ri].do_ref == 0)  // uniform: LDS value written before the last barrier
-                    continue;
-                const SvtHipPlane8 &rp = job.ref[li][ri].full;
-                // part 1: search area from settings + HME results
-                if (tid == 0) {
-                    uint16_t dist = pic_dist(p, li, ri);
-                    int16_t  xc = S.sr[li][ri].hme_sc_x, yc = S.sr[li][ri].hme_sc_y;
-                    int16_t  sw = (int16_t)p.me_sa_min.width, sh_ = (int16_t)p.me_sa_min.height;
-                    dist        = scaled_dist(dist);
-                    sw          = (int16_t)MINV((sw * dist), p.me_sa_max.width);
-                    sh_         = (int16_t)MINV((sh_ * dist), p.me_sa_max.height);
-                    if (p.mv_sa_adj_enabled && (!p.mv_sa_adj_nearest_ref_only || ri == 0)) {
-                        if (ABSV(xc) > p.mv_sa_adj_mv_size_th) sw = (int16_t)(sw * p.mv_sa_adj_sa_multiplier);
-                        if (ABSV(yc) > p.mv_sa_adj_mv_size_th) sh_ = (int16_t)(sh_ * p.mv_sa_adj_sa_multiplier);
-                    }
-                    sw  = (int16_t)((MAXV(1u, ((uint32_t)sw / S.reduce_div[li][ri])) + 7) & ~0x07u);
-                    sh_ = (int16_t)MAXV(3u, ((uint32_t)sh_ / S.reduce_div[li][ri]));
-                    S.xc = xc, S.yc = yc, S.sw = sw, S.sh = sh_;
-                    S.need_zero_sad = 0, S.need_hme_sad = 0;
-                    if (p.me_early_exit_th) {
-                        if (S.zz_sad[li][ri] < (p.me_early_exit_th / 6))
-                            S.sw = S.sh = 1;
-                    } else if ((xc != 0 || yc != 0) && p.is_ref) {
-                        // check_00_center needs two 64x(h/2) SADs (:1139-1206)
-                        S.need_zero_sad = 1;  // me_early_exit_th == 0 here, so zz_sad is not available
-                        S.need_hme_sad  = 1;
-                        int16_t cx = xc, cy = yc;
-                        const int16_t RW = (int16_t)rp.width, RH = (int16_t)rp.height;
-                        cx = ((ox_b + cx) < -pad) ? (int16_t)(-pad - ox_b) : cx;
-                        cx = ((ox_b + cx) > RW - 1) ? (int16_t)(cx - ((ox_b + cx) - (RW - 1))) : cx;
-                        cy = ((oy_b + cy) < -pad) ? (int16_t)(-pad - oy_b) : cy;
-                        cy = ((oy_b + cy) > RH - 1) ? (int16_t)(cy - ((oy_b + cy) - (RH - 1))) : cy;
-                        S.xc = cx, S.yc = cy;
-                    }
-                }
-                __syncthreads();
-                if (S.need_zero_sad) {
-                    wg_block_sad(L, plane_at(rp, ox_b, oy_b), rp.stride, b64_w, b64_h >> 1, 2);
-                    if (tid == 0)
-                        S.zero_sad = S.wg_sum;
-                    __syncthreads();
-                    wg_block_sad(L, plane_at(rp, ox_b + S.xc, oy_b + S.yc), rp.stride, b64_w, b64_h >> 1, 2);
-                    if (tid == 0)
-                        S.hme_mv_sad = S.wg_sum;
-                    __syncthreads();
-                }
-                // part 2: finish check_00_center, SR adjustment, decide on the centre probe
-                if (tid == 0) {
-                    int16_t       sw = S.sw, sh_ = S.sh;
-                    const int16_t sw0 = sw, sh0 = sh_;
-                    if (!p.me_early_exit_th) {
-                        uint8_t  accurate     = 1;
-                        uint64_t best_hme_sad = ~(uint64_t)0;
-                        if (S.need_zero_sad) {
-                            const uint32_t zero_sad = S.zero_sad << 1;
-                            const uint32_t hme_sad  = S.hme_mv_sad << 1;
-                            const uint64_t zc = (uint64_t)(zero_sad << 8), hc = (uint64_t)(hme_sad << 8);
-                            const uint64_t cost = MINV(zc, hc);
-                            if (cost == zc)
-                                S.xc = 0, S.yc = 0;
-                            best_hme_sad = hme_sad;
-                            if (S.xc == 0 && S.yc == 0)
-                                accurate = 0;
-                        }
-                        if (p.enable_me_sr_adjustment == 2) {
-                            if ((accurate && (best_hme_sad < (24 * 24))) || (p.is_ref && S.sr[li][ri].hme_sad < (24 * 24)))
-                                sh_ = (int16_t)(sh_ / 2);
-                            if ((li || ri) && S.first_ref_sad64 < 5000 && sh_ == sh0 && sw == sw0) {
-                                sh_ = (int16_t)(sh_ >> 1);
-                                sw  = (int16_t)(sw >> 1);
-                            }
-                        }
-                    }
-                    S.sw = sw, S.sh = sh_;
-                    S.do_centre = p.me_8x8_var_enabled && (sw * sh_ > 24);
-                    S.staged    = 0;
-                    if (S.do_centre) {
-                        // Stage once for the centre probe AND the search: the block of positions spanned by the centre and by
-                        // the window these settings give (the 8x8-variance rule below can only shrink it around the same
-                        // centre).  Origin congruent to the centre mod 4 keeps both dword-aligned in the staged tile.
-                        int16_t cw_ = sw, chh = sh_, cx0, cy0;
-                        clamp_me_window(S.xc, S.yc, ox_b, oy_b, W, H, pad, &cw_, &chh, &cx0, &cy0);
-                        int x0 = MINV((int)S.xc, (int)cx0), x1 = MAXV((int)S.xc + 1, (int)cx0 + (cw_ > 0 ? cw_ : 0));
-                        int y0 = MINV((int)S.yc, (int)cy0), y1 = MAXV((int)S.yc + 1, (int)cy0 + (chh > 0 ? chh : 0));
-                        x0 -= (x0 - (int)S.xc) & 3;
-                        if (x1 - x0 > (int)FP_TILE_W || (uint32_t)(y1 - y0 + 63) * fp_pitch((uint32_t)(x1 - x0)) > ME_WIN_DW)
-                            x0 = S.xc, x1 = S.xc + 1, y0 = S.yc, y1 = S.yc + 1;  // does not fit: the centre alone
-                        S.stx = (int16_t)x0, S.sty = (int16_t)y0, S.stw = (int16_t)(x1 - x0), S.sth = (int16_t)(y1 - y0);
-                        S.staged = 1;
-                    }
-                }
-                if (tid < 85)
-                    L.bestkey[tid] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
-                __syncthreads();
-                if (S.do_centre) {
-                    fp_stage(L, plane_at(rp, ox_b + S.stx, oy_b + S.sty), rp.stride, (uint32_t)S.stw, (uint32_t)S.sth);
-                    fp_search(L, fp_pitch((uint32_t)S.stw), (uint32_t)(S.xc - S.stx), (uint32_t)(S.yc - S.sty), 1, 1, 0, 1, me_sub);
-                    if (tid < 64) {  // variance of the 64 8x8 SADs at the centre (:1393-1441)
-                        const uint32_t v    = (uint32_t)(L.bestkey[21 + tid] >> 32);
-                        const uint32_t mean = (uint32_t)(L.bestkey[0] >> 32) / 64;
-                        const int32_t  dv   = (int32_t)v - (int32_t)mean;
-                        const uint32_t ssq  = wave_sum((uint32_t)(dv * dv));
-                        if (tid == 0) {
-                            int16_t        sw = S.sw, sh_ = S.sh;
-                            const uint32_t var = ssq / 64;
-                            if (var > p.me_sr_mult2_th) {
-                                sw  = (int16_t)((MAXV(1, sw * 3 / 2) + 7) & ~0x7);
-                                sh_ = (int16_t)MAXV(1, sh_ * 3 / 2);
-                            }
-                            if (var < p.me_sr_div4_th) {
-                                sw  = (int16_t)((MAXV(1, sw >> 2) + 7) & ~0x7);
-                                sh_ = (int16_t)MAXV(1, sh_ >> 2);
-                                sh_ = (int16_t)MAXV(3, sh_);
-                            } else if (var < p.me_sr_div2_th) {
-                                sw  = (int16_t)((MINV(sw, sw >> 1) + 7) & ~0x7);
-                                sh_ = (int16_t)MINV(sh_, sh_ >> 1);
-                                sh_ = (int16_t)MAXV(3, sh_);
-                            }
-                            S.sw = sw, S.sh = sh_;
-                        }
-                    }
-                    __syncthreads();
-                }
-                // part 3: final window (:1442-1561)
-                if (tid == 0) {
-                    int16_t sw = S.sw, sh_ = S.sh, ox, oy;
-                    clamp_me_window(S.xc, S.yc, ox_b, oy_b, W, H, pad, &sw, &sh_, &ox, &oy);
-                    S.sw = sw, S.sh = sh_, S.ox = ox, S.oy = oy;
-                    // reuse the staged block if the final window lies inside it, dword-aligned
-                    S.restage = !(S.staged && ox >= S.stx && oy >= S.sty && ox + (sw > 0 ? sw : 0) <= S.stx + S.stw &&
-                                  oy + (sh_ > 0 ? sh_ : 0) <= S.sty + S.sth && ((ox - S.stx) & 3) == 0);
-                }
-                __syncthreads();
-                {
-                    const int      ox = S.ox, oy = S.oy;
-                    const uint32_t sw = (uint32_t)(S.sw > 0 ? S.sw : 0), sh_ = (uint32_t)(S.sh > 0 ? S.sh : 0);
-                    if (!S.restage) {
-                        fp_search(L, fp_pitch((uint32_t)S.stw), (uint32_t)(ox - S.stx), (uint32_t)(oy - S.sty), sw, sh_, 1, sw, me_sub);
-                    } else {
-                        // tiles that fit the window buffer
-                        const uint32_t tw = sw < FP_TILE_W ? sw : FP_TILE_W;
-                        const uint32_t pitch_t = fp_pitch(tw);
-                        uint32_t       th      = tw ? MINV(sh_, ME_WIN_DW / pitch_t - 63) : 0;
-                        for (uint32_t ty = 0; th && ty < sh_; ty += th)
-                            for (uint32_t tx = 0; tx < sw; tx += tw) {
-                                const uint32_t cw = MINV(tw, sw - tx), ch = MINV(th, sh_ - ty);
-                                fp_stage(L, plane_at(rp, ox_b + ox + (int)tx, oy_b + oy + (int)ty), rp.stride, cw, ch);
-                                fp_search(L, fp_pitch(cw), 0, 0, cw, ch, 1 + ty * sw + tx, sw, me_sub);
-                            }
-                    }
-                    // keys -> p_sb_best_sad / p_sb_best_mv of this reference
-                    uint32_t my_sad = 0;
-                    if (tid < 85) {
-                        const uint64_t key = L.bestkey[tid];
-                        const uint32_t ord = (uint32_t)key;
-                        my_sad             = (uint32_t)(key >> 32);
-                        gs[(li * NR + ri) * 85 + tid] = my_sad;
-                        if (li == 0 && ri == 0 && tid == 0)
-                            S.first_ref_sad64 = my_sad;
-                        if (ord != 0xffffffffu) {
-                            int16_t mx, my;
-                            if (ord == 0) {
-                                mx = S.xc, my = S.yc;
-                            } else {
-                                const uint32_t pos = ord - 1;
-                                mx = (int16_t)((int)(pos % sw) + ox), my = (int16_t)((int)(pos / sw) + oy);
-                            }
-                            gm[(li * NR + ri) * 85 + tid] = ((uint32_t)(uint16_t)my << 16) | (uint16_t)mx;
-                        }
-                    }
-                    // sum of the 64 8x8 SADs (tab8x8 is a permutation, so the plain sum equals :1608-1611)
-                    if (tid < 128) {
-                        const uint32_t part = wave_sum((tid >= 21 && tid < 85) ? my_sad : 0u);
-                        if ((tid & 63) == 0)
-                            atomicAdd((unsigned long long *)&S.me_sad_sum[li][ri], (unsigned long long)part);
-                    }
-                }
-                __syncthreads();
-            }
+// integer_search_b64 (motion_estimation.c:1249-1586) for one reference; all threads.  `store`: write the winners to the
+// output arrays and accumulate the 8x8 SAD sum (false when the reference is only evaluated for first_ref_sad64).
+__device__ void fullpel_ref(MeLds &L, const Ctx &c, int li, int ri, bool store) {
+    ME_CTX_LOCALS(c);
+    const int16_t W = (int16_t)aw, H = (int16_t)ah, pad = 63;
+    const int16_t ox_b = (int16_t)org_x, oy_b = (int16_t)org_y;
+    const SvtHipPlane8 &rp = job.ref[li][ri].full;
+    // part 1: search area from settings + HME results
+    if (tid == 0) {
+        uint16_t dist = pic_dist(p, li, ri);
+        int16_t  xc = S.sr[li][ri].hme_sc_x, yc = S.sr[li][ri].hme_sc_y;
+        int16_t  sw = (int16_t)p.me_sa_min.width, sh_ = (int16_t)p.me_sa_min.height;
+        dist        = scaled_dist(dist);
+        sw          = (int16_t)MINV((sw * dist), p.me_sa_max.width);
+        sh_         = (int16_t)MINV((sh_ * dist), p.me_sa_max.height);
+        if (p.mv_sa_adj_enabled && (!p.mv_sa_adj_nearest_ref_only || ri == 0)) {
+            if (ABSV(xc) > p.mv_sa_adj_mv_size_th) sw = (int16_t)(sw * p.mv_sa_adj_sa_multiplier);
+            if (ABSV(yc) > p.mv_sa_adj_mv_size_th) sh_ = (int16_t)(sh_ * p.mv_sa_adj_sa_multiplier);
+        }
+        sw  = (int16_t)((MAXV(1u, ((uint32_t)sw / S.reduce_div[li][ri])) + 7) & ~0x07u);
+        sh_ = (int16_t)MAXV(3u, ((uint32_t)sh_ / S.reduce_div[li][ri]));
+        S.xc = xc, S.yc = yc, S.sw = sw, S.sh = sh_;
+        S.need_zero_sad = 0, S.need_hme_sad = 0;
+        if (p.me_early_exit_th) {
+            if (S.zz_sad[li][ri] < (p.me_early_exit_th / 6))
+                S.sw = S.sh = 1;
+        } else if ((xc != 0 || yc != 0) && p.is_ref) {
+            // check_00_center needs two 64x(h/2) SADs (:1139-1206)
+            S.need_zero_sad = 1;  // me_early_exit_th == 0 here, so zz_sad is not available
+            S.need_hme_sad  = 1;
+            int16_t cx = xc, cy = yc;
+            const int16_t RW = (int16_t)rp.width, RH = (int16_t)rp.height;
+            cx = ((ox_b + cx) < -pad) ? (int16_t)(-pad - ox_b) : cx;
+            cx = ((ox_b + cx) > RW - 1) ? (int16_t)(cx - ((ox_b + cx) - (RW - 1))) : cx;
+            cy = ((oy_b + cy) < -pad) ? (int16_t)(-pad - oy_b) : cy;
+            cy = ((oy_b + cy) > RH - 1) ? (int16_t)(cy - ((oy_b + cy) - (RH - 1))) : cy;
+            S.xc = cx, S.yc = cy;
+        }
     }
-
-    ME_PHASE(7);
-    // ---- me_prune_ref (motion_estimation.c:1592-1635) ----
-    if (p.enable_hme_flag && p.enable_me_hme_ref_pruning) {
-        if (tid == 0) {
-            for (int li = 0; li < nlists; ++li)
-                for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                    S.sr[li][ri].hme_sad = 0;
-                    if (S.sr[li][ri].do_ref == 0) {
-                        S.sr[li][ri].hme_sad = (uint64_t)(MAX_SAD_VALUE_ * 64);
-                        continue;
-                    }
-                    S.sr[li][ri].hme_sad = S.me_sad_sum[li][ri];
+    __syncthreads();
+    if (S.need_zero_sad) {
+        wg_block_sad(L, plane_at(rp, ox_b, oy_b), rp.stride, b64_w, b64_h >> 1, 2);
+        if (tid == 0)
+            S.zero_sad = S.wg_sum;
+        __syncthreads();
+        wg_block_sad(L, plane_at(rp, ox_b + S.xc, oy_b + S.yc), rp.stride, b64_w, b64_h >> 1, 2);
+        if (tid == 0)
+            S.hme_mv_sad = S.wg_sum;
+        __syncthreads();
+    }
+    // part 2: finish check_00_center, SR adjustment, decide on the centre probe
+    if (tid == 0) {
+        int16_t       sw = S.sw, sh_ = S.sh;
+        const int16_t sw0 = sw, sh0 = sh_;
+        if (!p.me_early_exit_th) {
+            uint8_t  accurate     = 1;
+            uint64_t best_hme_sad = ~(uint64_t)0;
+            if (S.need_zero_sad) {
+                const uint32_t zero_sad = S.zero_sad << 1;
+                const uint32_t hme_sad  = S.hme_mv_sad << 1;
+                const uint64_t zc = (uint64_t)(zero_sad << 8), hc = (uint64_t)(hme_sad << 8);
+                const uint64_t cost = MINV(zc, hc);
+                if (cost == zc)
+                    S.xc = 0, S.yc = 0;
+                best_hme_sad = hme_sad;
+                if (S.xc == 0 && S.yc == 0)
+                    accurate = 0;
+            }
+            if (p.enable_me_sr_adjustment == 2) {
+                if ((accurate && (best_hme_sad < (24 * 24))) || (p.is_ref && S.sr[li][ri].hme_sad < (24 * 24)))
+                    sh_ = (int16_t)(sh_ / 2);
+                if ((li || ri) && S.first_ref_sad64 < 5000 && sh_ == sh0 && sw == sw0) {
+                    sh_ = (int16_t)(sh_ >> 1);
+                    sw  = (int16_t)(sw >> 1);
                 }
-            const uint16_t th = p.prune_ref_if_me_sad_dev_bigger_than_th;
-            if (th != (uint16_t)~0) {
-                uint64_t best = ~(uint64_t)0;
-                for (int i = 0; i < NL; i++)
-                    for (int j = 0; j < NR; j++)
-                        if (S.sr[i][j].hme_sad < best) best = S.sr[i][j].hme_sad;
-                for (int i = 0; i < NL; i++)
-                    for (int j = 1; j < NR; j++)
-                        if ((S.sr[i][j].hme_sad - best) * 100 > (th * best)) S.sr[i][j].do_ref = 0;
+            }
+        }
+        S.sw = sw, S.sh = sh_;
+        S.do_centre = p.me_8x8_var_enabled && (sw * sh_ > 24);
+        S.staged    = 0;
+        if (S.do_centre) {
+            // Stage once for the centre probe AND the search: the block of positions spanned by the centre and by
+            // the window these settings give (the 8x8-variance rule below can only shrink it around the same
+            // centre).  Origin congruent to the centre mod 4 keeps both dword-aligned in the staged tile.
+            int16_t cw_ = sw, chh = sh_, cx0, cy0;
+            clamp_me_window(S.xc, S.yc, ox_b, oy_b, W, H, pad, &cw_, &chh, &cx0, &cy0);
+            int x0 = MINV((int)S.xc, (int)cx0), x1 = MAXV((int)S.xc + 1, (int)cx0 + (cw_ > 0 ? cw_ : 0));
+            int y0 = MINV((int)S.yc, (int)cy0), y1 = MAXV((int)S.yc + 1, (int)cy0 + (chh > 0 ? chh : 0));
+            x0 -= (x0 - (int)S.xc) & 3;
+            if (x1 - x0 > (int)FP_TILE_W || (uint32_t)(y1 - y0 + 63) * fp_pitch((uint32_t)(x1 - x0)) > ME_WIN_DW)
+                x0 = S.xc, x1 = S.xc + 1, y0 = S.yc, y1 = S.yc + 1;  // does not fit: the centre alone
+            S.stx = (int16_t)x0, S.sty = (int16_t)y0, S.stw = (int16_t)(x1 - x0), S.sth = (int16_t)(y1 - y0);
+            S.staged = 1;
+        }
+    }
+    for (uint32_t pu = tid; pu < 85; pu += blockDim.x) L.bestkey[pu] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
+    __syncthreads();
+    if (S.do_centre) {
+        fp_stage(L, plane_at(rp, ox_b + S.stx, oy_b + S.sty), rp.stride, (uint32_t)S.stw, (uint32_t)S.sth);
+        fp_search(L, fp_pitch((uint32_t)S.stw), (uint32_t)(S.xc - S.stx), (uint32_t)(S.yc - S.sty), 1, 1, 0, 1, me_sub);
+        if (tid < 64) {  // variance of the 64 8x8 SADs at the centre (:1393-1441)
+            const uint32_t v    = (uint32_t)(L.bestkey[21 + tid] >> 32);
+            const uint32_t mean = (uint32_t)(L.bestkey[0] >> 32) / 64;
+            const int32_t  dv   = (int32_t)v - (int32_t)mean;
+            const uint32_t ssq  = wave_sum((uint32_t)(dv * dv));
+            if (tid == 0) {
+                int16_t        sw = S.sw, sh_ = S.sh;
+                const uint32_t var = ssq / 64;
+                if (var > p.me_sr_mult2_th) {
+                    sw  = (int16_t)((MAXV(1, sw * 3 / 2) + 7) & ~0x7);
+                    sh_ = (int16_t)MAXV(1, sh_ * 3 / 2);
+                }
+                if (var < p.me_sr_div4_th) {
+                    sw  = (int16_t)((MAXV(1, sw >> 2) + 7) & ~0x7);
+                    sh_ = (int16_t)MAXV(1, sh_ >> 2);
+                    sh_ = (int16_t)MAXV(3, sh_);
+                } else if (var < p.me_sr_div2_th) {
+                    sw  = (int16_t)((MINV(sw, sw >> 1) + 7) & ~0x7);
+                    sh_ = (int16_t)MINV(sh_, sh_ >> 1);
+                    sh_ = (int16_t)MAXV(3, sh_);
+                }
+                S.sw = sw, S.sh = sh_;
             }
         }
         __syncthreads();
     }
+    // part 3: final window (:1442-1561)
+    if (tid == 0) {
+        int16_t sw = S.sw, sh_ = S.sh, ox, oy;
+        clamp_me_window(S.xc, S.yc, ox_b, oy_b, W, H, pad, &sw, &sh_, &ox, &oy);
+        S.sw = sw, S.sh = sh_, S.ox = ox, S.oy = oy;
+        // reuse the staged block if the final window lies inside it, dword-aligned
+        S.restage = !(S.staged && ox >= S.stx && oy >= S.sty && ox + (sw > 0 ? sw : 0) <= S.stx + S.stw &&
+                      oy + (sh_ > 0 ? sh_ : 0) <= S.sty + S.sth && ((ox - S.stx) & 3) == 0);
+    }
+    __syncthreads();
+    {
+        const int      ox = S.ox, oy = S.oy;
+        const uint32_t sw = (uint32_t)(S.sw > 0 ? S.sw : 0), sh_ = (uint32_t)(S.sh > 0 ? S.sh : 0);
+        if (!S.restage) {
+            fp_search(L, fp_pitch((uint32_t)S.stw), (uint32_t)(ox - S.stx), (uint32_t)(oy - S.sty), sw, sh_, 1, sw, me_sub);
+        } else {
+            // tiles that fit the window buffer
+            const uint32_t tw = sw < FP_TILE_W ? sw : FP_TILE_W;
+            const uint32_t pitch_t = fp_pitch(tw);
+            uint32_t       th      = tw ? MINV(sh_, ME_WIN_DW / pitch_t - 63) : 0;
+            for (uint32_t ty = 0; th && ty < sh_; ty += th)
+                for (uint32_t tx = 0; tx < sw; tx += tw) {
+                    const uint32_t cw = MINV(tw, sw - tx), ch = MINV(th, sh_ - ty);
+                    fp_stage(L, plane_at(rp, ox_b + ox + (int)tx, oy_b + oy + (int)ty), rp.stride, cw, ch);
+                    fp_search(L, fp_pitch(cw), 0, 0, cw, ch, 1 + ty * sw + tx, sw, me_sub);
+                }
+        }
+        // keys -> p_sb_best_sad / p_sb_best_mv of this reference
+        uint32_t part = 0;  // this lane's share of the sum of the 64 8x8 SADs (tab8x8 is a permutation, :1608-1611)
+        for (uint32_t pu = tid; pu < 85; pu += blockDim.x) {
+            const uint64_t key    = L.bestkey[pu];
+            const uint32_t ord    = (uint32_t)key;
+            const uint32_t my_sad = (uint32_t)(key >> 32);
+            if (li == 0 && ri == 0 && pu == 0)
+                S.first_ref_sad64 = my_sad;
+            if (pu >= 21)
+                part += my_sad;
+            if (!store)
+                continue;
+            gs[(li * NR + ri) * 85 + pu] = my_sad;
+            if (ord != 0xffffffffu) {
+                int16_t mx, my;
+                if (ord == 0) {
+                    mx = S.xc, my = S.yc;
+                } else {
+                    const uint32_t pos = ord - 1;
+                    mx = (int16_t)((int)(pos % sw) + ox), my = (int16_t)((int)(pos / sw) + oy);
+                }
+                gm[(li * NR + ri) * 85 + pu] = ((uint32_t)(uint16_t)my << 16) | (uint16_t)mx;
+            }
+        }
+        part = wave_sum(part);
+        if (store && (tid & 63) == 0 && part)
+            atomicAdd((unsigned long long *)&S.me_sad_sum[li][ri], (unsigned long long)part);
+    }
+    __syncthreads();
+}
 
-    ME_PHASE(8);
+// me_prune_ref (motion_estimation.c:1592-1635); lane 0 only
+__device__ void me_prune_lane0(MeLds &L, const Ctx &c) {
+    ME_CTX_LOCALS(c);
+    if (tid == 0) {
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
+                S.sr[li][ri].hme_sad = 0;
+                if (S.sr[li][ri].do_ref == 0) {
+                    S.sr[li][ri].hme_sad = (uint64_t)(MAX_SAD_VALUE_ * 64);
+                    continue;
+                }
+                S.sr[li][ri].hme_sad = S.me_sad_sum[li][ri];
+            }
+        const uint16_t th = p.prune_ref_if_me_sad_dev_bigger_than_th;
+        if (th != (uint16_t)~0) {
+            uint64_t best = ~(uint64_t)0;
+            for (int i = 0; i < NL; i++)
+                for (int j = 0; j < NR; j++)
+                    if (S.sr[i][j].hme_sad < best) best = S.sr[i][j].hme_sad;
+            for (int i = 0; i < NL; i++)
+                for (int j = 1; j < NR; j++)
+                    if ((S.sr[i][j].hme_sad - best) * 100 > (th * best)) S.sr[i][j].do_ref = 0;
+        }
+    }
+}
+
+// candidates (motion_estimation.c:3196-3211), compute_distortion (:3034-3077) and the per-reference search results
+__device__ void finalize_b64(MeLds &L, const Ctx &c) {
+    ME_CTX_LOCALS(c);
+    const uint32_t b64 = c.b64;
     // ---- candidates (motion_estimation.c:3196-3211) ----
     const SvtHipMeFrameOut &out    = job.out;
     const uint32_t          stored = p.enable_me_16x16 ? (p.enable_me_8x8 ? 85u : 21u) : 5u;
@@ -1149,7 +1157,6 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
     }
     __syncthreads();
 
-    ME_PHASE(9);
     // ---- compute_distortion (motion_estimation.c:3034-3077) + result write-back ----
     if (tid == 0) {
         uint32_t d64 = L.me_dist[0], d32 = 0, d16 = 0, d8 = 0;
@@ -1172,6 +1179,84 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
     }
     if (tid < NL * NR)
         out.search_results[(size_t)b64 * NL * NR + tid] = (&S.sr[0][0])[tid];
+    if (tid < NL * NR)
+        job.out.search_results[(size_t)b64 * NL * NR + tid] = (&S.sr[0][0])[tid];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// One launch, one workgroup per b64: all stages back to back (lowest latency for a single picture).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
+    __shared__ MeLds L;
+#ifdef SVT_HIP_ME_PROFILE
+    unsigned long long prof_last = wall_clock64();
+#endif
+    Ctx c;
+    if (!make_ctx(c, jobs[blockIdx.y], blockIdx.x))
+        return;
+    ME_CTX_LOCALS(c);
+    stage_sources(L, c, 7);
+    for (uint32_t i = tid; i < NL * NR * 85; i += blockDim.x) gs[i] = 0, gm[i] = 0;
+    init_state_lane0(L, c);
+    __syncthreads();
+    ME_PHASE(0);
+    if (p.me_early_exit_th || p.me_safe_limit_zz_th) {
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
+                if (tl > 0 || li == 0)
+                    zz_sad_ref(L, c, li, ri);
+        zz_prune_lane0(L, c);
+        __syncthreads();
+    }
+    ME_PHASE(1);
+    if (p.prehme_enable) {
+        // List 1 reads list 0's results for the l1 early exit (:1771-1781) and for the tl == 0 mirror (:1853-1860); only
+        // then does it need a round of its own — otherwise all references are searched by one call.
+        const bool split = nlists == 2 && (p.prehme_l1_early_exit || tl == 0);
+        if (split) {
+            prehme_round(L, c, 0, R0, true);
+            prehme_round(L, c, R0, nref, tl > 0);
+        } else {
+            prehme_round(L, c, 0, nref, true);
+        }
+        phme_prune_lane0(L, c);
+        __syncthreads();
+    }
+    ME_PHASE(2);
+    if (p.enable_hme_flag && p.enable_hme_level0_flag) {
+        // With distance-based resizing, references other than the first read the first one's quadrant-(0,0) vector
+        // (get_hme_l0_search_area, :1881-1890): the first reference then gets a round of its own.
+        const bool dep = p.enable_me_sr_adjustment && p.distance_based_hme_resizing && p.reduce_hme_l0_sr_th_min &&
+            p.reduce_hme_l0_sr_th_max && nref > 1;
+        if (dep) {
+            hme_l0_round(L, c, 0, 1);
+            hme_l0_round(L, c, 1, nref);
+        } else {
+            hme_l0_round(L, c, 0, nref);
+        }
+    }
+    ME_PHASE(3);
+    if (p.enable_hme_flag && p.enable_hme_level1_flag)
+        hme_l1_round(L, c, 0, nref);
+    ME_PHASE(4);
+    if (p.enable_hme_flag && p.enable_hme_level2_flag)
+        hme_l2_round(L, c, 0, nref);
+    ME_PHASE(5);
+    centre_prune_lane0(L, c);
+    __syncthreads();
+    ME_PHASE(6);
+    for (int li = 0; li < nlists; ++li)
+        for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
+            if (S.sr[li][ri].do_ref)  // uniform: LDS value written before the last barrier
+                fullpel_ref(L, c, li, ri, true);
+    ME_PHASE(7);
+    if (p.enable_hme_flag && p.enable_me_hme_ref_pruning) {
+        me_prune_lane0(L, c);
+        __syncthreads();
+    }
+    ME_PHASE(8);
+    finalize_b64(L, c);
     ME_PHASE(10);
 }
 

@@ -300,11 +300,11 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
         // stage: one flat index space over the (64-dword aligned) segments; a wave always works inside one segment,
         // so the descriptor reads are broadcasts; four independent loads in flight per thread
         const uint32_t total = sh.nstage_dw;
-        for (uint32_t base = tid; base < total; base += 4 * WG_THREADS) {
+        for (uint32_t base = tid; base < total; base += 4 * blockDim.x) {
             uint32_t v[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t idx = base + u * WG_THREADS;
+                const uint32_t idx = base + u * blockDim.x;
                 v[u]               = 0;
                 if (idx < total) {
                     const SearchSeg  &sg  = sh.seg[sh.chunk_seg[idx / SEG_ALIGN]];
@@ -318,7 +318,7 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t idx = base + u * WG_THREADS;
+                const uint32_t idx = base + u * blockDim.x;
                 if (idx < total)
                     win[idx] = v[u];
             }
@@ -327,7 +327,7 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
         MS_PHASE(1);
         // search
         const uint32_t nitems = sh.nitems;
-        for (uint32_t item = tid; item < nitems; item += WG_THREADS) {
+        for (uint32_t item = tid; item < nitems; item += blockDim.x) {
             const uint32_t   s  = find_seg<true>(sh, nseg, item);
             const SearchSeg  sg = sh.seg[s];
             const SearchDesc &ds = sh.desc[sg.d];
@@ -374,7 +374,7 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
         const uint32_t npos = ds.n_srows * (uint32_t)ds.sa_w;
         const uint8_t *sb   = (const uint8_t *)src;
         uint64_t       key  = KEY_NONE;
-        for (uint32_t p = tid; p < npos; p += WG_THREADS) {
+        for (uint32_t p = tid; p < npos; p += blockDim.x) {
             const uint32_t j = p / (uint32_t)ds.sa_w, sx = p - j * (uint32_t)ds.sa_w;
             const uint32_t sy = ds.skip ? 2 * j + 1 : j;
             const uint8_t *g  = ds.ref + (size_t)sy * ds.raw_stride + sx;
