@@ -67,6 +67,7 @@ struct B64State {
 };
 
 struct MeLds {
+    static constexpr uint32_t WIN_DW = ME_WIN_DW;
     SearchShared sh;
     B64State     st;
     alignas(16) uint32_t win[ME_WIN_DW];
@@ -95,7 +96,8 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *g) { retur
 
 // Workgroup-wide SAD between the staged 64x64 source (rows 0,2,4.. when `sub`) and a global block.
 // Result in L.st.wg_sum (valid after the trailing barrier).  width must be a multiple of 4.
-__device__ void wg_block_sad(MeLds &L, const uint8_t *ref, uint32_t ref_stride, uint32_t width, uint32_t rows,
+template <class LDS>
+__device__ void wg_block_sad(LDS &L, const uint8_t *ref, uint32_t ref_stride, uint32_t width, uint32_t rows,
                              uint32_t row_step) {
     if (threadIdx.x == 0)
         L.st.wg_sum = 0;
@@ -151,7 +153,8 @@ __device__ void set_desc(SearchDesc &d, const SvtHipMeParams &p, const SvtHipPla
     d.skip          = skip;
 }
 
-__device__ void decode_result(const SearchShared &sh, uint32_t i, bool sub, uint64_t *sad, int16_t *x, int16_t *y) {
+template <class SH>
+__device__ void decode_result(const SH &sh, uint32_t i, bool sub, uint64_t *sad, int16_t *x, int16_t *y) {
     const uint64_t key = sh.best[i];
     uint64_t       s   = key >> 32;
     if (key != KEY_NONE) {
@@ -208,21 +211,26 @@ __device__ void clamp_me_window(int16_t xc, int16_t yc, int16_t ox_b, int16_t oy
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fp_pitch(uint32_t tw) { return (((tw + 3) >> 2) + 17) | 1u; }
 
-__device__ void fp_stage(MeLds &L, const uint8_t *win_org, uint32_t stride, uint32_t tw, uint32_t th) {
-    const uint32_t tid = threadIdx.x, pitch = fp_pitch(tw), total = (th + 63) * pitch, inv = make_inv(pitch);
-    for (uint32_t base = tid; base < total; base += 4 * blockDim.x) {
-        uint32_t v[4];
+template <class LDS>
+__device__ void fp_stage(LDS &L, const uint8_t *win_org, uint32_t stride, uint32_t tw, uint32_t th) {
+    // 32 lanes per window row (rows are 17..33 dwords), four rows in flight per lane
+    const uint32_t tid = threadIdx.x, pitch = fp_pitch(tw), rows = th + 63, rpp = blockDim.x >> 5;
+    const uint32_t c0 = tid & 31, r0 = tid >> 5;
+    for (uint32_t col = c0; col < pitch; col += 32)
+        for (uint32_t row = r0; row < rows; row += 4 * rpp) {
+            uint32_t v[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t idx = base + u * blockDim.x;
-            const uint32_t r = fast_div(idx, inv), i = idx - r * pitch;
-            v[u]             = idx < total ? load_u32_unaligned(win_org + (size_t)r * stride + 4 * i) : 0u;
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t rr = row + u * rpp;
+                v[u]              = rr < rows ? load_u32_unaligned(win_org + (size_t)rr * stride + 4 * col) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t rr = row + u * rpp;
+                if (rr < rows)
+                    L.win[rr * pitch + col] = v[u];
+            }
         }
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++)
-            if (base + u * blockDim.x < total)
-                L.win[base + u * blockDim.x] = v[u];
-    }
     __syncthreads();
 }
 
@@ -231,7 +239,8 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-__device__ void fp_search(MeLds &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint32_t cw, uint32_t ch, uint32_t order0,
+template <class LDS>
+__device__ void fp_search(LDS &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint32_t cw, uint32_t ch, uint32_t order0,
                           uint32_t order_pitch, bool sub) {
     const uint32_t tid = threadIdx.x;
     const uint32_t nq = (cw + 3) >> 2, nitems = nq * ch * 16, inv_nq = make_inv(nq);
@@ -323,7 +332,8 @@ __device__ __forceinline__ int use_me_pu(const SvtHipMeParams &p, uint32_t n) {
 #define GS(li, ri, n) gs[((li) * NR + (ri)) * 85 + (n)]
 #define GM(li, ri, n) gm[((li) * NR + (ri)) * 85 + (n)]
 
-__device__ void cand_single_ref(MeLds &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+template <class LDS>
+__device__ void cand_single_ref(LDS &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
                                 uint32_t *mv, uint8_t *cand) {
     const uint8_t pu = z_to_raster_d[n];
     L.me_dist[pu]    = GS(0, 0, n);
@@ -335,7 +345,8 @@ __device__ void cand_single_ref(MeLds &L, const SvtHipMeParams &p, const uint32_
     }
 }
 
-__device__ void cand_mrp_off(MeLds &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+template <class LDS>
+__device__ void cand_mrp_off(LDS &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
                              uint32_t nlist, uint32_t *mv, uint8_t *cand, uint8_t *total) {
     const uint8_t org0 = L.st.sr[0][0].do_ref, org1 = (uint8_t)((nlist == 1) ? 0 : L.st.sr[1][0].do_ref);
     if (nlist < 2 || !L.st.sr[1][0].do_ref)
@@ -380,7 +391,8 @@ __device__ void cand_mrp_off(MeLds &L, const SvtHipMeParams &p, const uint32_t *
     }
 }
 
-__device__ void cand_general(MeLds &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+template <class LDS>
+__device__ void cand_general(LDS &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
                              uint32_t nlist, uint32_t *mv, uint8_t *cand, uint8_t *total) {
     const uint8_t pu  = (n > 4) ? z_to_raster_d[n] : (uint8_t)n;
     uint8_t       off = 0;
@@ -457,8 +469,9 @@ __device__ unsigned long long g_me_prof[16];
 
 // ------------------------------------------------------------------------------------------------
 // Stage functions.  Every stage of svt_aom_motion_estimation_b64 is a device function over the per-b64 state in LDS
-// (B64State) so that the same code serves the one-launch kernel (all stages of one b64 in one workgroup) and the staged
-// pipeline (one workgroup per b64 x reference for the search stages).  `Ctx` carries the uniform geometry.
+// (B64State); `Ctx` carries the uniform geometry.  (A staged variant — one workgroup per b64 x reference and stage, handing
+// results over through global records — was measured at 1.46 ms against 0.98 ms for the one-launch kernel on the bench
+// workload: the kernel is instruction-issue bound, and the staged form repeats the scalar set-up per reference.)
 // ------------------------------------------------------------------------------------------------
 struct Ctx {
     const SvtHipMeFrameJob *job;
@@ -502,7 +515,8 @@ __device__ bool make_ctx(Ctx &c, const SvtHipMeFrameJob &job, uint32_t bx) {
 
 
 // source blocks of this b64 (me_process.c:183-214): which = 1 full | 2 quarter | 4 sixteenth
-__device__ void stage_sources(MeLds &L, const Ctx &c, int which) {
+template <class LDS>
+__device__ void stage_sources(LDS &L, const Ctx &c, int which) {
     ME_CTX_LOCALS(c);
     if (which & 1)
         for (uint32_t idx = tid; idx < 64 * 16; idx += blockDim.x) {
@@ -522,7 +536,8 @@ __device__ void stage_sources(MeLds &L, const Ctx &c, int which) {
 }
 
 // init_me_hme_data (motion_estimation.c:3080-3140); lane 0 only
-__device__ void init_state_lane0(MeLds &L, const Ctx &c) {
+template <class LDS>
+__device__ void init_state_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
     if (tid == 0) {
         S.first_ref_sad64 = 0;
@@ -550,7 +565,8 @@ __device__ void init_state_lane0(MeLds &L, const Ctx &c) {
 }
 
 // zero-MV SAD of one reference (init_zz_sad, motion_estimation.c:2452-2470); all threads, ends with a barrier
-__device__ void zz_sad_ref(MeLds &L, const Ctx &c, int li, int ri) {
+template <class LDS>
+__device__ void zz_sad_ref(LDS &L, const Ctx &c, int li, int ri) {
     ME_CTX_LOCALS(c);
     const SvtHipPlane8 &rp = job.ref[li][ri].full;
     wg_block_sad(L, plane_at(rp, (int16_t)org_x, (int16_t)org_y), rp.stride, b64_w, b64_h >> 1, 2);
@@ -563,7 +579,8 @@ __device__ void zz_sad_ref(MeLds &L, const Ctx &c, int li, int ri) {
 }
 
 // zz-SAD based reference pruning (init_zz_sad, motion_estimation.c:2471-2504); lane 0 only
-__device__ void zz_prune_lane0(MeLds &L, const Ctx &c) {
+template <class LDS>
+__device__ void zz_prune_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
     if (tid == 0) {
         uint32_t best = MAX_U32_;
@@ -592,7 +609,8 @@ __device__ void zz_prune_lane0(MeLds &L, const Ctx &c) {
 
 // prehme_b64 (motion_estimation.c:1792-1866) for references [f0, f1): one lane per (reference, region) sets its
 // descriptor up, ONE wg_multi_search call searches them all, the same lane decodes.  Ends with a barrier.
-__device__ void prehme_round(MeLds &L, const Ctx &c, int f0, int f1, bool searching) {
+template <class LDS>
+__device__ void prehme_round(LDS &L, const Ctx &c, int f0, int f1, bool searching) {
     ME_CTX_LOCALS(c);
     const int      f  = f0 + (int)(tid >> 1), si = (int)(tid & 1);
     const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
@@ -649,7 +667,7 @@ __device__ void prehme_round(MeLds &L, const Ctx &c, int f0, int f1, bool search
     }
     if (searching) {
         wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
-                        ME_WIN_DW);
+                        LDS::WIN_DW);
         if (go) {
             PreHme &d = S.ph[li][ri][si];
             decode_result(L.sh, tid, hme_sub, &d.sad, &d.col, &d.row);
@@ -664,7 +682,8 @@ __device__ void prehme_round(MeLds &L, const Ctx &c, int f0, int f1, bool search
 }
 
 // pre-HME based reference pruning (:1851-1865); lane 0 only
-__device__ void phme_prune_lane0(MeLds &L, const Ctx &c) {
+template <class LDS>
+__device__ void phme_prune_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
     if (tid == 0) {
         uint32_t best_sad = MAX_U32_;
@@ -689,7 +708,8 @@ __device__ void phme_prune_lane0(MeLds &L, const Ctx &c) {
 }
 
 // HME level 0 (motion_estimation.c:1976-2106) for references [f0, f1); one lane per (reference, quadrant).  Ends with a barrier.
-__device__ void hme_l0_round(MeLds &L, const Ctx &c, int f0, int f1) {
+template <class LDS>
+__device__ void hme_l0_round(LDS &L, const Ctx &c, int f0, int f1) {
     ME_CTX_LOCALS(c);
     const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
     const bool     mine = tid < nd;
@@ -752,7 +772,7 @@ __device__ void hme_l0_round(MeLds &L, const Ctx &c, int f0, int f1) {
         }
     }
     wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
-                    ME_WIN_DW);
+                    LDS::WIN_DW);
     if (go) {
         int16_t mx = S.l0x[li][ri][sw_][sh_], my = S.l0y[li][ri][sw_][sh_];
         decode_result(L.sh, tid, hme_sub, &S.l0s[li][ri][sw_][sh_], &mx, &my);
@@ -780,7 +800,8 @@ __device__ void hme_l0_round(MeLds &L, const Ctx &c, int f0, int f1) {
 }
 
 // HME level 1 (motion_estimation.c:2111-2192) for references [f0, f1).  Ends with a barrier.
-__device__ void hme_l1_round(MeLds &L, const Ctx &c, int f0, int f1) {
+template <class LDS>
+__device__ void hme_l1_round(LDS &L, const Ctx &c, int f0, int f1) {
     ME_CTX_LOCALS(c);
     const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
     const bool     mine = tid < nd;
@@ -819,7 +840,7 @@ __device__ void hme_l1_round(MeLds &L, const Ctx &c, int f0, int f1) {
         }
     }
     wg_multi_search(L.sh, nd, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1), L.win,
-                    ME_WIN_DW);
+                    LDS::WIN_DW);
     if (go) {
         int16_t mx = S.l1x[li][ri][sw_][sh_], my = S.l1y[li][ri][sw_][sh_];
         decode_result(L.sh, tid, hme_sub, &S.l1s[li][ri][sw_][sh_], &mx, &my);
@@ -831,7 +852,8 @@ __device__ void hme_l1_round(MeLds &L, const Ctx &c, int f0, int f1) {
 }
 
 // HME level 2 (motion_estimation.c:2197-2247) for references [f0, f1).  Ends with a barrier.
-__device__ void hme_l2_round(MeLds &L, const Ctx &c, int f0, int f1) {
+template <class LDS>
+__device__ void hme_l2_round(LDS &L, const Ctx &c, int f0, int f1) {
     ME_CTX_LOCALS(c);
     const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
     const bool     mine = tid < nd;
@@ -863,7 +885,7 @@ __device__ void hme_l2_round(MeLds &L, const Ctx &c, int f0, int f1) {
             }
         }
     }
-    wg_multi_search(L.sh, nd, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, L.win, ME_WIN_DW);
+    wg_multi_search(L.sh, nd, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, L.win, LDS::WIN_DW);
     if (go) {
         int16_t mx = S.l2x[li][ri][sw_][sh_], my = S.l2y[li][ri][sw_][sh_];
         decode_result(L.sh, tid, hme_sub, &S.l2s[li][ri][sw_][sh_], &mx, &my);
@@ -874,7 +896,8 @@ __device__ void hme_l2_round(MeLds &L, const Ctx &c, int f0, int f1) {
 }
 
 // set_final_seach_centre_sb (:2252-2450) + hme_prune_ref_and_adjust_sr (:2547-2588); lane 0 only
-__device__ void centre_prune_lane0(MeLds &L, const Ctx &c) {
+template <class LDS>
+__device__ void centre_prune_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
     if (tid == 0) {
         int16_t  hx = 0, hy = 0, xc = 0, yc = 0;
@@ -924,7 +947,8 @@ __device__ void centre_prune_lane0(MeLds &L, const Ctx &c) {
 
 // integer_search_b64 (motion_estimation.c:1249-1586) for one reference; all threads.  `store`: write the winners to the
 // output arrays and accumulate the 8x8 SAD sum (false when the reference is only evaluated for first_ref_sad64).
-__device__ void fullpel_ref(MeLds &L, const Ctx &c, int li, int ri, bool store) {
+template <class LDS>
+__device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store) {
     ME_CTX_LOCALS(c);
     const int16_t W = (int16_t)aw, H = (int16_t)ah, pad = 63;
     const int16_t ox_b = (int16_t)org_x, oy_b = (int16_t)org_y;
@@ -1011,7 +1035,7 @@ __device__ void fullpel_ref(MeLds &L, const Ctx &c, int li, int ri, bool store) 
             int x0 = MINV((int)S.xc, (int)cx0), x1 = MAXV((int)S.xc + 1, (int)cx0 + (cw_ > 0 ? cw_ : 0));
             int y0 = MINV((int)S.yc, (int)cy0), y1 = MAXV((int)S.yc + 1, (int)cy0 + (chh > 0 ? chh : 0));
             x0 -= (x0 - (int)S.xc) & 3;
-            if (x1 - x0 > (int)FP_TILE_W || (uint32_t)(y1 - y0 + 63) * fp_pitch((uint32_t)(x1 - x0)) > ME_WIN_DW)
+            if (x1 - x0 > (int)FP_TILE_W || (uint32_t)(y1 - y0 + 63) * fp_pitch((uint32_t)(x1 - x0)) > LDS::WIN_DW)
                 x0 = S.xc, x1 = S.xc + 1, y0 = S.yc, y1 = S.yc + 1;  // does not fit: the centre alone
             S.stx = (int16_t)x0, S.sty = (int16_t)y0, S.stw = (int16_t)(x1 - x0), S.sth = (int16_t)(y1 - y0);
             S.staged = 1;
@@ -1067,7 +1091,7 @@ __device__ void fullpel_ref(MeLds &L, const Ctx &c, int li, int ri, bool store) 
             // tiles that fit the window buffer
             const uint32_t tw = sw < FP_TILE_W ? sw : FP_TILE_W;
             const uint32_t pitch_t = fp_pitch(tw);
-            uint32_t       th      = tw ? MINV(sh_, ME_WIN_DW / pitch_t - 63) : 0;
+            uint32_t       th      = tw ? MINV(sh_, LDS::WIN_DW / pitch_t - 63) : 0;
             for (uint32_t ty = 0; th && ty < sh_; ty += th)
                 for (uint32_t tx = 0; tx < sw; tx += tw) {
                     const uint32_t cw = MINV(tw, sw - tx), ch = MINV(th, sh_ - ty);
@@ -1107,7 +1131,8 @@ __device__ void fullpel_ref(MeLds &L, const Ctx &c, int li, int ri, bool store) 
 }
 
 // me_prune_ref (motion_estimation.c:1592-1635); lane 0 only
-__device__ void me_prune_lane0(MeLds &L, const Ctx &c) {
+template <class LDS>
+__device__ void me_prune_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
     if (tid == 0) {
         for (int li = 0; li < nlists; ++li)
@@ -1133,7 +1158,8 @@ __device__ void me_prune_lane0(MeLds &L, const Ctx &c) {
 }
 
 // candidates (motion_estimation.c:3196-3211), compute_distortion (:3034-3077) and the per-reference search results
-__device__ void finalize_b64(MeLds &L, const Ctx &c) {
+template <class LDS>
+__device__ void finalize_b64(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
     const uint32_t b64 = c.b64;
     // ---- candidates (motion_estimation.c:3196-3211) ----
@@ -1185,15 +1211,21 @@ __device__ void finalize_b64(MeLds &L, const Ctx &c) {
 
 
 // ------------------------------------------------------------------------------------------------
-// One launch, one workgroup per b64: all stages back to back (lowest latency for a single picture).
+// One launch, one workgroup per b64: all stages back to back.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
     __shared__ MeLds L;
 #ifdef SVT_HIP_ME_PROFILE
     unsigned long long prof_last = wall_clock64();
 #endif
+    // the job descriptor (parameters, plane descriptors, output pointers) is read hundreds of times by the scalar stage
+    // logic: keep a copy in LDS instead of going back to memory for every field
+    __shared__ SvtHipMeFrameJob sjob;
+    for (uint32_t i = threadIdx.x; i < sizeof(SvtHipMeFrameJob) / 4; i += blockDim.x)
+        ((uint32_t *)&sjob)[i] = ((const uint32_t *)&jobs[blockIdx.y])[i];
+    __syncthreads();
     Ctx c;
-    if (!make_ctx(c, jobs[blockIdx.y], blockIdx.x))
+    if (!make_ctx(c, sjob, blockIdx.x))
         return;
     ME_CTX_LOCALS(c);
     stage_sources(L, c, 7);
@@ -1345,6 +1377,12 @@ extern "C" int32_t svt_hip_me_validate_jobs(const SvtHipMeFrameJob *jobs, uint32
     return SVT_HIP_OK;
 }
 
+static int32_t launch_me(const SvtHipMeFrameJob *d_jobs, uint32_t n_jobs, uint32_t max_b64, hipStream_t st) {
+    hipLaunchKernelGGL(me_b64_kernel, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, st, d_jobs);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
 extern "C" int32_t svt_hip_me_frames_dev(const SvtHipMeFrameJob *d_jobs, uint32_t n_jobs, uint32_t max_b64, void *stream) {
     if (!d_jobs || n_jobs == 0 || n_jobs > 65535 || max_b64 == 0) {
         set_error("svt_hip_me_frames_dev: bad argument");
@@ -1352,9 +1390,7 @@ extern "C" int32_t svt_hip_me_frames_dev(const SvtHipMeFrameJob *d_jobs, uint32_
     }
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
-    hipLaunchKernelGGL(me_b64_kernel, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, resolve_stream(stream), d_jobs);
-    SVT_HIP_CHECK(hipGetLastError());
-    return SVT_HIP_OK;
+    return launch_me(d_jobs, n_jobs, max_b64, resolve_stream(stream));
 }
 
 extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jobs, void *stream) {
@@ -1369,10 +1405,9 @@ extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jo
     const SvtHipMeFrameJob *d_jobs = (const SvtHipMeFrameJob *)stage_descriptors(jobs, sizeof(SvtHipMeFrameJob) * n_jobs, st);
     if (!d_jobs)
         return SVT_HIP_ERR_RUNTIME;
-    hipLaunchKernelGGL(me_b64_kernel, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, st, d_jobs);
+    const int32_t rc = launch_me(d_jobs, n_jobs, max_b64, st);
     stage_commit(st);
-    SVT_HIP_CHECK(hipGetLastError());
-    return SVT_HIP_OK;
+    return rc;
 }
 
 extern "C" int32_t svt_hip_install_rtcd_me(void **table, uint32_t n_slots) {

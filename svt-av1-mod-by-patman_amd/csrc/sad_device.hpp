@@ -48,14 +48,16 @@ struct SearchSeg {
     uint32_t item_base;  // first work item of this segment
 };
 
-struct SearchShared {
-    SearchDesc desc[MAX_SEARCH];
-    SearchSeg  seg[MAX_SEARCH];
-    uint64_t   best[MAX_SEARCH];
+template <int NS> struct SearchSharedT {
+    static constexpr int MAXS = NS;  // descriptors (and segments per pass) this instance can hold
+    SearchDesc desc[NS];
+    SearchSeg  seg[NS];
+    uint64_t   best[NS];
     uint32_t   nseg, nitems, nstage_dw;
     uint32_t   next_d, next_j;  // continuation point of the planner
     uint8_t    chunk_seg[MAX_CHUNKS];  // segment owning each 64-dword chunk of the window buffer
 };
+using SearchShared = SearchSharedT<MAX_SEARCH>;
 
 #ifdef SVT_HIP_ME_PROFILE
 static __device__ unsigned long long g_ms_prof[8];  // plan, stage, search, slow-path/exit (per translation unit)
@@ -182,7 +184,7 @@ __device__ __forceinline__ void search_plan_desc(SearchDesc &d, uint32_t bw, uin
 }
 
 // segment that contains flat index `v` of a monotonic per-segment base (lds_dw or item_base)
-template <bool ITEMS> __device__ __forceinline__ uint32_t find_seg(const SearchShared &sh, uint32_t nseg, uint32_t v) {
+template <bool ITEMS, class SH> __device__ __forceinline__ uint32_t find_seg(const SH &sh, uint32_t nseg, uint32_t v) {
     uint32_t lo = 0, hi = nseg;  // invariant: base[lo] <= v < base[hi]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -199,7 +201,8 @@ template <bool ITEMS> __device__ __forceinline__ uint32_t find_seg(const SearchS
 // On return sh.best[i] holds the winning key of descriptor i (KEY_NONE if nothing was searched).
 // Must be called by all WG_THREADS threads of the workgroup; contains barriers.  Descriptor i must have been
 // written by thread i (or be visible through an earlier barrier).
-__device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint32_t *__restrict__ src,
+template <class SH>
+__device__ inline void wg_multi_search(SH &sh, uint32_t n, const uint32_t *__restrict__ src,
                                        uint32_t src_row_dw, uint32_t bw, uint32_t bh, uint32_t *__restrict__ win,
                                        uint32_t win_cap_dw) {
     const uint32_t tid = threadIdx.x;
@@ -262,7 +265,7 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
         if (!planned) {
             if (tid == 0) {
                 uint32_t nseg = 0, used = 0, items = 0, d = sh.next_d, j = sh.next_j;
-                while (d < n && nseg < MAX_SEARCH) {
+                while (d < n && nseg < (uint32_t)SH::MAXS) {
                     const SearchDesc &ds = sh.desc[d];
                     if (!ds.fast || j >= ds.n_srows) {
                         d++, j = 0;
@@ -297,30 +300,36 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
         const uint32_t nseg = sh.nseg;
         if (nseg == 0)
             break;
-        // stage: one flat index space over the (64-dword aligned) segments; a wave always works inside one segment,
-        // so the descriptor reads are broadcasts; four independent loads in flight per thread
-        const uint32_t total = sh.nstage_dw;
-        for (uint32_t base = tid; base < total; base += 4 * blockDim.x) {
-            uint32_t v[4];
+        // stage.  Row-group mapping: G lanes share a window row (G = 8 / 16 / 32 by row length), so the row address is
+        // computed once per row and the inner loop is load + LDS store; four rows are in flight per lane.  With at least
+        // as many segments as waves every wave takes whole segments, otherwise all waves split each segment's rows.
+        {
+            const uint32_t nwv = blockDim.x >> 6;
+            const bool     per_wave = nseg >= nwv;
+            const uint32_t lanes = per_wave ? 64u : blockDim.x, lid = per_wave ? (tid & 63u) : tid;
+            for (uint32_t s = per_wave ? (tid >> 6) : 0u; s < nseg; s += per_wave ? nwv : 1u) {
+                const SearchSeg   sg    = sh.seg[s];
+                const SearchDesc &ds    = sh.desc[sg.d];
+                const uint32_t    pitch = ds.pitch_dw, rows = sg.nstage, rstride = ds.raw_stride;
+                const uint32_t    G = pitch <= 8 ? 8u : (pitch <= 16 ? 16u : 32u), rpp = lanes / G;
+                const uint32_t    c0 = lid & (G - 1), r0 = lid / G;
+                const uint8_t    *g0 = ds.ref + (size_t)(ds.skip ? 2 * sg.j0 + 1 : sg.j0) * rstride;
+                uint32_t         *w0 = win + sg.lds_dw;
+                for (uint32_t col = c0; col < pitch; col += G)
+                    for (uint32_t row = r0; row < rows; row += 4 * rpp) {
+                        uint32_t v[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t idx = base + u * blockDim.x;
-                v[u]               = 0;
-                if (idx < total) {
-                    const SearchSeg  &sg  = sh.seg[sh.chunk_seg[idx / SEG_ALIGN]];
-                    const SearchDesc &ds  = sh.desc[sg.d];
-                    const uint32_t    loc = idx - sg.lds_dw;
-                    const uint32_t    row = fast_div(loc, ds.inv_pitch), i = loc - row * ds.pitch_dw;
-                    const uint32_t    sy0 = ds.skip ? 2 * sg.j0 + 1 : sg.j0;
-                    if (row < sg.nstage)
-                        v[u] = load_u32_any(ds.ref + (size_t)(sy0 + row) * ds.raw_stride + 4 * i);
-                }
-            }
+                        for (uint32_t u = 0; u < 4; u++) {
+                            const uint32_t rr = row + u * rpp;
+                            v[u]              = rr < rows ? load_u32_any(g0 + rr * rstride + 4 * col) : 0u;
+                        }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t idx = base + u * blockDim.x;
-                if (idx < total)
-                    win[idx] = v[u];
+                        for (uint32_t u = 0; u < 4; u++) {
+                            const uint32_t rr = row + u * rpp;
+                            if (rr < rows)
+                                w0[rr * pitch + col] = v[u];
+                        }
+                    }
             }
         }
         __syncthreads();
@@ -328,7 +337,7 @@ __device__ inline void wg_multi_search(SearchShared &sh, uint32_t n, const uint3
         // search
         const uint32_t nitems = sh.nitems;
         for (uint32_t item = tid; item < nitems; item += blockDim.x) {
-            const uint32_t   s  = find_seg<true>(sh, nseg, item);
+            const uint32_t   s  = find_seg<true, SH>(sh, nseg, item);
             const SearchSeg  sg = sh.seg[s];
             const SearchDesc &ds = sh.desc[sg.d];
             const uint32_t   li = item - sg.item_base;
