@@ -396,6 +396,8 @@ def bench_lf(lib, dev, args, world, rank):
     total += timed("cdef_apply_3planes", lambda: LB.run_cdef_apply(lib, inp, sp), 2 * 1.5 * P * d)
     timed("sgr_filter_luma_one_eps", lambda: LB.run_sgr_filter(lib, inp, sp), P * d + 8 * P)
     timed("sgr_apply_luma", lambda: LB.run_sgr_apply(lib, inp, sp), 2 * P * d)
+    timed("wiener_stats_luma_win7", lambda: LB.run_wiener_stats(lib, inp, sp), 2 * P * d + inp["n_wiener"] * (49 + 49 * 49) * 8)
+    timed("wiener_convolve_luma", lambda: LB.run_wiener_convolve(lib, inp, sp), 2 * P * d)
     shard.barrier()
     if rank == 0:
         worst = min(stages.items(), key=lambda kv: kv[1]["GBps"])
@@ -405,7 +407,7 @@ def bench_lf(lib, dev, args, world, rank):
             "value_scope": "4K 10-bit pictures per second through deblocking + CDEF search + CDEF apply (kernel-level, not a whole encode)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "4K 10-bit 4:2:0 in-loop filters: deblock frame, CDEF search (8 strengths) + apply, self-guided filter/apply",
+            "config": {"workload": "4K 10-bit 4:2:0 in-loop filters: deblock frame, CDEF search (8 strengths) + apply, self-guided filter/apply, Wiener statistics + filter",
                        "width": W4, "height": H4, "stages": stages},
             "roofline": {"bound": "hbm", "kernel": worst[0], "achieved": worst[1]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(worst[1]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,

@@ -12,6 +12,8 @@
 #ifndef SVT_HIP_LF_H
 #define SVT_HIP_LF_H
 
+#include <stddef.h>
+
 #include "svt_hip.h"
 
 #ifdef __cplusplus
@@ -200,6 +202,47 @@ SVT_HIP_API int32_t svt_hip_sgr_apply_unit(const SvtHipSgrUnit *unit, int32_t ep
 SVT_HIP_API size_t  svt_hip_sgr_search_work_bytes(uint32_t width, uint32_t height, int32_t n_ep);
 SVT_HIP_API int32_t svt_hip_sgr_search_unit(const SvtHipSgrUnit *unit, int32_t start_ep, int32_t end_ep, int32_t ep_inc,
                                             int32_t do_refine, void *d_work, int32_t out[3], int64_t *best_err, void *stream);
+
+/* =============================================================================================
+ * Wiener restoration (what runs at presets M4-M8)
+ *   Source/Lib/Codec/aom_dsp_rtcd.h:66,68        svt_av1_compute_stats, svt_av1_compute_stats_highbd
+ *   Source/Lib/Codec/common_dsp_rtcd.h:177,179   svt_av1_wiener_convolve_add_src, svt_av1_highbd_wiener_convolve_add_src
+ *   callers: search_wiener (restoration_pick.c:1296-1430), wiener_filter_stripe (restoration.c:432-458)
+ * ============================================================================================= */
+typedef struct SvtHipConvolveParams { /* ConvolveParams, definitions.h:580-593 (only round_0 / round_1 are read) */
+    int32_t ref, do_average;
+    void   *dst;
+    int32_t dst_stride, round_0, round_1, plane, is_compound, use_jnt_comp_avg, fwd_offset, bck_offset, use_dist_wtd_comp_avg;
+} SvtHipConvolveParams;
+
+/* Tier A: RTCD signatures (highbd: CONVERT_TO_BYTEPTR-encoded pointers; bit_depth = EbBitDepth value 8 / 10 / 12). */
+SVT_HIP_API void svt_av1_compute_stats_hip(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end,
+                                           int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H);
+SVT_HIP_API void svt_av1_compute_stats_highbd_hip(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start,
+                                                  int32_t h_end, int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride,
+                                                  int64_t *M, int64_t *H, int32_t bit_depth);
+SVT_HIP_API void svt_av1_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride,
+                                                     const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h,
+                                                     const SvtHipConvolveParams *conv_params);
+SVT_HIP_API void svt_av1_highbd_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst,
+                                                            ptrdiff_t dst_stride, const int16_t *filter_x, const int16_t *filter_y,
+                                                            int32_t w, int32_t h, const SvtHipConvolveParams *conv_params, int32_t bd);
+
+/* Tier B: statistics of many restoration units in one launch chain.  dgd / src point at sample (0,0) of the planes the
+ * limits refer to (device memory; dgd readable wiener_win/2 samples beyond every limit); M = int64 [n][49],
+ * H = int64 [n][49*49] (device), laid out as the reference's (only the first win^2 rows / columns are used). */
+typedef struct SvtHipWienerUnit {
+    const void *dgd, *src;
+    uint32_t    dgd_stride, src_stride; /* in samples */
+    int32_t     h_start, h_end, v_start, v_end; /* RestorationTileLimits */
+} SvtHipWienerUnit;
+SVT_HIP_API int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units /* host */, uint32_t n_units, int32_t wiener_win, int32_t is_16bit,
+                                         int32_t bit_depth, int64_t *d_M, int64_t *d_H, void *stream);
+/* The separable filter over a w x h region (any size; the reference's callers tile it in <= 64 x 64 processing units,
+ * which gives the same samples).  Output must not alias the input. */
+SVT_HIP_API int32_t svt_hip_wiener_convolve(const void *d_src, uint32_t src_stride, void *d_dst, uint32_t dst_stride, uint32_t w,
+                                            uint32_t h, const int16_t filter_x[8], const int16_t filter_y[8], int32_t is_16bit,
+                                            int32_t bit_depth, void *stream);
 
 #ifdef __cplusplus
 }

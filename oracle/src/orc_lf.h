@@ -49,6 +49,13 @@ ORC_API void    orc_sgr_filter_unit(const void *dat, int32_t width, int32_t heig
 ORC_API int64_t orc_sgr_search_unit(const void *dat, int32_t width, int32_t height, int32_t dat_stride, const void *src,
                                     int32_t src_stride, int32_t is16, int32_t bit_depth, int32_t pu_w, int32_t pu_h, int32_t start_ep,
                                     int32_t end_ep, int32_t ep_inc, int32_t do_refine, int32_t out[3]);
+/* Wiener restoration (orc_wiener.c) */
+ORC_API void orc_wiener_compute_stats(int32_t wiener_win, const void *dgd, const void *src, int32_t h_start, int32_t h_end,
+                                      int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H,
+                                      int32_t is16, int32_t bit_depth);
+ORC_API void orc_wiener_convolve_add_src(const void *src, int32_t src_stride, void *dst, int32_t dst_stride, const int16_t *fx,
+                                         const int16_t *fy, int32_t w, int32_t h, int32_t round_0, int32_t round_1, int32_t bd,
+                                         int32_t is16);
 #ifdef __cplusplus
 }
 #endif

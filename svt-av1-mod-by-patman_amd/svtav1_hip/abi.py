@@ -219,3 +219,14 @@ SGR_PARAMS = [(2, 1, 140, 3236), (2, 1, 112, 2158), (2, 1, 93, 1618), (2, 1, 80,
 
 class AnalysisJob(C.Structure):   # SvtHipAnalysisJob
     _fields_ = [("pyr", Pyramid8), ("variance", C.c_void_p), ("mean", C.c_void_p)]
+
+
+class WienerUnit(C.Structure):    # SvtHipWienerUnit
+    _fields_ = [("dgd", C.c_void_p), ("src", C.c_void_p), ("dgd_stride", C.c_uint32), ("src_stride", C.c_uint32),
+                ("h_start", C.c_int32), ("h_end", C.c_int32), ("v_start", C.c_int32), ("v_end", C.c_int32)]
+
+
+class ConvolveParams(C.Structure):   # SvtHipConvolveParams == ConvolveParams (definitions.h:580-593)
+    _fields_ = [("ref", C.c_int32), ("do_average", C.c_int32), ("dst", C.c_void_p), ("dst_stride", C.c_int32), ("round_0", C.c_int32),
+                ("round_1", C.c_int32), ("plane", C.c_int32), ("is_compound", C.c_int32), ("use_jnt_comp_avg", C.c_int32),
+                ("fwd_offset", C.c_int32), ("bck_offset", C.c_int32), ("use_dist_wtd_comp_avg", C.c_int32)]

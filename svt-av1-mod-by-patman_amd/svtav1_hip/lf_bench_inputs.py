@@ -91,6 +91,16 @@ def build(lib, dev, rng, W, H, bd, torch):
     inp["d_flt0"] = torch.zeros(H * W, dtype=torch.int32, device=dev)
     inp["d_flt1"] = torch.zeros(H * W, dtype=torch.int32, device=dev)
     inp["xqd"] = (C.c_int32 * 2)(-20, 40)
+    # ---- Wiener: every 256x256 luma restoration unit of the picture (the last row / column absorbs the remainder)
+    lim = [(x, W if W - x < 384 else x + 256, y, H if H - y < 384 else y + 256) for y in range(0, H - 127, 256) for x in range(0, W - 127, 256)]
+    wu = (abi.WienerUnit * len(lim))()
+    for i, (hs, he, vs, ve) in enumerate(lim):
+        wu[i] = abi.WienerUnit(ptr(planes[0], W), ptr(srcs[0], W), W + 2 * PAD, W + 2 * PAD, hs, he, vs, ve)
+    inp["wiener_units"], inp["n_wiener"] = wu, len(lim)
+    inp["d_wM"] = torch.zeros(len(lim) * 49, dtype=torch.int64, device=dev)
+    inp["d_wH"] = torch.zeros(len(lim) * 49 * 49, dtype=torch.int64, device=dev)
+    inp["wfx"] = (C.c_int16 * 8)(3, -12, 30, 86 - 128, 30, -12, 3, 0)
+    inp["wfy"] = (C.c_int16 * 8)(2, -9, 25, 92 - 128, 25, -9, 2, 0)
     return inp
 
 
@@ -127,3 +137,16 @@ def run_sgr_apply(lib, inp, sp):
     out = inp["outs"][0]
     off = (PAD * (W + 2 * PAD) + PAD) * 2
     _chk(lib, lib.svt_hip_sgr_apply_unit(C.byref(inp["sgr_plane"]), 3, inp["xqd"], C.c_void_p(out.data_ptr() + off), W + 2 * PAD, sp))
+
+
+def run_wiener_stats(lib, inp, sp):
+    _chk(lib, lib.svt_hip_wiener_stats(inp["wiener_units"], inp["n_wiener"], 7, 1, inp["bd"], C.c_void_p(inp["d_wM"].data_ptr()),
+                                       C.c_void_p(inp["d_wH"].data_ptr()), sp))
+
+
+def run_wiener_convolve(lib, inp, sp):
+    W, H = inp["W"], inp["H"]
+    out = inp["outs"][0]
+    off = (PAD * (W + 2 * PAD) + PAD) * 2
+    _chk(lib, lib.svt_hip_wiener_convolve(C.c_void_p(inp["ptr"](inp["planes"][0], W)), W + 2 * PAD, C.c_void_p(out.data_ptr() + off),
+                                          W + 2 * PAD, W, H, inp["wfx"], inp["wfy"], 1, inp["bd"], sp))

@@ -72,3 +72,35 @@ for key, w, h, bd, is16, kind, pu, (s0, s1, inc, refine), seed in G.GOLDEN_SGR:
     store[key + "_flt0"], store[key + "_flt1"], store[key + "_rec"] = f0, f1, rec
 np.savez_compressed(os.path.join(HERE, "sgr.npz"), **store)
 print("sgr.npz:", len(store), "arrays", os.path.getsize(os.path.join(HERE, "sgr.npz")), "bytes")
+
+# ---- Wiener restoration: svt_av1_compute_stats(_highbd) and svt_av1_(highbd_)wiener_convolve_add_src of the reference
+import test_wiener_oracle as TW  # noqa: E402
+
+store = {}
+f8 = L.rtcd(ref, "svt_av1_compute_stats", None, C.c_int32, V, V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, V, V)
+f16 = L.rtcd(ref, "svt_av1_compute_stats_highbd", None, C.c_int32, V, V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, V, V, C.c_int32)
+c8 = L.rtcd(ref, "svt_av1_wiener_convolve_add_src", None, V, C.c_ssize_t, V, C.c_ssize_t, V, V, C.c_int32, C.c_int32, V)
+c16 = L.rtcd(ref, "svt_av1_highbd_wiener_convolve_add_src", None, V, C.c_ssize_t, V, C.c_ssize_t, V, V, C.c_int32, C.c_int32, V, C.c_int32)
+for key, bd, is16, win, w, h, seed in G.GOLDEN_WIENER:
+    rng = np.random.default_rng(seed)
+    dat, src = G.sgr_plane(rng, w + 4, h + 4, bd, is16, 0)
+    enc = (lambda a: V(a >> 1)) if is16 else V
+    M, H = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+    if is16:
+        f16(win, enc(G.at(dat)), enc(G.at(src)), 1, 1 + w, 2, 2 + h, dat.shape[1], src.shape[1], P(M), P(H), bd)
+    else:
+        f8(win, enc(G.at(dat)), enc(G.at(src)), 1, 1 + w, 2, 2 + h, dat.shape[1], src.shape[1], P(M), P(H))
+    fx, kx = G.wiener_filter(rng)
+    fy, ky = G.wiener_filter(rng)
+    r0, r1 = G.wiener_rounds(bd)
+    cp = TW.ConvolveParams(round_0=r0, round_1=r1)
+    cw, ch = min(w, 128), min(h, 128)
+    out = np.zeros((ch, cw), dat.dtype)
+    if is16:
+        c16(enc(G.at(dat)), dat.shape[1], enc(out.ctypes.data), cw, P(fx), P(fy), cw, ch, C.byref(cp), bd)
+    else:
+        c8(enc(G.at(dat)), dat.shape[1], P(out), cw, P(fx), P(fy), cw, ch, C.byref(cp))
+    store[key + "_dat"], store[key + "_src"], store[key + "_M"], store[key + "_H"] = dat, src, M, H
+    store[key + "_fx"], store[key + "_fy"], store[key + "_out"] = np.array(fx), np.array(fy), out
+np.savez_compressed(os.path.join(HERE, "wiener.npz"), **store)
+print("wiener.npz:", len(store), "arrays", os.path.getsize(os.path.join(HERE, "wiener.npz")), "bytes")
