@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=16, help="pictures per step and rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--txfm-frames", type=int, default=4, help="txfm workload: 4K pictures per launch")
     ap.add_argument("--workload", choices=("me", "txfm", "lf"), default="me",
                     help="me: BASELINE.json configs[1] (default, the N=1 workload); txfm: configs[2] kernel-level measurement; "
                          "lf: in-loop filters (deblock, CDEF, self-guided) on one 4K 10-bit picture, kernel-level")
@@ -282,7 +283,9 @@ def bench_txfm(lib, dev, args, world, rank):
     (svt_aom_highbd_quantize_b) -> inverse transform + prediction -> reconstruction), tiled with ONE block size per
     launch.  Algorithmic bytes per block of N coefficients: 2N residual + 4N qcoeff + 4N dqcoeff
     + 2*2N prediction/reconstruction (10-bit in uint16) = 14N."""
-    W4, H4 = 3840, 2160
+    W4, HP = 3840, 2160
+    FR = max(1, args.txfm_frames)          # pictures per launch, stacked vertically (SURVEY 8d: >= 2^16 blocks per launch per size class)
+    H4 = HP * FR
     rng = np.random.default_rng(3 + rank)
     resid = torch.from_numpy(rng.integers(-120, 121, size=(H4, W4), dtype=np.int16)).to(dev)
     pred = torch.from_numpy(rng.integers(0, 1024, size=(H4, W4), dtype=np.uint16).view(np.int16)).to(dev)
@@ -305,23 +308,21 @@ def bench_txfm(lib, dev, args, world, rank):
         arena[off_pred:off_pred + W4 * H4 * 2] = pred.view(torch.uint8).reshape(-1)
         iscan = np.arange(n, dtype=np.int16)
         arena[off_iscan:off_iscan + n * 2] = torch.from_numpy(iscan.view(np.uint8)).to(dev)
-        descs = (abi.TxfmDesc * nblk)()
-        for i in range(nblk):
-            bx, by = i % bw, i // bw
-            d = descs[i]
-            pix = (by * h) * W4 + bx * w
-            d.residual_off, d.residual_stride = off_res + pix * 2, W4
-            d.coeff_off = abi.NO_OFFSET
-            d.qcoeff_off, d.dqcoeff_off = off_q + i * n * 4, off_dq + i * n * 4
-            d.pred_off, d.recon_off, d.pred_stride, d.recon_stride = off_pred + pix * 2, off_rec + pix * 2, W4, W4
-            d.iscan_off, d.qm_off, d.iqm_off = off_iscan, abi.NO_OFFSET, abi.NO_OFFSET
-            d.zbin[0], d.zbin[1], d.round[0], d.round[1] = 27, 33, 15, 19
-            d.quant[0], d.quant[1], d.quant_shift[0], d.quant_shift[1] = -7491, 9363, 4096, 2048   # dequant 41 / 51
-            d.dequant[0], d.dequant[1] = 41, 51
-            d.tx_type, d.shape, d.bit_depth, d.quant_mode = i % 2 if max(w, h) <= 16 else 0, 0, 10, abi.QUANT_B_HBD
-            d.log_scale = 2 if w == 64 else (1 if w == 32 else 0)
-            d.flags = abi.TX_FWD | abi.TX_INV | abi.TX_PIXEL16
-        d_desc = torch.from_numpy(np.frombuffer(descs, dtype=np.uint8).copy()).to(dev)
+        descs = np.zeros(nblk, dtype=np.dtype(abi.TxfmDesc))      # one descriptor per block, filled vectorised
+        i = np.arange(nblk, dtype=np.uint64)
+        pix = (i // bw * h) * W4 + (i % bw) * w
+        descs["residual_off"], descs["residual_stride"] = off_res + pix * 2, W4
+        descs["coeff_off"] = abi.NO_OFFSET
+        descs["qcoeff_off"], descs["dqcoeff_off"] = off_q + i * (n * 4), off_dq + i * (n * 4)
+        descs["pred_off"], descs["recon_off"], descs["pred_stride"], descs["recon_stride"] = off_pred + pix * 2, off_rec + pix * 2, W4, W4
+        descs["iscan_off"], descs["qm_off"], descs["iqm_off"] = off_iscan, abi.NO_OFFSET, abi.NO_OFFSET
+        descs["zbin"], descs["round"] = (27, 33), (15, 19)
+        descs["quant"], descs["quant_shift"], descs["dequant"] = (-7491, 9363), (4096, 2048), (41, 51)   # dequant 41 / 51
+        descs["tx_type"] = (i % 2).astype(np.uint8) if max(w, h) <= 16 else 0
+        descs["shape"], descs["bit_depth"], descs["quant_mode"] = 0, 10, abi.QUANT_B_HBD
+        descs["log_scale"] = 2 if w == 64 else (1 if w == 32 else 0)
+        descs["flags"] = abi.TX_FWD | abi.TX_INV | abi.TX_PIXEL16
+        d_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
         d_res = torch.zeros(nblk * 16, dtype=torch.uint8, device=dev)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -349,13 +350,13 @@ def bench_txfm(lib, dev, args, world, rank):
         k16 = per_size["16x16"]
         print(json.dumps({
             "metric": "encoded fps (4K 10-bit preset 8) + ME+txfm HBM GB/s vs roofline, 1/2/4/8 GPU",
-            "value": round(world * 4.0 / (total_ms * 1e-3), 2), "unit": "fps",
+            "value": round(world * 4.0 * FR / (total_ms * 1e-3), 2), "unit": "fps",
             "value_scope": "4K 10-bit luma pictures per second through the fused fwd-txfm+quant+inv-txfm+recon kernel "
                            "(mean over the 4 block-size tilings; kernel-level, not a whole encode)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total_ms / 4, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "4K 10-bit fwd/inv txfm2d + quantize (BASELINE.json configs[2]), fused kernel, one block size per launch",
-                       "width": W4, "height": H4, "per_size": per_size},
+                       "width": W4, "height": HP, "pictures_per_launch": FR, "per_size": per_size},
             "roofline": {"bound": "hbm", "kernel": "txfm_kernel<16,16>", "achieved": k16["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(k16["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(14 * 256 * k16["blocks"]), "launch_ms": k16["launch_ms"],

@@ -70,6 +70,11 @@ __device__ __forceinline__ void load_qp(QP &q, const SvtHipTxfmDesc &d, const ui
     q.iqm = d.iqm_off == SVT_HIP_NO_OFFSET ? nullptr : base + d.iqm_off;
 }
 __device__ __forceinline__ int64_t clamp_i16(int64_t v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+// a * b with the exact 64-bit result; when a fits 32 bits (always, for coefficients in the range a bit depth can produce)
+// this is one v_mad_i64_i32 instead of the four quarter-rate multiplies of a generic 64 x 64 product
+__device__ __forceinline__ int64_t mul_64x32(int64_t a, int32_t b) {
+    return a == (int64_t)(int32_t)a ? (int64_t)(int32_t)a * (int64_t)b : a * (int64_t)b;
+}
 __device__ __forceinline__ void quant_one(const QP &q, int32_t c, uint32_t rc, int32_t &qc, int32_t &dqc) {
     const int     ac   = rc != 0;
     const int32_t sign = c < 0 ? -1 : 0;
@@ -81,28 +86,28 @@ __device__ __forceinline__ void quant_one(const QP &q, int32_t c, uint32_t rc, i
         if (mul32(absc, wt) >= (q.zbin[ac] << 5)) {
             int64_t tmp = clamp_i16((int64_t)add32(absc, q.round[ac]));
             tmp *= wt;
-            aq = (int32_t)(((((tmp * q.quant[ac]) >> 16) + tmp) * q.qshift[ac]) >> (16 - ls + 5));
+            aq = (int32_t)(mul_64x32((mul_64x32(tmp, q.quant[ac]) >> 16) + tmp, q.qshift[ac]) >> (16 - ls + 5));
             dq = (q.dequant[ac] * iwt + 16) >> 5;
         }
     } else if (q.mode == SVT_HIP_QUANT_B_HBD) {
         const int32_t cw = mul32(c, wt);
         if (cw >= q.zbin[ac] * 32 || cw <= -q.zbin[ac] * 32) {
-            const int64_t tmpw = ((int64_t)absc + q.round[ac]) * wt;
-            const int64_t tmp2 = ((tmpw * q.quant[ac]) >> 16) + tmpw;
-            aq = (int32_t)((tmp2 * q.qshift[ac]) >> (16 - ls + 5));
+            const int64_t tmpw = mul_64x32((int64_t)absc + q.round[ac], wt);
+            const int64_t tmp2 = (mul_64x32(tmpw, q.quant[ac]) >> 16) + tmpw;
+            aq = (int32_t)(mul_64x32(tmp2, q.qshift[ac]) >> (16 - ls + 5));
             dq = (q.dequant[ac] * iwt + 16) >> 5;
         }
     } else if (q.mode == SVT_HIP_QUANT_FP) {
         if (!q.qm && !q.iqm) {
             if (((int64_t)absc << (1 + ls)) >= (int64_t)q.dequant[ac]) {
                 const int64_t a2 = clamp_i16((int64_t)absc + q.round[ac]);
-                aq = (int32_t)((a2 * q.quant[ac]) >> (16 - ls));
+                aq = (int32_t)(mul_64x32(a2, q.quant[ac]) >> (16 - ls));
             }
         } else {
             dq = (q.dequant[ac] * iwt + 16) >> 5;
             if ((int64_t)absc * wt >= (int64_t)(q.dequant[ac] << (5 - (1 + ls)))) {
                 const int64_t a2 = clamp_i16((int64_t)absc + q.round[ac]);
-                aq = (int32_t)((a2 * wt * q.quant[ac]) >> (16 - ls + 5));
+                aq = (int32_t)(mul_64x32(a2 * wt, q.quant[ac]) >> (16 - ls + 5));
             }
         }
     } else {  // SVT_HIP_QUANT_FP_HBD
@@ -110,12 +115,12 @@ __device__ __forceinline__ void quant_one(const QP &q, int32_t c, uint32_t rc, i
             dq = (q.dequant[ac] * iwt + 16) >> 5;
             if ((int64_t)absc * wt >= (int64_t)(q.dequant[ac] << (5 - (1 + ls)))) {
                 const int64_t tmp = (int64_t)absc + q.round[ac];
-                aq = (int32_t)((tmp * q.quant[ac] * wt) >> (16 - ls + 5));
+                aq = (int32_t)(mul_64x32(mul_64x32(tmp, q.quant[ac]), wt) >> (16 - ls + 5));
             }
         } else {
             if ((int32_t)((uint32_t)absc << (1 + ls)) >= q.dequant[ac]) {
                 const int64_t tmp = (int64_t)absc + q.round[ac];
-                aq = (int32_t)((tmp * q.quant[ac]) >> (16 - ls));
+                aq = (int32_t)(mul_64x32(tmp, q.quant[ac]) >> (16 - ls));
             }
         }
     }
