@@ -54,8 +54,6 @@ struct B64State {
     SvtHipSearchArea l0_min, l0_max;
     // scratch shared between lane 0 and the workgroup
     uint32_t wg_sum;
-    int32_t  go;             // stage decision broadcast by lane 0
-    int16_t  q_ox[4], q_oy[4];  // per-search origin offsets (pre-HME regions / HME quadrants)
     // integer search of the current reference
     int16_t  xc, yc, sw, sh, ox, oy;
     int32_t  do_centre, need_zero_sad, need_hme_sad;
