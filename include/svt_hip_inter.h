@@ -1,0 +1,62 @@
+/*
+ * svt_hip_inter.h — C-ABI for inter-prediction interpolation, single-reference family.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   Source/Lib/Codec/common_dsp_rtcd.h:185-215   svt_av1_convolve_{2d_sr,x_sr,y_sr,2d_copy_sr} and the highbd set
+ *   Source/Lib/Codec/inter_prediction.c:311-417, 670-789   their C implementations
+ *   callers: svt_aom_inter_predictor / highbd_inter_predictor via sf->convolve[subpel_x != 0][subpel_y != 0][0]
+ * The compound (jnt_*) family and scaled references are not covered yet.
+ */
+#ifndef SVT_HIP_INTER_H
+#define SVT_HIP_INTER_H
+
+#include "svt_hip_lf.h" /* SvtHipConvolveParams */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SvtHipInterpFilterParams { /* InterpFilterParams, definitions.h:750-755 */
+    const int16_t *filter_ptr;           /* [subpel_shifts][taps] */
+    uint16_t       taps, subpel_shifts;
+    int32_t        interp_filter;
+} SvtHipInterpFilterParams;
+
+/* Tier A: RTCD signatures, host pointers (the highbd functions take real uint16 pointers, as in the reference). */
+#define SVT_HIP_DECL_CONV(mode)                                                                                                  \
+    SVT_HIP_API void svt_av1_convolve_##mode##_hip(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride,      \
+                                                   int32_t w, int32_t h, SvtHipInterpFilterParams *filter_params_x,              \
+                                                   SvtHipInterpFilterParams *filter_params_y, const int32_t subpel_x_q4,         \
+                                                   const int32_t subpel_y_q4, SvtHipConvolveParams *conv_params);               \
+    SVT_HIP_API void svt_av1_highbd_convolve_##mode##_hip(const uint16_t *src, int32_t src_stride, uint16_t *dst,               \
+                                                          int32_t dst_stride, int32_t w, int32_t h,                             \
+                                                          const SvtHipInterpFilterParams *filter_params_x,                      \
+                                                          const SvtHipInterpFilterParams *filter_params_y,                      \
+                                                          const int32_t subpel_x_q4, const int32_t subpel_y_q4,                 \
+                                                          SvtHipConvolveParams *conv_params, int32_t bd);
+SVT_HIP_DECL_CONV(2d_sr)
+SVT_HIP_DECL_CONV(x_sr)
+SVT_HIP_DECL_CONV(y_sr)
+SVT_HIP_DECL_CONV(2d_copy_sr)
+#undef SVT_HIP_DECL_CONV
+
+/* Tier B: one descriptor per predicted block, all pointers device memory.  taps_x / taps_y == 0 selects what the
+ * reference dispatches to when that direction has no sub-pel offset (x_sr, y_sr, 2d_copy_sr). */
+typedef struct SvtHipConvolveDesc {
+    const void *src;        /* sample the block's (0,0) maps to in the reference plane; taps/2-1 samples are read to the
+                             * left / above and taps/2 to the right / below */
+    void       *dst;
+    uint32_t    src_stride, dst_stride; /* in samples */
+    uint16_t    w, h;                   /* 2 .. 128 */
+    int16_t     filter_x[8], filter_y[8]; /* the kernels of this block's sub-pel phases (av1_get_interp_filter_subpel_kernel) */
+    uint8_t     taps_x, taps_y;         /* 0, or an even number <= 8 */
+    uint8_t     round_0, round_1;       /* ConvolveParams of get_conv_params (convolve.h:40-68) */
+    uint8_t     bit_depth, is_16bit;
+    uint8_t     pad_[6];
+} SvtHipConvolveDesc;
+SVT_HIP_API int32_t svt_hip_convolve_sr_batch(const SvtHipConvolveDesc *d_desc, uint32_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_INTER_H */

@@ -56,6 +56,10 @@ ORC_API void orc_wiener_compute_stats(int32_t wiener_win, const void *dgd, const
 ORC_API void orc_wiener_convolve_add_src(const void *src, int32_t src_stride, void *dst, int32_t dst_stride, const int16_t *fx,
                                          const int16_t *fy, int32_t w, int32_t h, int32_t round_0, int32_t round_1, int32_t bd,
                                          int32_t is16);
+/* inter-prediction interpolation, single reference (orc_convolve.c) */
+ORC_API void orc_convolve_sr(const void *src, int32_t src_stride, void *dst, int32_t dst_stride, int32_t w, int32_t h,
+                             const int16_t *fx, int32_t taps_x, const int16_t *fy, int32_t taps_y, int32_t round_0,
+                             int32_t round_1, int32_t bd, int32_t is16);
 #ifdef __cplusplus
 }
 #endif

@@ -230,3 +230,13 @@ class ConvolveParams(C.Structure):   # SvtHipConvolveParams == ConvolveParams (d
     _fields_ = [("ref", C.c_int32), ("do_average", C.c_int32), ("dst", C.c_void_p), ("dst_stride", C.c_int32), ("round_0", C.c_int32),
                 ("round_1", C.c_int32), ("plane", C.c_int32), ("is_compound", C.c_int32), ("use_jnt_comp_avg", C.c_int32),
                 ("fwd_offset", C.c_int32), ("bck_offset", C.c_int32), ("use_dist_wtd_comp_avg", C.c_int32)]
+
+
+class InterpFilterParams(C.Structure):   # SvtHipInterpFilterParams == InterpFilterParams (definitions.h:750-755)
+    _fields_ = [("filter_ptr", C.c_void_p), ("taps", C.c_uint16), ("subpel_shifts", C.c_uint16), ("interp_filter", C.c_int32)]
+
+
+class ConvolveDesc(C.Structure):         # SvtHipConvolveDesc (include/svt_hip_inter.h)
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_stride", C.c_uint32), ("dst_stride", C.c_uint32), ("w", C.c_uint16),
+                ("h", C.c_uint16), ("filter_x", C.c_int16 * 8), ("filter_y", C.c_int16 * 8), ("taps_x", C.c_uint8), ("taps_y", C.c_uint8),
+                ("round_0", C.c_uint8), ("round_1", C.c_uint8), ("bit_depth", C.c_uint8), ("is_16bit", C.c_uint8), ("pad_", C.c_uint8 * 6)]

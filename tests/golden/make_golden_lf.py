@@ -104,3 +104,31 @@ for key, bd, is16, win, w, h, seed in G.GOLDEN_WIENER:
     store[key + "_fx"], store[key + "_fy"], store[key + "_out"] = np.array(fx), np.array(fy), out
 np.savez_compressed(os.path.join(HERE, "wiener.npz"), **store)
 print("wiener.npz:", len(store), "arrays", os.path.getsize(os.path.join(HERE, "wiener.npz")), "bytes")
+
+# ---- single-reference interpolation: svt_av1_(highbd_)convolve_{2d,x,y,2d_copy}_sr of the reference
+import conv_cases as K  # noqa: E402
+
+store, n = {}, 0
+rng = np.random.default_rng(77)
+tabs = {nm: K.kernel_table(nm) for nm in K.TABLES}
+sig = (V, C.c_int32, V, C.c_int32, C.c_int32, C.c_int32, V, V, C.c_int32, C.c_int32, V)
+MODES = ("2d_sr", "x_sr", "y_sr", "2d_copy_sr")
+for bd, is16 in ((8, 0), (10, 1)):
+    r0, r1 = K.conv_rounds(bd)
+    for k in range(8):
+        w, h = K.SIZES[(k * 3) % len(K.SIZES)]
+        mode, ti = k % 4, k % 3
+        sx, sy = int(rng.integers(1, 16)), int(rng.integers(1, 16))
+        plane, at = K.ref_plane(rng, w, h, bd, is16, 0)
+        tab = tabs[list(K.TABLES)[ti]][0]
+        fp = K.InterpFilterParams(tab.ctypes.data, 8, 16, ti)
+        cp = TW.ConvolveParams(round_0=r0, round_1=r1)
+        o = np.zeros((h, w), plane.dtype)
+        fn = L.rtcd(ref, (f"svt_av1_highbd_convolve_{MODES[mode]}" if is16 else f"svt_av1_convolve_{MODES[mode]}"), None,
+                    *(sig + ((C.c_int32,) if is16 else ())))
+        fn(*([V(at), plane.shape[1], P(o), w, w, h, C.byref(fp), C.byref(fp), sx, sy, C.byref(cp)] + ([bd] if is16 else [])))
+        store[f"c{n}_meta"], store[f"c{n}_plane"], store[f"c{n}_out"] = np.array([bd, is16, w, h, mode, ti, sx, sy], np.int32), plane, o
+        n += 1
+store["n"] = np.array(n)
+np.savez_compressed(os.path.join(HERE, "convolve.npz"), **store)
+print("convolve.npz:", n, "cases", os.path.getsize(os.path.join(HERE, "convolve.npz")), "bytes")
