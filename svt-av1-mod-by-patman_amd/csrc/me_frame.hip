@@ -562,16 +562,30 @@ __device__ void init_state_lane0(LDS &L, const Ctx &c) {
     }
 }
 
-// zero-MV SAD of one reference (init_zz_sad, motion_estimation.c:2452-2470); all threads, ends with a barrier
+// zero-MV SADs of all references (init_zz_sad, motion_estimation.c:2452-2470) in one pass: wave w takes references
+// w, w + 4, ...; 64 x h/2 samples on every other row against the staged source; ends with a barrier
 template <class LDS>
-__device__ void zz_sad_ref(LDS &L, const Ctx &c, int li, int ri) {
+__device__ void zz_sad_all(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
-    const SvtHipPlane8 &rp = job.ref[li][ri].full;
-    wg_block_sad(L, plane_at(rp, (int16_t)org_x, (int16_t)org_y), rp.stride, b64_w, b64_h >> 1, 2);
-    if (tid == 0) {
-        uint32_t z = S.wg_sum << 1;
-        z          = (z * 64 * 64) / (b64_w * b64_h);
-        S.zz_sad[li][ri] = z;
+    const uint32_t wv = tid >> 6, lane = tid & 63, nwv = blockDim.x >> 6;
+    const uint32_t ndw = b64_w >> 2, rows = b64_h >> 1;
+    for (int f = (int)wv; f < nref; f += (int)nwv) {
+        const int li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+        if (!(tl > 0 || li == 0))
+            continue;
+        const SvtHipPlane8 &rp  = job.ref[li][ri].full;
+        const uint8_t      *ref = plane_at(rp, (int16_t)org_x, (int16_t)org_y);
+        uint32_t            acc = 0;
+        for (uint32_t idx = lane; idx < ndw * rows; idx += 64) {
+            const uint32_t r = idx / ndw, i = idx - r * ndw;
+            acc = __builtin_amdgcn_sad_u8(L.src_full[(2 * r) * 16 + i], load_u32_unaligned(ref + (size_t)(2 * r) * rp.stride + 4 * i), acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            uint32_t z = acc << 1;
+            z          = (z * 64 * 64) / (b64_w * b64_h);
+            S.zz_sad[li][ri] = z;
+        }
     }
     __syncthreads();
 }
@@ -1232,10 +1246,7 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
     __syncthreads();
     ME_PHASE(0);
     if (p.me_early_exit_th || p.me_safe_limit_zz_th) {
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
-                if (tl > 0 || li == 0)
-                    zz_sad_ref(L, c, li, ri);
+        zz_sad_all(L, c);
         zz_prune_lane0(L, c);
         __syncthreads();
     }

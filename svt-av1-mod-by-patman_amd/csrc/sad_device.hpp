@@ -357,17 +357,15 @@ __device__ inline void wg_multi_search(SH &sh, uint32_t n, const uint32_t *__res
                 quad_sad(w, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad);
             const uint32_t sy = ds.skip ? 2 * (sg.j0 + jl) + 1 : (sg.j0 + jl);
             const uint32_t saw = (uint32_t)ds.sa_w;
-            uint64_t       key = KEY_NONE;
+            // the four positions of a quad are in raster order: a strict '<' on the SAD keeps the first minimum, and the
+            // 64-bit (sad, raster index) key is built once
+            uint32_t best = ~0u, bpos = 0;
 #pragma unroll
-            for (uint32_t p = 0; p < 4; p++) {
-                const uint32_t sx = 4 * q + p;
-                if (sx < saw) {
-                    const uint64_t kk = ((uint64_t)sad[p] << 32) | (sy * saw + sx);
-                    key               = kk < key ? kk : key;
-                }
-            }
-            if (key < KEY_NONE)
-                atomicMin((unsigned long long *)&sh.best[sg.d], (unsigned long long)key);
+            for (uint32_t p = 0; p < 4; p++)
+                if (4 * q + p < saw && sad[p] < best)
+                    best = sad[p], bpos = p;
+            if (best != ~0u)
+                atomicMin((unsigned long long *)&sh.best[sg.d], ((unsigned long long)best << 32) | (sy * saw + 4 * q + bpos));
         }
         __syncthreads();
         MS_PHASE(2);
