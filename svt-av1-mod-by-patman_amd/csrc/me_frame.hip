@@ -31,7 +31,11 @@ namespace {
 #define MAX_SAD_VALUE_ (128 * 128 * 255) /* motion_estimation.h:85 */
 #define MAX_U32_ 0xFFFFFFFFu
 
-constexpr uint32_t ME_WIN_DW   = 4096;  // 16 KiB LDS window buffer of the HME stages (bigger windows: several passes)
+// LDS window buffers.  The pre-HME / HME level 0 / level 1 stages search down-scaled pictures and do not need the full
+// resolution source block, so their window buffer also covers it (and the full-pel bookkeeping); the block is staged again
+// before the first full resolution stage.  Bigger windows than the buffer: several passes.
+constexpr uint32_t ME_HME_WIN_DW = 6080;                          // 23.75 KiB: pre-HME, HME level 0 / 1
+constexpr uint32_t ME_WIN_DW     = ME_HME_WIN_DW - 64 * 16 - 256;  // HME level 2 and full-pel
 constexpr uint32_t FP_TILE_W   = 64;    // widest full-pel tile staged at once (positions)
 
 struct PreHme {
@@ -65,16 +69,22 @@ struct B64State {
 };
 
 struct MeLds {
-    static constexpr uint32_t WIN_DW = ME_WIN_DW;
+    static constexpr uint32_t WIN_DW = ME_WIN_DW, HME_WIN_DW = ME_HME_WIN_DW;
     SearchShared sh;
     B64State     st;
-    alignas(16) uint32_t win[ME_WIN_DW];
-    alignas(16) uint32_t src_full[64 * 16];
+    union {
+        alignas(16) uint32_t win[ME_HME_WIN_DW];
+        struct {
+            alignas(16) uint32_t fp_win_[ME_WIN_DW];
+            alignas(16) uint32_t src_full[64 * 16];
+            uint64_t bestkey[85];
+            uint32_t me_dist[85];
+        };
+    };
     alignas(16) uint32_t src_q[32 * 8];
     alignas(16) uint32_t src_s[16 * 4];
-    uint64_t     bestkey[85];
-    uint32_t     me_dist[85];
 };
+static_assert(sizeof(MeLds::win) >= (ME_WIN_DW + 64 * 16) * 4 + 85 * 12, "full-pel view must fit the HME window buffer");
 
 #define MINV(a, b) ((a) < (b) ? (a) : (b))
 #define MAXV(a, b) ((a) > (b) ? (a) : (b))
@@ -679,7 +689,7 @@ __device__ void prehme_round(LDS &L, const Ctx &c, int f0, int f1, bool searchin
     }
     if (searching) {
         wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
-                        LDS::WIN_DW);
+                        LDS::HME_WIN_DW);
         if (go) {
             PreHme &d = S.ph[li][ri][si];
             decode_result(L.sh, tid, hme_sub, &d.sad, &d.col, &d.row);
@@ -784,7 +794,7 @@ __device__ void hme_l0_round(LDS &L, const Ctx &c, int f0, int f1) {
         }
     }
     wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
-                    LDS::WIN_DW);
+                    LDS::HME_WIN_DW);
     if (go) {
         int16_t mx = S.l0x[li][ri][sw_][sh_], my = S.l0y[li][ri][sw_][sh_];
         decode_result(L.sh, tid, hme_sub, &S.l0s[li][ri][sw_][sh_], &mx, &my);
@@ -852,7 +862,7 @@ __device__ void hme_l1_round(LDS &L, const Ctx &c, int f0, int f1) {
         }
     }
     wg_multi_search(L.sh, nd, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1), L.win,
-                    LDS::WIN_DW);
+                    LDS::HME_WIN_DW);
     if (go) {
         int16_t mx = S.l1x[li][ri][sw_][sh_], my = S.l1y[li][ri][sw_][sh_];
         decode_result(L.sh, tid, hme_sub, &S.l1s[li][ri][sw_][sh_], &mx, &my);
@@ -1281,6 +1291,12 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
     if (p.enable_hme_flag && p.enable_hme_level1_flag)
         hme_l1_round(L, c, 0, nref);
     ME_PHASE(4);
+    // the down-scaled stages' windows may have overwritten the full resolution source block: stage it again (the barrier
+    // that ends the last search orders the window reads before these writes)
+    if (p.prehme_enable || (p.enable_hme_flag && (p.enable_hme_level0_flag || p.enable_hme_level1_flag))) {
+        stage_sources(L, c, 1);
+        __syncthreads();
+    }
     if (p.enable_hme_flag && p.enable_hme_level2_flag)
         hme_l2_round(L, c, 0, nref);
     ME_PHASE(5);

@@ -20,8 +20,7 @@ namespace dev {
 
 constexpr int      WG_THREADS = 256;
 constexpr int      MAX_SEARCH = 32;
-constexpr uint32_t SEG_ALIGN  = 64;   // segments start on 64-dword boundaries: one wave stages one segment's chunk
-constexpr int      MAX_CHUNKS = 192;  // window buffers up to 48 KiB
+constexpr uint32_t SEG_ALIGN  = 4;    // segments of the window buffer start on 16-byte boundaries
 constexpr uint64_t KEY_NONE   = ((uint64_t)0xffffffu << 32) | 0xffffffffu;  // best starts at 0xffffff
 
 struct SearchDesc {
@@ -55,7 +54,6 @@ template <int NS> struct SearchSharedT {
     uint64_t   best[NS];
     uint32_t   nseg, nitems, nstage_dw;
     uint32_t   next_d, next_j;  // continuation point of the planner
-    uint8_t    chunk_seg[MAX_CHUNKS];  // segment owning each 64-dword chunk of the window buffer
 };
 using SearchShared = SearchSharedT<MAX_SEARCH>;
 
@@ -221,81 +219,61 @@ __device__ inline void wg_multi_search(SH &sh, uint32_t n, const uint32_t *__res
     __syncthreads();
 
     // ---- fast path: passes of (stage -> search) until every descriptor row has been searched ----
-    bool first = true;
     for (;;) {
-        // plan.  Common case: everything fits the window buffer at once -> the first wave lays the segments out with a
-        // prefix sum (one lane per descriptor); otherwise lane 0 packs as many rows as fit, pass after pass.
-        bool planned = false;
-        if (first) {
-            if (tid < 64) {
-                uint32_t need = 0, items = 0, nstage = 0;
-                if (tid < n) {
-                    const SearchDesc &ds = sh.desc[tid];
-                    if (ds.fast && ds.n_srows) {
-                        nstage = (ds.n_srows - 1) * (ds.skip ? 2u : 1u) + ds.rows_per_pos;
-                        need   = (nstage * ds.pitch_dw + SEG_ALIGN - 1) & ~(SEG_ALIGN - 1);
-                        items  = ds.n_srows * ds.nq;
+        // plan, by the first wave (lane = descriptor): starting at the continuation point, take as many whole descriptors
+        // as fit the window buffer (prefix sum of their needs); a descriptor too big to fit even alone gets a pass of
+        // its own for as many of its search rows as fit.
+        if (tid < 64) {
+            const uint32_t d0 = sh.next_d, j0 = sh.next_j;
+            uint32_t       need = 0, items = 0, nstage = 0, nj = 0, jstart = 0;
+            bool           part = false;
+            if (tid >= d0 && tid < n) {
+                const SearchDesc &ds = sh.desc[tid];
+                jstart               = tid == d0 ? j0 : 0;
+                if (ds.fast && ds.n_srows > jstart) {
+                    const uint32_t step = ds.skip ? 2u : 1u;
+                    nj                  = ds.n_srows - jstart;
+                    nstage              = (nj - 1) * step + ds.rows_per_pos;
+                    if (tid == d0 && nstage * ds.pitch_dw > win_cap_dw) {
+                        // rows staged for nj searched rows: (nj-1)*step + rows_per_pos ('fast' guarantees nj >= 1)
+                        nj     = (fast_div(win_cap_dw, ds.inv_pitch) - ds.rows_per_pos) / step + 1;
+                        nstage = (nj - 1) * step + ds.rows_per_pos;
+                        part   = true;
                     }
+                    need  = (nstage * ds.pitch_dw + SEG_ALIGN - 1) & ~(SEG_ALIGN - 1);
+                    items = nj * ds.nq;
                 }
-                uint32_t need_in = need, items_in = items, cnt_in = need ? 1u : 0u;
+            }
+            const bool split = __shfl((int)part, (int)(d0 & 63u), 64) != 0;
+            uint32_t   need_in = need, items_in = items, cnt_in = need ? 1u : 0u;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t a = __shfl_up(need_in, off, 64), b2 = __shfl_up(items_in, off, 64), c = __shfl_up(cnt_in, off, 64);
-                    if ((int)tid >= off)
-                        need_in += a, items_in += b2, cnt_in += c;
-                }
-                const uint32_t total = __shfl(need_in, 63, 64);
-                if (total <= win_cap_dw) {
-                    if (need) {
-                        const uint32_t sidx = cnt_in - 1, off0 = need_in - need;
-                        SearchSeg     &sg   = sh.seg[sidx];
-                        sg.d = tid, sg.j0 = 0, sg.nj = sh.desc[tid].n_srows, sg.lds_dw = off0, sg.nstage = nstage;
-                        sg.item_base = items_in - items;
-                        for (uint32_t c = off0 / SEG_ALIGN; c < (off0 + need) / SEG_ALIGN; c++) sh.chunk_seg[c] = (uint8_t)sidx;
-                    }
-                    if (tid == 63)
-                        sh.nseg = cnt_in, sh.nitems = items_in, sh.nstage_dw = total, sh.next_d = n, sh.next_j = 0;
-                    planned = true;  // wave-uniform
-                }
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t a = __shfl_up(need_in, off, 64), b2 = __shfl_up(items_in, off, 64), c = __shfl_up(cnt_in, off, 64);
+                if ((int)tid >= off)
+                    need_in += a, items_in += b2, cnt_in += c;
             }
-            planned = __syncthreads_or(planned);
-            first   = false;
-        }
-        const bool onepass = planned;
-        if (!planned) {
+            const bool take = tid >= d0 && tid < n && need_in <= win_cap_dw && (!split || tid == d0);
+            if (take && need) {
+                SearchSeg &sg = sh.seg[cnt_in - 1];
+                sg.d = tid, sg.j0 = jstart, sg.nj = nj, sg.lds_dw = need_in - need, sg.nstage = nstage;
+                sg.item_base = items_in - items;
+            }
+            const uint32_t ntake = (uint32_t)__popcll(__ballot(take));
+            // totals of the taken range live in its last lane
+            const uint32_t last = d0 + (ntake ? ntake - 1 : 0);
+            const uint32_t t_need = __shfl(need_in, (int)(last & 63u), 64), t_items = __shfl(items_in, (int)(last & 63u), 64),
+                           t_cnt = __shfl(cnt_in, (int)(last & 63u), 64);
+            const uint32_t nj_d0 = __shfl(nj, (int)(d0 & 63u), 64);
             if (tid == 0) {
-                uint32_t nseg = 0, used = 0, items = 0, d = sh.next_d, j = sh.next_j;
-                while (d < n && nseg < (uint32_t)SH::MAXS) {
-                    const SearchDesc &ds = sh.desc[d];
-                    if (!ds.fast || j >= ds.n_srows) {
-                        d++, j = 0;
-                        continue;
-                    }
-                    const uint32_t step    = ds.skip ? 2u : 1u;
-                    const uint32_t free_dw = win_cap_dw - used;
-                    // rows staged for nj searched rows: (nj-1)*step + rows_per_pos
-                    if (ds.pitch_dw * ds.rows_per_pos > free_dw)
-                        break;
-                    const uint32_t max_rows = fast_div(free_dw, ds.inv_pitch);
-                    uint32_t       nj       = (max_rows - ds.rows_per_pos) / step + 1;
-                    if (nj > ds.n_srows - j)
-                        nj = ds.n_srows - j;
-                    SearchSeg &sg = sh.seg[nseg];
-                    sg.d = d, sg.j0 = j, sg.nj = nj, sg.lds_dw = used;
-                    sg.nstage    = (nj - 1) * step + ds.rows_per_pos;
-                    sg.item_base = items;
-                    const uint32_t need = (sg.nstage * ds.pitch_dw + SEG_ALIGN - 1) & ~(SEG_ALIGN - 1);
-                    for (uint32_t c = used / SEG_ALIGN; c < (used + need) / SEG_ALIGN && c < (uint32_t)MAX_CHUNKS; c++)
-                        sh.chunk_seg[c] = (uint8_t)nseg;
-                    nseg++;
-                    used = used + need < win_cap_dw ? used + need : win_cap_dw;
-                    items += nj * ds.nq;
-                    j += nj;
-                }
-                sh.nseg = nseg, sh.nitems = items, sh.nstage_dw = used, sh.next_d = d, sh.next_j = j;
+                sh.nseg = ntake ? t_cnt : 0, sh.nitems = ntake ? t_items : 0, sh.nstage_dw = ntake ? t_need : 0;
+                if (split)
+                    sh.next_d = d0, sh.next_j = j0 + nj_d0;
+                else
+                    sh.next_d = d0 + ntake, sh.next_j = 0;
             }
-            __syncthreads();
         }
+        __syncthreads();
+        const bool onepass = sh.next_d >= n;  // nothing left after this pass
         MS_PHASE(0);
         const uint32_t nseg = sh.nseg;
         if (nseg == 0)
