@@ -460,6 +460,11 @@ __device__ void cand_general(LDS &L, const SvtHipMeParams &p, const uint32_t *gs
 // Phase timing for kernel tuning (make PROF=1): per-phase wall-clock ticks (100 MHz) summed over all workgroups.
 #ifdef SVT_HIP_ME_PROFILE
 __device__ unsigned long long g_me_prof[16];
+#define ME_SITE(k)             \
+    do {                       \
+        if (threadIdx.x == 0)  \
+            L.sh.prof_site = k; \
+    } while (0)
 #define ME_PHASE(i)                                                        \
     do {                                                                   \
         if (threadIdx.x == 0) {                                            \
@@ -471,6 +476,9 @@ __device__ unsigned long long g_me_prof[16];
 #else
 #define ME_PHASE(i) \
     do {            \
+    } while (0)
+#define ME_SITE(k) \
+    do {           \
     } while (0)
 #endif
 
@@ -1261,6 +1269,7 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
         __syncthreads();
     }
     ME_PHASE(1);
+    ME_SITE(0);
     if (p.prehme_enable) {
         // List 1 reads list 0's results for the l1 early exit (:1771-1781) and for the tl == 0 mirror (:1853-1860); only
         // then does it need a round of its own — otherwise all references are searched by one call.
@@ -1275,6 +1284,7 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
         __syncthreads();
     }
     ME_PHASE(2);
+    ME_SITE(1);
     if (p.enable_hme_flag && p.enable_hme_level0_flag) {
         // With distance-based resizing, references other than the first read the first one's quadrant-(0,0) vector
         // (get_hme_l0_search_area, :1881-1890): the first reference then gets a round of its own.
@@ -1288,9 +1298,11 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
         }
     }
     ME_PHASE(3);
+    ME_SITE(2);
     if (p.enable_hme_flag && p.enable_hme_level1_flag)
         hme_l1_round(L, c, 0, nref);
     ME_PHASE(4);
+    ME_SITE(3);
     // the down-scaled stages' windows may have overwritten the full resolution source block: stage it again (the barrier
     // that ends the last search orders the window reads before these writes)
     if (p.prehme_enable || (p.enable_hme_flag && (p.enable_hme_level0_flag || p.enable_hme_level1_flag))) {
@@ -1321,14 +1333,14 @@ __global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFra
 
 #ifdef SVT_HIP_ME_PROFILE
 // tuning aid, only in PROF=1 builds: copies (and optionally clears) the phase counters
-extern "C" __attribute__((visibility("default"))) int32_t svt_hip_debug_me_profile(unsigned long long out[16], int32_t reset) {
+extern "C" __attribute__((visibility("default"))) int32_t svt_hip_debug_me_profile(unsigned long long out[32], int32_t reset) {
     SVT_HIP_CHECK(hipDeviceSynchronize());
     SVT_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_prof), sizeof(unsigned long long) * 11));
-    SVT_HIP_CHECK(hipMemcpyFromSymbol(out + 11, HIP_SYMBOL(g_ms_prof), sizeof(unsigned long long) * 5));
+    SVT_HIP_CHECK(hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_ms_prof), sizeof(unsigned long long) * 16));
     if (reset) {
         unsigned long long z[16] = {};
         SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_me_prof), z, sizeof(z)));
-        SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ms_prof), z, sizeof(unsigned long long) * 8));
+        SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ms_prof), z, sizeof(unsigned long long) * 16));
     }
     return SVT_HIP_OK;
 }

@@ -54,16 +54,19 @@ template <int NS> struct SearchSharedT {
     uint64_t   best[NS];
     uint32_t   nseg, nitems, nstage_dw;
     uint32_t   next_d, next_j;  // continuation point of the planner
+#ifdef SVT_HIP_ME_PROFILE
+    uint32_t   prof_site;  // PROF=1 builds: which caller the phase times are booked to
+#endif
 };
 using SearchShared = SearchSharedT<MAX_SEARCH>;
 
 #ifdef SVT_HIP_ME_PROFILE
-static __device__ unsigned long long g_ms_prof[8];  // plan, stage, search, slow-path/exit (per translation unit)
+static __device__ unsigned long long g_ms_prof[16];  // [call site][plan, stage, search, -] (per translation unit)
 #define MS_PHASE(i)                                                 \
     do {                                                            \
         if (threadIdx.x == 0) {                                     \
             const unsigned long long t_ = wall_clock64();           \
-            atomicAdd(&g_ms_prof[i], t_ - ms_last);                 \
+            atomicAdd(&g_ms_prof[(sh.prof_site & 3u) * 4 + i], t_ - ms_last);                 \
             ms_last = t_;                                           \
         }                                                           \
     } while (0)

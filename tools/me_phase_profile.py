@@ -23,13 +23,15 @@ def main():
     if not hasattr(lib, "svt_hip_debug_me_profile"):
         raise SystemExit("library was not built with PROF=1")
     import bench
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 32)()
     bench.main()
     lib.svt_hip_debug_me_profile(out, 1)
     tot = sum(out[:11]) or 1
     res = {n: round(100.0 * out[i] / tot, 2) for i, n in enumerate(PHASES)}
     res["total_ticks_100MHz"] = int(tot)
-    res["inside_wg_multi_search_percent_of_total"] = {n: round(100.0 * out[11 + i] / tot, 2) for i, n in enumerate(("plan", "stage", "search"))}
+    res["inside_wg_multi_search_percent_of_total"] = {
+        site: {n: round(100.0 * out[16 + 4 * k + i] / tot, 2) for i, n in enumerate(("plan", "stage", "search"))}
+        for k, site in enumerate(("pre-HME", "HME L0", "HME L1", "HME L2"))}
     print(json.dumps({"me_phase_percent": res}))
 
 
