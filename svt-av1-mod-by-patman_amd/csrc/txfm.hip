@@ -55,19 +55,25 @@ struct QP {
     int32_t        zbin[2], round[2], quant[2], qshift[2], dequant[2];
     int32_t        log_scale, mode;
     const uint8_t *qm, *iqm;
+    bool           simple;  // no quantisation matrices and 16-bit table entries: quant_small() applies to small coefficients
 };
 __device__ __forceinline__ int32_t rpot(int32_t v, int n) { return (v + ((1 << n) >> 1)) >> n; }
 __device__ __forceinline__ void load_qp(QP &q, const SvtHipTxfmDesc &d, const uint8_t *base) {
     q.log_scale = d.log_scale, q.mode = d.quant_mode;
+    bool small = true;
     for (int i = 0; i < 2; i++) {
         q.zbin[i]    = rpot(d.zbin[i], d.log_scale);
         q.round[i]   = rpot(d.round[i], d.log_scale);
         q.quant[i]   = d.quant[i];
         q.qshift[i]  = d.quant_shift[i];
         q.dequant[i] = d.dequant[i];
+        // the ranges the reference's int16 tables can hold
+        small = small && q.zbin[i] >= 0 && q.zbin[i] < 65536 && q.round[i] >= 0 && q.round[i] < 32768 && q.quant[i] >= -32768 && q.quant[i] < 32768 &&
+            q.qshift[i] >= 0 && q.qshift[i] < 65536 && q.dequant[i] >= 0 && q.dequant[i] < 32768;
     }
     q.qm  = d.qm_off == SVT_HIP_NO_OFFSET ? nullptr : base + d.qm_off;
     q.iqm = d.iqm_off == SVT_HIP_NO_OFFSET ? nullptr : base + d.iqm_off;
+    q.simple = small && !q.qm && !q.iqm && d.log_scale >= 0 && d.log_scale <= 2;
 }
 __device__ __forceinline__ int64_t clamp_i16(int64_t v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 // a * b with the exact 64-bit result; when a fits 32 bits (always, for coefficients in the range a bit depth can produce)
@@ -129,6 +135,44 @@ __device__ __forceinline__ void quant_one(const QP &q, int32_t c, uint32_t rc, i
     dqc               = (adq ^ sign) - sign;
 }
 
+// quant_one for the common case: no quantisation matrix (weights 32, so the << 5 / >> 5 pairs cancel), 16-bit table entries
+// (q.simple) and |c| < 2^15.  Every product then fits 32 bits except x * quant_shift (38 bits: one v_mad_i64_i32), where
+//   (((t << 5) * quant) >> 16) + (t << 5)  ==  ((t * quant) >> 11) + (t << 5)      exactly (t * quant fits 32 bits),
+// so the results are bit-identical to the general path at about a third of its instructions.
+__device__ __forceinline__ void quant_small(const QP &q, int32_t c, int ac, int32_t &qc, int32_t &dqc) {
+    const int32_t sign = c >> 31;
+    const int32_t absc = (c ^ sign) - sign;  // < 2^15
+    const int     ls   = q.log_scale;
+    int32_t       aq   = 0;
+    if (q.mode == SVT_HIP_QUANT_B || q.mode == SVT_HIP_QUANT_B_HBD) {
+        if (absc >= q.zbin[ac]) {
+            int32_t t = absc + q.round[ac];                        // < 2^16
+            t         = q.mode == SVT_HIP_QUANT_B && t > 32767 ? 32767 : t;
+            const int32_t x = (__mul24(t, q.quant[ac]) >> 11) + (t << 5);  // 0 <= x < 2^22
+            aq              = (int32_t)(((int64_t)x * (int64_t)q.qshift[ac]) >> (21 - ls));
+        }
+    } else {
+        if ((absc << (1 + ls)) >= q.dequant[ac]) {
+            int32_t a2 = absc + q.round[ac];
+            a2         = q.mode == SVT_HIP_QUANT_FP && a2 > 32767 ? 32767 : a2;
+            aq         = __mul24(a2, q.quant[ac]) >> (16 - ls);
+        }
+    }
+    qc                = (aq ^ sign) - sign;
+    const int32_t adq = mul32(aq, q.dequant[ac]) >> ls;
+    dqc               = (adq ^ sign) - sign;
+}
+
+template <int N>
+__device__ __forceinline__ uint32_t max_abs(const int32_t (&v)[N]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t a = v[i] < 0 ? 0u - (uint32_t)v[i] : (uint32_t)v[i];
+        m                = a > m ? a : m;
+    }
+    return m;
+}
 template <int L>
 __device__ __forceinline__ uint32_t group_max(uint32_t v) {
 #pragma unroll
@@ -145,11 +189,12 @@ __device__ __forceinline__ uint64_t group_sum64(uint64_t v) {
     return v;
 }
 
+// highbd_clip_pixel_add with the check_range clamp of the residual (inv_transforms.c:2490-2520); everything fits 32 bits
+// for bit depths up to 12
 __device__ __forceinline__ uint16_t clip_pixel_add(uint32_t dest, int32_t trans, int bd) {
-    const int64_t mx = ((int64_t)1 << (7 + bd)) - 1 + ((int64_t)914 << (bd - 7)), mn = -mx - 1;
-    int64_t       t  = trans;
-    t                = t > mx ? mx : (t < mn ? mn : t);
-    const int32_t v  = (int32_t)dest + (int32_t)t;
+    const int32_t mx = (1 << (7 + bd)) - 1 + (914 << (bd - 7)), mn = -mx - 1;
+    const int32_t t  = trans > mx ? mx : (trans < mn ? mn : trans);
+    const int32_t v  = (int32_t)dest + t;
     const int32_t hi = (1 << bd) - 1;
     return (uint16_t)(v < 0 ? 0 : (v > hi ? hi : v));
 }
@@ -191,6 +236,7 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
     const int vk = VTX_D[d.tx_type & 15], hk = HTX_D[d.tx_type & 15];
     const bool ud = vk == 2, lr = hk == 2;
     const int  bd = d.bit_depth;
+    const int  bdi = bd == 8 ? 0 : (bd == 10 ? 1 : (bd == 12 ? 2 : -1));  // row of INV_FAST_OK
     const bool do_fwd = d.flags & SVT_HIP_TX_FWD, do_inv = d.flags & SVT_HIP_TX_INV;
     constexpr int sh0 = FWD_SHIFT[G::WI][G::HI][0], sh1 = FWD_SHIFT[G::WI][G::HI][1], sh2 = FWD_SHIFT[G::WI][G::HI][2];
     int32_t *lds = buf[slot];
@@ -205,21 +251,47 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
             const int16_t *res = (const int16_t *)(base + d.residual_off);
 #pragma unroll
             for (int r = 0; r < H; r++) v[r] = (int32_t)((uint32_t)(int32_t)res[(size_t)(ud ? H - 1 - r : r) * d.residual_stride + t] << sh0);
-            fwd1d<H>(v, vk, FWD_COS_COL[G::WI][G::HI]);
+            // 24-bit multiplies and 32-bit sums whenever the whole wave's inputs are small enough for them to be exact
+            // (the limits leave room for the rounding term of the shift that follows)
+            if (__all(max_abs<H>(v) <= (uint32_t)FWD_FAST_LIMIT[G::HI][kind_index(vk)][FWD_COS_COL[G::WI][G::HI] - 10])) {
+                fwd1d<Fast, H>(v, vk, FWD_COS_COL[G::WI][G::HI]);
+                if constexpr (sh1 < 0) {
+#pragma unroll
+                    for (int r = 0; r < H; r++) v[r] = Fast::rs(v[r], -sh1);
+                }
+            } else {
+                fwd1d<Exact, H>(v, vk, FWD_COS_COL[G::WI][G::HI]);
+                if constexpr (sh1 < 0) {
+#pragma unroll
+                    for (int r = 0; r < H; r++) v[r] = rshift64(v[r], -sh1);
+                }
+            }
             const int cc = lr ? W - 1 - t : t;
 #pragma unroll
-            for (int r = 0; r < H; r++) lds[r * PW + cc] = sh1 < 0 ? rshift64(v[r], -sh1) : v[r];
+            for (int r = 0; r < H; r++) lds[r * PW + cc] = v[r];
         }
         __syncthreads();
         // -------------------------------------------------------------- forward: rows
         if (live && t < H) {
 #pragma unroll
             for (int c = 0; c < W; c++) row[c] = lds[t * PW + c];
-            fwd1d<W>(row, hk, FWD_COS_ROW[G::WI][G::HI]);
+            if (__all(max_abs<W>(row) <= (uint32_t)FWD_FAST_LIMIT[G::WI][kind_index(hk)][FWD_COS_ROW[G::WI][G::HI] - 10])) {
+                fwd1d<Fast, W>(row, hk, FWD_COS_ROW[G::WI][G::HI]);
+                if constexpr (sh2 < 0) {
+#pragma unroll
+                    for (int c = 0; c < W; c++) row[c] = Fast::rs(row[c], -sh2);
+                }
+            } else {
+                fwd1d<Exact, W>(row, hk, FWD_COS_ROW[G::WI][G::HI]);
+                if constexpr (sh2 < 0) {
+#pragma unroll
+                    for (int c = 0; c < W; c++) row[c] = rshift64(row[c], -sh2);
+                }
+            }
             const int kw = W >> d.shape, kh = H >> d.shape;
 #pragma unroll
             for (int c = 0; c < W; c++) {
-                int32_t x = sh2 < 0 ? rshift64(row[c], -sh2) : row[c];
+                int32_t x = row[c];
                 if (G::RECT)
                     x = rshift64((int64_t)x * 5793, 12);
                 row[c] = (t < kh && c < kw) ? x : 0;
@@ -263,7 +335,10 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
             for (int c = 0; c < IW; c++) {
                 const uint32_t rc = (uint32_t)(t * IW + c);
                 int32_t        qc, dqc;
-                quant_one(q, row[c], rc, qc, dqc);
+                if (q.simple && (uint32_t)(row[c] + 32767) <= 65534u)
+                    quant_small(q, row[c], rc != 0, qc, dqc);
+                else
+                    quant_one(q, row[c], rc, qc, dqc);
                 if (qc) {
                     const uint32_t pos = (uint32_t)(uint16_t)iscan[rc] + 1u;
                     eob                = pos > eob ? pos : eob;
@@ -314,10 +389,20 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
             any |= row[c] != 0;
         }
         if (any) {  // an all-zero row stays all-zero through every 1-D kernel
-            inv1d<W>(row, hk, range_row);
             constexpr int ish0 = INV_SHIFT0[G::WI][G::HI];
+            if (__all(bdi >= 0 && INV_FAST_OK[bdi < 0 ? 0 : bdi][0][G::WI][kind_index(hk)] != 0)) {
+                inv1d<Fast, W>(row, hk, range_row);
+                if constexpr (ish0 < 0) {
 #pragma unroll
-            for (int c = 0; c < W; c++) row[c] = ish0 < 0 ? rshift64(row[c], -ish0) : row[c];
+                    for (int c = 0; c < W; c++) row[c] = Fast::rs(row[c], -ish0);
+                }
+            } else {
+                inv1d<Exact, W>(row, hk, range_row);
+                if constexpr (ish0 < 0) {
+#pragma unroll
+                    for (int c = 0; c < W; c++) row[c] = rshift64(row[c], -ish0);
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < W; c++) lds[t * PW + c] = row[c];
@@ -330,19 +415,27 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
         const int cc = lr ? W - 1 - t : t;
 #pragma unroll
         for (int r = 0; r < H; r++) v[r] = clampv<true>(lds[r * PW + cc], col_clamp);
-        inv1d<H>(v, vk, range_col);
+        if (__all(bdi >= 0 && INV_FAST_OK[bdi < 0 ? 0 : bdi][1][G::HI][kind_index(vk)] != 0)) {
+            inv1d<Fast, H>(v, vk, range_col);
+#pragma unroll
+            for (int r = 0; r < H; r++) v[r] = Fast::rs(v[r], 4);
+        } else {
+            inv1d<Exact, H>(v, vk, range_col);
+#pragma unroll
+            for (int r = 0; r < H; r++) v[r] = rshift64(v[r], 4);
+        }
         if (d.flags & SVT_HIP_TX_PIXEL16) {
             const uint16_t *pr = (const uint16_t *)(base + d.pred_off);
             uint16_t       *rc = (uint16_t *)(base + d.recon_off);
 #pragma unroll
             for (int r = 0; r < H; r++)
-                rc[(size_t)r * d.recon_stride + t] = clip_pixel_add(pr[(size_t)r * d.pred_stride + t], rshift64(v[ud ? H - 1 - r : r], 4), bd);
+                rc[(size_t)r * d.recon_stride + t] = clip_pixel_add(pr[(size_t)r * d.pred_stride + t], v[ud ? H - 1 - r : r], bd);
         } else {
             const uint8_t *pr = base + d.pred_off;
             uint8_t       *rc = base + d.recon_off;
 #pragma unroll
             for (int r = 0; r < H; r++)
-                rc[(size_t)r * d.recon_stride + t] = (uint8_t)clip_pixel_add(pr[(size_t)r * d.pred_stride + t], rshift64(v[ud ? H - 1 - r : r], 4), 8);
+                rc[(size_t)r * d.recon_stride + t] = (uint8_t)clip_pixel_add(pr[(size_t)r * d.pred_stride + t], v[ud ? H - 1 - r : r], 8);
         }
     }
 }
@@ -363,7 +456,10 @@ __global__ __launch_bounds__(256) void quantize_kernel(uint8_t *__restrict__ bas
     uint32_t       eob = 0;
     for (uint32_t rc = threadIdx.x; rc < n_coeffs; rc += 256) {
         int32_t qc, dqc;
-        quant_one(q, ci[rc], rc, qc, dqc);
+        if (q.simple && (uint32_t)(ci[rc] + 32767) <= 65534u)
+            quant_small(q, ci[rc], rc != 0, qc, dqc);
+        else
+            quant_one(q, ci[rc], rc, qc, dqc);
         if (qc) {
             const uint32_t pos = (uint32_t)(uint16_t)iscan[rc] + 1u;
             eob                = pos > eob ? pos : eob;

@@ -12,14 +12,25 @@
 // clamps every addition to the pass's stage range (inv_transforms.c:42-84).
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TXD_FN __device__ __forceinline__
+#else
+// host build: tools/txfm_bounds.cpp instantiates the same networks over intervals to derive the Fast-path limits
+#define TXD_FN inline
+#endif
 
 namespace svthip {
 namespace txd {
 
+#if defined(__HIPCC__)
 __constant__ int32_t d_cospi[4][64];  // bits 10..13; uploaded by txfm_init_tables()
 __constant__ int32_t d_sinpi[4][5];
+#else
+static int32_t d_cospi[4][64];
+static int32_t d_sinpi[4][5];
+#endif
 
 struct Rot {
     const int32_t *c;  // d_cospi[bit-10]
@@ -38,182 +49,256 @@ constexpr int clog2(int n) {
     return l;
 }
 
-__device__ __forceinline__ int32_t mul32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
-__device__ __forceinline__ int32_t add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
-__device__ __forceinline__ int32_t sub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
-__device__ __forceinline__ int32_t rshift64(int64_t v, int bit) { return (int32_t)((v + ((int64_t)1 << (bit - 1))) >> bit); }
-__device__ __forceinline__ int32_t btf(int32_t w0, int32_t a, int32_t w1, int32_t b, int bit) {
-    const int64_t r = (int64_t)mul32(w0, a) + (int64_t)mul32(w1, b);
-    return (int32_t)((r + ((int64_t)1 << (bit - 1))) >> bit);
-}
-template <bool INV>
-__device__ __forceinline__ int32_t clampv(int32_t v, int bit) {
-    if (!INV)
-        return v;
+TXD_FN int32_t mul32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+TXD_FN int32_t add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+TXD_FN int32_t sub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+TXD_FN int32_t rshift64(int64_t v, int bit) { return (int32_t)((v + ((int64_t)1 << (bit - 1))) >> bit); }
+TXD_FN int32_t clamp_bits(int32_t v, int bit) {
     const int32_t hi = (int32_t)(((int64_t)1 << (bit - 1)) - 1), lo = -hi - 1;  // bit is 16..20 here
     return v > hi ? hi : (v < lo ? lo : v);
 }
+template <bool INV>
+TXD_FN int32_t clampv(int32_t v, int bit) {
+    return INV ? clamp_bits(v, bit) : v;
+}
+
+// ------------------------------------------------------------------------------------- arithmetic policies
+// The networks below are written once over an arithmetic policy A (value type A::T):
+//   Exact — the reference's arithmetic verbatim: 32-bit wrapping products, 64-bit sum, one rounding shift.  On gfx950 a
+//           32-bit product is a quarter-rate instruction and the 64-bit tail costs six more.
+//   Fast  — 24-bit multiplies (full rate) and a 32-bit sum.  Gives the same bits as Exact whenever every multiplied value is
+//           below 2^23 in magnitude and no sum leaves 32 bits; the callers only take it when that is PROVEN for the vector at
+//           hand: forward transforms compare the largest input magnitude with fast_fwd_limit() (derived by propagating
+//           intervals through these same templates, tools/txfm_bounds.cpp), inverse transforms are covered for 8/10-bit
+//           by their stage-range clamps.
+//   (tools/txfm_bounds.cpp adds a third policy over intervals.)
+struct Exact {
+    using T = int32_t;
+    static TXD_FN T add(T a, T b) { return add32(a, b); }
+    static TXD_FN T sub(T a, T b) { return sub32(a, b); }
+    static TXD_FN T neg(T a) { return (int32_t)(0u - (uint32_t)a); }
+    static TXD_FN T mul(int32_t w, T a) { return mul32(w, a); }
+    static TXD_FN T btf(int32_t w0, T a, int32_t w1, T b, int bit) {
+        const int64_t r = (int64_t)mul32(w0, a) + (int64_t)mul32(w1, b);
+        return (int32_t)((r + ((int64_t)1 << (bit - 1))) >> bit);
+    }
+    static TXD_FN T rs(T v, int bit) { return rshift64(v, bit); }                                   // rounding shift
+    static TXD_FN T scale(T v, int32_t k, int bit) { return rshift64((int64_t)v * k, bit); }        // (v * k + half) >> bit
+    static TXD_FN T times(T v, int32_t k) { return (int32_t)((int64_t)v * k); }
+    template <bool INV> static TXD_FN T clamp(T v, int bit) { return clampv<INV>(v, bit); }
+    static TXD_FN bool all_zero4(T a, T b, T c, T d) { return !(a | b | c | d); }
+};
+#if defined(__HIPCC__)
+struct Fast {
+    using T = int32_t;
+    static TXD_FN T add(T a, T b) { return a + b; }
+    static TXD_FN T sub(T a, T b) { return a - b; }
+    static TXD_FN T neg(T a) { return -a; }
+    static TXD_FN T mul(int32_t w, T a) { return __mul24(w, a); }
+    static TXD_FN T btf(int32_t w0, T a, int32_t w1, T b, int bit) {
+        return (__mul24(w0, a) + __mul24(w1, b) + (1 << (bit - 1))) >> bit;
+    }
+    static TXD_FN T rs(T v, int bit) { return (v + (1 << (bit - 1))) >> bit; }
+    static TXD_FN T scale(T v, int32_t k, int bit) { return (__mul24(v, k) + (1 << (bit - 1))) >> bit; }
+    static TXD_FN T times(T v, int32_t k) { return __mul24(v, k); }
+    template <bool INV> static TXD_FN T clamp(T v, int bit) { return clampv<INV>(v, bit); }
+    static TXD_FN bool all_zero4(T a, T b, T c, T d) { return !(a | b | c | d); }
+};
+#endif
+
+// ------------------------------------------------------------------------------------- Fast-path limits
+#if defined(__HIPCC__)
+#define TXD_TABLE __device__ const
+#else
+#define TXD_TABLE static const
+#endif
+#if defined(__HIPCC__) || defined(TXD_WITH_TABLES)
+// BEGIN GENERATED (tools/txfm_bounds.cpp)
+// largest input magnitude for which Fast == Exact: [log2(N) - 2][kind: DCT, ADST, identity][cos bit - 10]
+TXD_TABLE int32_t FWD_FAST_LIMIT[5][3][4] = {
+    /* 4 */ {{741534, 370767, 185383, 92675}, {462819, 231509, 115729, 57863}, {370702, 370702, 370702, 370702}},
+    /* 8 */ {{313229, 156559, 78279, 39142}, {267445, 133814, 66914, 33445}, {8388607, 8388607, 8388607, 8388607}},
+    /* 16 */ {{133722, 66907, 33457, 16722}, {112837, 56386, 28195, 14096}, {185351, 185351, 185351, 185351}},
+    /* 32 */ {{56418, 28193, 14097, 7048}, {0, 0, 0, 0}, {8388607, 8388607, 8388607, 8388607}},
+    /* 64 */ {{23888, 11939, 5970, 2984}, {0, 0, 0, 0}, {92675, 92675, 92675, 92675}},
+};
+// stage clamps make Fast == Exact: [bit depth 8, 10, 12][pass: row, column][log2(N) - 2][kind: DCT, ADST, identity]
+TXD_TABLE uint8_t INV_FAST_OK[3][2][5][3] = {
+    {{{1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 0, 1}, {1, 0, 1}}, {{1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 0, 1}, {1, 0, 1}}},
+    {{{1, 0, 1}, {1, 1, 1}, {1, 1, 1}, {1, 0, 1}, {1, 0, 0}}, {{1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 0, 1}, {1, 0, 1}}},
+    {{{0, 0, 0}, {0, 0, 1}, {0, 0, 0}, {0, 0, 1}, {0, 0, 0}}, {{1, 0, 1}, {1, 1, 1}, {1, 1, 1}, {1, 0, 1}, {1, 0, 0}}},
+};
+// END GENERATED
+#endif
+// index of a 1-D kernel kind (0 DCT, 1 ADST, 2 FLIPADST, 3 identity) in the tables above
+TXD_FN int kind_index(int kind) { return kind == 0 ? 0 : (kind == 3 ? 2 : 1); }
 
 // ---------------------------------------------------------------------------------------------- DCT
-__device__ __forceinline__ void lvl_f1(int32_t *a, int lo, int hi, int S, int C, const Rot &r) {
-    const int32_t x = a[lo], y = a[hi];
-    a[lo] = btf(-r.c[S], x, r.c[C], y, r.bit);
-    a[hi] = btf(r.c[S], y, r.c[C], x, r.bit);
+template <class A>
+TXD_FN void lvl_f1(typename A::T *a, int lo, int hi, int S, int C, const Rot &r) {
+    const typename A::T x = a[lo], y = a[hi];
+    a[lo] = A::btf(-r.c[S], x, r.c[C], y, r.bit);
+    a[hi] = A::btf(r.c[S], y, r.c[C], x, r.bit);
 }
-__device__ __forceinline__ void lvl_f2(int32_t *a, int lo, int hi, int S, int C, const Rot &r) {
-    const int32_t x = a[lo], y = a[hi];
-    a[lo] = btf(-r.c[C], x, -r.c[S], y, r.bit);
-    a[hi] = btf(r.c[C], y, -r.c[S], x, r.bit);
+template <class A>
+TXD_FN void lvl_f2(typename A::T *a, int lo, int hi, int S, int C, const Rot &r) {
+    const typename A::T x = a[lo], y = a[hi];
+    a[lo] = A::btf(-r.c[C], x, -r.c[S], y, r.bit);
+    a[hi] = A::btf(r.c[C], y, -r.c[S], x, r.bit);
 }
-template <int M, int LV>
-__device__ __forceinline__ void odd_level(int32_t *a, const Rot &r) {  // a points at the odd part base
+template <class A, int M, int LV>
+TXD_FN void odd_level(typename A::T *a, const Rot &r) {  // a points at the odd part base
     if constexpr (LV == 1) {
 #pragma unroll
-        for (int j = M / 4; j < M / 2; j++) lvl_f1(a, j, M - 1 - j, 32, 32, r);
+        for (int j = M / 4; j < M / 2; j++) lvl_f1<A>(a, j, M - 1 - j, 32, 32, r);
     } else {
         constexpr int G = 1 << (LV - 2), gs = (M / 2) / G, q = gs / 4, unit = 64 >> LV;
 #pragma unroll
         for (int k = 0; k < G; k++) {
             const int S = unit * (1 + 4 * cbrev(LV - 2, k)), C = 64 - S;
 #pragma unroll
-            for (int j = q; j < 2 * q; j++) lvl_f1(a, k * gs + j, M - 1 - (k * gs + j), S, C, r);
+            for (int j = q; j < 2 * q; j++) lvl_f1<A>(a, k * gs + j, M - 1 - (k * gs + j), S, C, r);
 #pragma unroll
-            for (int j = 2 * q; j < 3 * q; j++) lvl_f2(a, k * gs + j, M - 1 - (k * gs + j), S, C, r);
+            for (int j = 2 * q; j < 3 * q; j++) lvl_f2<A>(a, k * gs + j, M - 1 - (k * gs + j), S, C, r);
         }
     }
 }
-template <int M, int G, bool INV>
-__device__ __forceinline__ void odd_bf(int32_t *a, const Rot &r) {
+template <class A, int M, int G, bool INV>
+TXD_FN void odd_bf(typename A::T *a, const Rot &r) {
 #pragma unroll
     for (int t = 0; t < M / G; t++)
 #pragma unroll
         for (int i = 0; i < G / 2; i++) {
-            const int     lo = t * G + i, hi = t * G + G - 1 - i;
-            const int32_t x = a[lo], y = a[hi];
+            const int           lo = t * G + i, hi = t * G + G - 1 - i;
+            const typename A::T x = a[lo], y = a[hi];
             if (!(t & 1)) {
-                a[lo] = clampv<INV>(add32(x, y), r.clamp);
-                a[hi] = clampv<INV>(sub32(x, y), r.clamp);
+                a[lo] = A::template clamp<INV>(A::add(x, y), r.clamp);
+                a[hi] = A::template clamp<INV>(A::sub(x, y), r.clamp);
             } else {
-                a[lo] = clampv<INV>(sub32(y, x), r.clamp);
-                a[hi] = clampv<INV>(add32(y, x), r.clamp);
+                a[lo] = A::template clamp<INV>(A::sub(y, x), r.clamp);
+                a[hi] = A::template clamp<INV>(A::add(y, x), r.clamp);
             }
         }
 }
-template <int M, bool INV>
-__device__ __forceinline__ void odd_out(int32_t *a, const Rot &r) {
+template <class A, int M, bool INV>
+TXD_FN void odd_out(typename A::T *a, const Rot &r) {
     constexpr int L = clog2(M), unit = 64 / (2 * M);
 #pragma unroll
     for (int i = 0; i < M / 2; i++) {
-        const int     B = unit * (1 + 4 * cbrev(L - 1, i)), A = 64 - B;
-        const int     lo = i, hi = M - 1 - i;
-        const int32_t x = a[lo], y = a[hi];
+        const int           B = unit * (1 + 4 * cbrev(L - 1, i)), Aw = 64 - B;
+        const int           lo = i, hi = M - 1 - i;
+        const typename A::T x = a[lo], y = a[hi];
         if (!INV) {
-            a[lo] = btf(r.c[A], x, r.c[B], y, r.bit);
-            a[hi] = btf(r.c[A], y, -r.c[B], x, r.bit);
+            a[lo] = A::btf(r.c[Aw], x, r.c[B], y, r.bit);
+            a[hi] = A::btf(r.c[Aw], y, -r.c[B], x, r.bit);
         } else {
-            a[lo] = btf(r.c[A], x, -r.c[B], y, r.bit);
-            a[hi] = btf(r.c[B], x, r.c[A], y, r.bit);
+            a[lo] = A::btf(r.c[Aw], x, -r.c[B], y, r.bit);
+            a[hi] = A::btf(r.c[B], x, r.c[Aw], y, r.bit);
         }
     }
 }
-template <int M, bool INV>
-__device__ __forceinline__ void odd_part(int32_t *a, const Rot &r) {
+template <class A, int M, bool INV>
+TXD_FN void odd_part(typename A::T *a, const Rot &r) {
     constexpr int L = clog2(M);
     if constexpr (!INV) {
-        if constexpr (L > 1) { odd_level<M, 1>(a, r); odd_bf<M, (M >> 1), false>(a, r); }
-        if constexpr (L > 2) { odd_level<M, 2>(a, r); odd_bf<M, (M >> 2), false>(a, r); }
-        if constexpr (L > 3) { odd_level<M, 3>(a, r); odd_bf<M, (M >> 3), false>(a, r); }
-        if constexpr (L > 4) { odd_level<M, 4>(a, r); odd_bf<M, (M >> 4), false>(a, r); }
-        odd_out<M, false>(a, r);
+        if constexpr (L > 1) { odd_level<A, M, 1>(a, r); odd_bf<A, M, (M >> 1), false>(a, r); }
+        if constexpr (L > 2) { odd_level<A, M, 2>(a, r); odd_bf<A, M, (M >> 2), false>(a, r); }
+        if constexpr (L > 3) { odd_level<A, M, 3>(a, r); odd_bf<A, M, (M >> 3), false>(a, r); }
+        if constexpr (L > 4) { odd_level<A, M, 4>(a, r); odd_bf<A, M, (M >> 4), false>(a, r); }
+        odd_out<A, M, false>(a, r);
     } else {
-        odd_out<M, true>(a, r);
-        if constexpr (L > 4) { odd_bf<M, (M >> 4), true>(a, r); odd_level<M, 4>(a, r); }
-        if constexpr (L > 3) { odd_bf<M, (M >> 3), true>(a, r); odd_level<M, 3>(a, r); }
-        if constexpr (L > 2) { odd_bf<M, (M >> 2), true>(a, r); odd_level<M, 2>(a, r); }
-        if constexpr (L > 1) { odd_bf<M, (M >> 1), true>(a, r); odd_level<M, 1>(a, r); }
+        odd_out<A, M, true>(a, r);
+        if constexpr (L > 4) { odd_bf<A, M, (M >> 4), true>(a, r); odd_level<A, M, 4>(a, r); }
+        if constexpr (L > 3) { odd_bf<A, M, (M >> 3), true>(a, r); odd_level<A, M, 3>(a, r); }
+        if constexpr (L > 2) { odd_bf<A, M, (M >> 2), true>(a, r); odd_level<A, M, 2>(a, r); }
+        if constexpr (L > 1) { odd_bf<A, M, (M >> 1), true>(a, r); odd_level<A, M, 1>(a, r); }
     }
 }
-template <int N>
-__device__ __forceinline__ void fdct_rec(int32_t *a, const Rot &r) {
+template <class A, int N>
+TXD_FN void fdct_rec(typename A::T *a, const Rot &r) {
     if constexpr (N == 2) {
-        const int32_t x = a[0], y = a[1];
-        a[0] = btf(r.c[32], x, r.c[32], y, r.bit);
-        a[1] = btf(-r.c[32], y, r.c[32], x, r.bit);
+        const typename A::T x = a[0], y = a[1];
+        a[0] = A::btf(r.c[32], x, r.c[32], y, r.bit);
+        a[1] = A::btf(-r.c[32], y, r.c[32], x, r.bit);
     } else {
 #pragma unroll
         for (int i = 0; i < N / 2; i++) {
-            const int32_t x = a[i], y = a[N - 1 - i];
-            a[i] = add32(x, y), a[N - 1 - i] = sub32(x, y);
+            const typename A::T x = a[i], y = a[N - 1 - i];
+            a[i] = A::add(x, y), a[N - 1 - i] = A::sub(x, y);
         }
-        fdct_rec<N / 2>(a, r);
-        odd_part<N / 2, false>(a + N / 2, r);
+        fdct_rec<A, N / 2>(a, r);
+        odd_part<A, N / 2, false>(a + N / 2, r);
     }
 }
-template <int N>
-__device__ __forceinline__ void idct_rec(int32_t *a, const Rot &r) {
+template <class A, int N>
+TXD_FN void idct_rec(typename A::T *a, const Rot &r) {
     if constexpr (N == 2) {
-        const int32_t x = a[0], y = a[1];
-        a[0] = btf(r.c[32], x, r.c[32], y, r.bit);
-        a[1] = btf(r.c[32], x, -r.c[32], y, r.bit);
+        const typename A::T x = a[0], y = a[1];
+        a[0] = A::btf(r.c[32], x, r.c[32], y, r.bit);
+        a[1] = A::btf(r.c[32], x, -r.c[32], y, r.bit);
     } else {
-        idct_rec<N / 2>(a, r);
-        odd_part<N / 2, true>(a + N / 2, r);
+        idct_rec<A, N / 2>(a, r);
+        odd_part<A, N / 2, true>(a + N / 2, r);
 #pragma unroll
         for (int i = 0; i < N / 2; i++) {
-            const int32_t x = a[i], y = a[N - 1 - i];
-            a[i] = clampv<true>(add32(x, y), r.clamp), a[N - 1 - i] = clampv<true>(sub32(x, y), r.clamp);
+            const typename A::T x = a[i], y = a[N - 1 - i];
+            a[i] = A::template clamp<true>(A::add(x, y), r.clamp), a[N - 1 - i] = A::template clamp<true>(A::sub(x, y), r.clamp);
         }
     }
 }
 // in-place, natural order in and out
-template <int N>
-__device__ __forceinline__ void fdct(int32_t (&v)[N], const Rot &r) {
-    fdct_rec<N>(v, r);
-    int32_t t[N];
+template <class A, int N>
+TXD_FN void fdct(typename A::T (&v)[N], const Rot &r) {
+    fdct_rec<A, N>(v, r);
+    typename A::T t[N];
 #pragma unroll
     for (int k = 0; k < N; k++) t[k] = v[cbrev(clog2(N), k)];
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = t[k];
 }
-template <int N>
-__device__ __forceinline__ void idct(int32_t (&v)[N], const Rot &r) {
-    int32_t t[N];
+template <class A, int N>
+TXD_FN void idct(typename A::T (&v)[N], const Rot &r) {
+    typename A::T t[N];
 #pragma unroll
     for (int k = 0; k < N; k++) t[k] = v[cbrev(clog2(N), k)];
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = t[k];
-    idct_rec<N>(v, r);
+    idct_rec<A, N>(v, r);
 }
 
 // --------------------------------------------------------------------------------------------- ADST
-__device__ __forceinline__ void fadst4(int32_t (&v)[4], int bit) {
+template <class A>
+TXD_FN void fadst4(typename A::T (&v)[4], int bit) {
+    using T = typename A::T;
     const int32_t *s = d_sinpi[bit - 10];
-    const int32_t  x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-    if (!(x0 | x1 | x2 | x3))
+    const T        x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    if (A::all_zero4(x0, x1, x2, x3))
         return;  // all zero stays all zero
-    const int32_t s0 = mul32(s[1], x0), s1 = mul32(s[4], x0), s2 = mul32(s[2], x1), s3 = mul32(s[1], x1);
-    const int32_t s4 = mul32(s[3], x2), s5 = mul32(s[4], x3), s6 = mul32(s[2], x3);
-    const int32_t s7 = sub32(add32(x0, x1), x3);
-    const int32_t y0 = add32(add32(s0, s2), s5), y1 = mul32(s[3], s7), y2 = add32(sub32(s1, s3), s6), y3 = s4;
-    v[0] = rshift64(add32(y0, y3), bit);
-    v[1] = rshift64(y1, bit);
-    v[2] = rshift64(sub32(y2, y3), bit);
-    v[3] = rshift64(add32(sub32(y2, y0), y3), bit);
+    const T s0 = A::mul(s[1], x0), s1 = A::mul(s[4], x0), s2 = A::mul(s[2], x1), s3 = A::mul(s[1], x1);
+    const T s4 = A::mul(s[3], x2), s5 = A::mul(s[4], x3), s6 = A::mul(s[2], x3);
+    const T s7 = A::sub(A::add(x0, x1), x3);
+    const T y0 = A::add(A::add(s0, s2), s5), y1 = A::mul(s[3], s7), y2 = A::add(A::sub(s1, s3), s6), y3 = s4;
+    v[0] = A::rs(A::add(y0, y3), bit);
+    v[1] = A::rs(y1, bit);
+    v[2] = A::rs(A::sub(y2, y3), bit);
+    v[3] = A::rs(A::add(A::sub(y2, y0), y3), bit);
 }
-__device__ __forceinline__ void iadst4(int32_t (&v)[4], int bit) {
+template <class A>
+TXD_FN void iadst4(typename A::T (&v)[4], int bit) {
+    using T = typename A::T;
     const int32_t *s = d_sinpi[bit - 10];
-    const int32_t  x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-    if (!(x0 | x1 | x2 | x3))
+    const T        x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    if (A::all_zero4(x0, x1, x2, x3))
         return;
-    int32_t       s0 = mul32(s[1], x0), s1 = mul32(s[2], x0), s2 = mul32(s[3], x1), s3 = mul32(s[4], x2);
-    const int32_t s4 = mul32(s[1], x2), s5 = mul32(s[2], x3), s6 = mul32(s[4], x3);
-    const int32_t s7 = add32(sub32(x0, x2), x3);
-    s0 = add32(s0, s3), s1 = sub32(s1, s4), s3 = s2, s2 = mul32(s[3], s7);
-    s0 = add32(s0, s5), s1 = sub32(s1, s6);
-    v[0] = rshift64(add32(s0, s3), bit);
-    v[1] = rshift64(add32(s1, s3), bit);
-    v[2] = rshift64(s2, bit);
-    v[3] = rshift64(sub32(add32(s0, s1), s3), bit);
+    T       s0 = A::mul(s[1], x0), s1 = A::mul(s[2], x0), s2 = A::mul(s[3], x1), s3 = A::mul(s[4], x2);
+    const T s4 = A::mul(s[1], x2), s5 = A::mul(s[2], x3), s6 = A::mul(s[4], x3);
+    const T s7 = A::add(A::sub(x0, x2), x3);
+    s0 = A::add(s0, s3), s1 = A::sub(s1, s4), s3 = s2, s2 = A::mul(s[3], s7);
+    s0 = A::add(s0, s5), s1 = A::sub(s1, s6);
+    v[0] = A::rs(A::add(s0, s3), bit);
+    v[1] = A::rs(A::add(s1, s3), bit);
+    v[2] = A::rs(s2, bit);
+    v[3] = A::rs(A::sub(A::add(s0, s1), s3), bit);
 }
 
 template <int N> struct AdstPerm;
@@ -225,95 +310,97 @@ template <> struct AdstPerm<16> {
     static constexpr int in[16]  = {0, -15, -7, 8, -3, 12, 4, -11, -1, 14, 6, -9, 2, -13, -5, 10};
     static constexpr int out[16] = {1, 14, 3, 12, 5, 10, 7, 8, 9, 6, 11, 4, 13, 2, 15, 0};
 };
-__device__ __forceinline__ void adst_a(int32_t *a, int i, int X, const Rot &r) {  // (cX x + cY y, cY x - cX y)
-    const int32_t x = a[i], y = a[i + 1];
-    a[i]     = btf(r.c[X], x, r.c[64 - X], y, r.bit);
-    a[i + 1] = btf(r.c[64 - X], x, -r.c[X], y, r.bit);
+template <class A>
+TXD_FN void adst_a(typename A::T *a, int i, int X, const Rot &r) {  // (cX x + cY y, cY x - cX y)
+    const typename A::T x = a[i], y = a[i + 1];
+    a[i]     = A::btf(r.c[X], x, r.c[64 - X], y, r.bit);
+    a[i + 1] = A::btf(r.c[64 - X], x, -r.c[X], y, r.bit);
 }
-__device__ __forceinline__ void adst_b(int32_t *a, int i, int P, const Rot &r) {  // (-cP x + cQ y, cQ x + cP y)
-    const int32_t x = a[i], y = a[i + 1];
-    a[i]     = btf(-r.c[P], x, r.c[64 - P], y, r.bit);
-    a[i + 1] = btf(r.c[64 - P], x, r.c[P], y, r.bit);
+template <class A>
+TXD_FN void adst_b(typename A::T *a, int i, int P, const Rot &r) {  // (-cP x + cQ y, cQ x + cP y)
+    const typename A::T x = a[i], y = a[i + 1];
+    a[i]     = A::btf(-r.c[P], x, r.c[64 - P], y, r.bit);
+    a[i + 1] = A::btf(r.c[64 - P], x, r.c[P], y, r.bit);
 }
-template <int N, int T>
-__device__ __forceinline__ void adst_rot(int32_t *a, const Rot &r) {
+template <class A, int N, int T>
+TXD_FN void adst_rot(typename A::T *a, const Rot &r) {
     constexpr int G = 2 << T;
 #pragma unroll
     for (int g = 0; g < N; g += G) {
         if constexpr (T == 1) {
-            adst_a(a, g + 2, 32, r);
+            adst_a<A>(a, g + 2, 32, r);
         } else {
             constexpr int np = G / 4, unit = 64 >> T;
 #pragma unroll
-            for (int p = 0; p < np / 2; p++) adst_a(a, g + G / 2 + 2 * p, unit * (1 + 4 * p), r);
+            for (int p = 0; p < np / 2; p++) adst_a<A>(a, g + G / 2 + 2 * p, unit * (1 + 4 * p), r);
 #pragma unroll
-            for (int p = 0; p < np / 2; p++) adst_b(a, g + G / 2 + np + 2 * p, 64 - unit * (1 + 4 * p), r);
+            for (int p = 0; p < np / 2; p++) adst_b<A>(a, g + G / 2 + np + 2 * p, 64 - unit * (1 + 4 * p), r);
         }
     }
 }
-template <int N, int SPAN, bool INV>
-__device__ __forceinline__ void adst_bf(int32_t *a, const Rot &r) {
+template <class A, int N, int SPAN, bool INV>
+TXD_FN void adst_bf(typename A::T *a, const Rot &r) {
 #pragma unroll
     for (int g = 0; g < N; g += 2 * SPAN)
 #pragma unroll
         for (int i = 0; i < SPAN; i++) {
-            const int32_t x = a[g + i], y = a[g + i + SPAN];
-            a[g + i]        = clampv<INV>(add32(x, y), r.clamp);
-            a[g + i + SPAN] = clampv<INV>(sub32(x, y), r.clamp);
+            const typename A::T x = a[g + i], y = a[g + i + SPAN];
+            a[g + i]        = A::template clamp<INV>(A::add(x, y), r.clamp);
+            a[g + i + SPAN] = A::template clamp<INV>(A::sub(x, y), r.clamp);
         }
 }
-template <int N>
-__device__ __forceinline__ void adst_final(int32_t *a, const Rot &r) {
+template <class A, int N>
+TXD_FN void adst_final(typename A::T *a, const Rot &r) {
     constexpr int unit = N == 8 ? 16 : 8, first = N == 8 ? 4 : 2;
 #pragma unroll
-    for (int j = 0; j < N / 2; j++) adst_a(a, 2 * j, first + unit * j, r);
+    for (int j = 0; j < N / 2; j++) adst_a<A>(a, 2 * j, first + unit * j, r);
 }
-template <int N>
-__device__ __forceinline__ void fadst(int32_t (&v)[N], const Rot &r) {
+template <class A, int N>
+TXD_FN void fadst(typename A::T (&v)[N], const Rot &r) {
     if constexpr (N == 4) {
-        fadst4(v, r.bit);
+        fadst4<A>(v, r.bit);
     } else {
-        int32_t a[N];
+        typename A::T a[N];
 #pragma unroll
         for (int j = 0; j < N; j++) {
             constexpr auto &P = AdstPerm<N>::in;
-            a[j] = P[j] < 0 ? (int32_t)(0u - (uint32_t)v[-P[j]]) : v[P[j]];
+            a[j] = P[j] < 0 ? A::neg(v[-P[j]]) : v[P[j]];
         }
-        adst_rot<N, 1>(a, r);
-        adst_bf<N, 2, false>(a, r);
-        adst_rot<N, 2>(a, r);
-        adst_bf<N, 4, false>(a, r);
+        adst_rot<A, N, 1>(a, r);
+        adst_bf<A, N, 2, false>(a, r);
+        adst_rot<A, N, 2>(a, r);
+        adst_bf<A, N, 4, false>(a, r);
         if constexpr (N == 16) {
-            adst_rot<N, 3>(a, r);
-            adst_bf<N, 8, false>(a, r);
+            adst_rot<A, N, 3>(a, r);
+            adst_bf<A, N, 8, false>(a, r);
         }
-        adst_final<N>(a, r);
+        adst_final<A, N>(a, r);
 #pragma unroll
         for (int k = 0; k < N; k++) v[k] = a[AdstPerm<N>::out[k]];
     }
 }
-template <int N>
-__device__ __forceinline__ void iadst(int32_t (&v)[N], const Rot &r) {
+template <class A, int N>
+TXD_FN void iadst(typename A::T (&v)[N], const Rot &r) {
     if constexpr (N == 4) {
-        iadst4(v, r.bit);
+        iadst4<A>(v, r.bit);
     } else {
-        int32_t a[N];
+        typename A::T a[N];
 #pragma unroll
         for (int k = 0; k < N; k++) a[AdstPerm<N>::out[k]] = v[k];
-        adst_final<N>(a, r);
+        adst_final<A, N>(a, r);
         if constexpr (N == 16) {
-            adst_bf<N, 8, true>(a, r);
-            adst_rot<N, 3>(a, r);
+            adst_bf<A, N, 8, true>(a, r);
+            adst_rot<A, N, 3>(a, r);
         }
-        adst_bf<N, 4, true>(a, r);
-        adst_rot<N, 2>(a, r);
-        adst_bf<N, 2, true>(a, r);
-        adst_rot<N, 1>(a, r);
+        adst_bf<A, N, 4, true>(a, r);
+        adst_rot<A, N, 2>(a, r);
+        adst_bf<A, N, 2, true>(a, r);
+        adst_rot<A, N, 1>(a, r);
 #pragma unroll
         for (int j = 0; j < N; j++) {
             constexpr auto &P = AdstPerm<N>::in;
             if (P[j] < 0)
-                v[-P[j]] = (int32_t)(0u - (uint32_t)a[j]);
+                v[-P[j]] = A::neg(a[j]);
             else
                 v[P[j]] = a[j];
         }
@@ -321,46 +408,46 @@ __device__ __forceinline__ void iadst(int32_t (&v)[N], const Rot &r) {
 }
 
 // ----------------------------------------------------------------------------------------- identity
-template <int N>
-__device__ __forceinline__ void identity(int32_t (&v)[N]) {
+template <class A, int N>
+TXD_FN void identity(typename A::T (&v)[N]) {
 #pragma unroll
     for (int i = 0; i < N; i++) {
         if constexpr (N == 4)
-            v[i] = rshift64((int64_t)v[i] * 5793, 12);
+            v[i] = A::scale(v[i], 5793, 12);
         else if constexpr (N == 8)
-            v[i] = (int32_t)((int64_t)v[i] * 2);
+            v[i] = A::times(v[i], 2);
         else if constexpr (N == 16)
-            v[i] = rshift64((int64_t)v[i] * 2 * 5793, 12);
+            v[i] = A::scale(v[i], 2 * 5793, 12);
         else if constexpr (N == 32)
-            v[i] = (int32_t)((int64_t)v[i] * 4);
+            v[i] = A::times(v[i], 4);
         else
-            v[i] = rshift64((int64_t)v[i] * 4 * 5793, 12);
+            v[i] = A::scale(v[i], 4 * 5793, 12);
     }
 }
 
 // kind: 0 DCT, 1 ADST (also FLIPADST: the flip is applied by the caller), 3 identity
-template <int N>
-__device__ __forceinline__ void fwd1d(int32_t (&v)[N], int kind, int bit) {
+template <class A, int N>
+TXD_FN void fwd1d(typename A::T (&v)[N], int kind, int bit) {
     const Rot r{d_cospi[bit - 10], bit, 0};
     if (kind == 0) {
-        fdct<N>(v, r);
+        fdct<A, N>(v, r);
     } else if (kind == 3) {
-        identity<N>(v);
+        identity<A, N>(v);
     } else {
         if constexpr (N <= 16)
-            fadst<N>(v, r);
+            fadst<A, N>(v, r);
     }
 }
-template <int N>
-__device__ __forceinline__ void inv1d(int32_t (&v)[N], int kind, int clamp) {
+template <class A, int N>
+TXD_FN void inv1d(typename A::T (&v)[N], int kind, int clamp) {
     const Rot r{d_cospi[2], 12, clamp};
     if (kind == 0) {
-        idct<N>(v, r);
+        idct<A, N>(v, r);
     } else if (kind == 3) {
-        identity<N>(v);
+        identity<A, N>(v);
     } else {
         if constexpr (N <= 16)
-            iadst<N>(v, r);
+            iadst<A, N>(v, r);
     }
 }
 
