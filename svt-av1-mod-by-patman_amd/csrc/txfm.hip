@@ -139,32 +139,31 @@ __device__ __forceinline__ void quant_one(const QP &q, int32_t c, uint32_t rc, i
 // (q.simple) and |c| < 2^15.  Every product then fits 32 bits except x * quant_shift (38 bits: one v_mad_i64_i32), where
 //   (((t << 5) * quant) >> 16) + (t << 5)  ==  ((t * quant) >> 11) + (t << 5)      exactly (t * quant fits 32 bits),
 // so the results are bit-identical to the general path at about a third of its instructions.
+template <bool BTYPE>  // BTYPE: quantize_b family (zbin, quant + quant_shift); otherwise the fp family
 __device__ __forceinline__ void quant_small(const QP &q, int32_t c, int ac, int32_t &qc, int32_t &dqc) {
     const int32_t sign = c >> 31;
     const int32_t absc = (c ^ sign) - sign;  // < 2^15
     const int     ls   = q.log_scale;
-    int32_t       aq   = 0;
-    if (q.mode == SVT_HIP_QUANT_B || q.mode == SVT_HIP_QUANT_B_HBD) {
-        if (absc >= q.zbin[ac]) {
-            int32_t t = absc + q.round[ac];                        // < 2^16
-            t         = q.mode == SVT_HIP_QUANT_B && t > 32767 ? 32767 : t;
-            const int32_t x = (__mul24(t, q.quant[ac]) >> 11) + (t << 5);  // 0 <= x < 2^22
-            aq              = (int32_t)(((int64_t)x * (int64_t)q.qshift[ac]) >> (21 - ls));
-        }
+    int32_t       aq;
+    if (BTYPE) {
+        int32_t t = absc + q.round[ac];  // < 2^16
+        t         = q.mode == SVT_HIP_QUANT_B && t > 32767 ? 32767 : t;
+        const int32_t x = (__mul24(t, q.quant[ac]) >> 11) + (t << 5);  // 0 <= x < 2^22
+        aq              = (int32_t)(((int64_t)x * (int64_t)q.qshift[ac]) >> (21 - ls));
+        aq              = absc >= q.zbin[ac] ? aq : 0;
     } else {
-        if ((absc << (1 + ls)) >= q.dequant[ac]) {
-            int32_t a2 = absc + q.round[ac];
-            a2         = q.mode == SVT_HIP_QUANT_FP && a2 > 32767 ? 32767 : a2;
-            aq         = __mul24(a2, q.quant[ac]) >> (16 - ls);
-        }
+        int32_t a2 = absc + q.round[ac];
+        a2         = q.mode == SVT_HIP_QUANT_FP && a2 > 32767 ? 32767 : a2;
+        aq         = __mul24(a2, q.quant[ac]) >> (16 - ls);
+        aq         = (absc << (1 + ls)) >= q.dequant[ac] ? aq : 0;
     }
     qc                = (aq ^ sign) - sign;
-    const int32_t adq = mul32(aq, q.dequant[ac]) >> ls;
+    const int32_t adq = __mul24(aq, q.dequant[ac]) >> ls;  // aq < 2^19, dequant < 2^15
     dqc               = (adq ^ sign) - sign;
 }
 
 template <int N>
-__device__ __forceinline__ uint32_t max_abs(const int32_t (&v)[N]) {
+__device__ __forceinline__ uint32_t max_abs(const int32_t *v) {
     uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -331,18 +330,23 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
 #pragma unroll
                 for (int c = 0; c < IW; c++) row[c] = ci[c];
             }
+            // one decision per wave: every coefficient small and plain tables -> the branch-free short form
+            const bool btype = q.mode == SVT_HIP_QUANT_B || q.mode == SVT_HIP_QUANT_B_HBD;
+            const int  path  = (q.simple && max_abs<IW>(row) <= 32767u) ? (btype ? 1 : 2) : 0;
+            const bool all1 = __all(path == 1), all2 = __all(path == 2);
 #pragma unroll
             for (int c = 0; c < IW; c++) {
                 const uint32_t rc = (uint32_t)(t * IW + c);
+                const int      ac = (c > 0) | (t > 0);
                 int32_t        qc, dqc;
-                if (q.simple && (uint32_t)(row[c] + 32767) <= 65534u)
-                    quant_small(q, row[c], rc != 0, qc, dqc);
+                if (all1)
+                    quant_small<true>(q, row[c], ac, qc, dqc);
+                else if (all2)
+                    quant_small<false>(q, row[c], ac, qc, dqc);
                 else
                     quant_one(q, row[c], rc, qc, dqc);
-                if (qc) {
-                    const uint32_t pos = (uint32_t)(uint16_t)iscan[rc] + 1u;
-                    eob                = pos > eob ? pos : eob;
-                }
+                const uint32_t pos = qc ? (uint32_t)(uint16_t)iscan[rc] + 1u : 0u;
+                eob                = pos > eob ? pos : eob;
                 lds[t * PW + c] = qc;  // staged for the coalesced store below
                 row[c]          = dqc;
             }
@@ -456,8 +460,11 @@ __global__ __launch_bounds__(256) void quantize_kernel(uint8_t *__restrict__ bas
     uint32_t       eob = 0;
     for (uint32_t rc = threadIdx.x; rc < n_coeffs; rc += 256) {
         int32_t qc, dqc;
-        if (q.simple && (uint32_t)(ci[rc] + 32767) <= 65534u)
-            quant_small(q, ci[rc], rc != 0, qc, dqc);
+        const bool small = q.simple && (uint32_t)(ci[rc] + 32767) <= 65534u;
+        if (small && (q.mode == SVT_HIP_QUANT_B || q.mode == SVT_HIP_QUANT_B_HBD))
+            quant_small<true>(q, ci[rc], rc != 0, qc, dqc);
+        else if (small)
+            quant_small<false>(q, ci[rc], rc != 0, qc, dqc);
         else
             quant_one(q, ci[rc], rc, qc, dqc);
         if (qc) {

@@ -55,7 +55,14 @@ TXD_FN int32_t sub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uin
 TXD_FN int32_t rshift64(int64_t v, int bit) { return (int32_t)((v + ((int64_t)1 << (bit - 1))) >> bit); }
 TXD_FN int32_t clamp_bits(int32_t v, int bit) {
     const int32_t hi = (int32_t)(((int64_t)1 << (bit - 1)) - 1), lo = -hi - 1;  // bit is 16..20 here
+#if defined(__HIPCC__)
+    // one instruction; the compiler only forms a median-of-three for constant bounds
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+#else
     return v > hi ? hi : (v < lo ? lo : v);
+#endif
 }
 template <bool INV>
 TXD_FN int32_t clampv(int32_t v, int bit) {
