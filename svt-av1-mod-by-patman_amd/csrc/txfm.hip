@@ -248,8 +248,12 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
         if (live && t < W) {
             int32_t        v[H];
             const int16_t *res = (const int16_t *)(base + d.residual_off);
+            {   // FLIPADST columns read the rows bottom-up: walk the pointer, the register index stays constant
+                const ptrdiff_t step = ud ? -(ptrdiff_t)d.residual_stride : (ptrdiff_t)d.residual_stride;
+                const int16_t  *rp   = res + (ud ? (ptrdiff_t)(H - 1) * d.residual_stride : 0) + t;
 #pragma unroll
-            for (int r = 0; r < H; r++) v[r] = (int32_t)((uint32_t)(int32_t)res[(size_t)(ud ? H - 1 - r : r) * d.residual_stride + t] << sh0);
+                for (int r = 0; r < H; r++, rp += step) v[r] = (int32_t)((uint32_t)(int32_t)*rp << sh0);
+            }
             // 24-bit multiplies and 32-bit sums whenever the whole wave's inputs are small enough for them to be exact
             // (the limits leave room for the rounding term of the shift that follows)
             if (__all(max_abs<H>(v) <= (uint32_t)FWD_FAST_LIMIT[G::HI][kind_index(vk)][FWD_COS_COL[G::WI][G::HI] - 10])) {
@@ -428,18 +432,20 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(ui
 #pragma unroll
             for (int r = 0; r < H; r++) v[r] = rshift64(v[r], 4);
         }
+        // FLIPADST columns: output row r of the network is picture row H-1-r — flip the addresses, not the register index
+        // (a run-time register index costs a 16-way select per element)
+        const ptrdiff_t r0 = ud ? H - 1 : 0, ps = ud ? -(ptrdiff_t)d.pred_stride : (ptrdiff_t)d.pred_stride,
+                        rs = ud ? -(ptrdiff_t)d.recon_stride : (ptrdiff_t)d.recon_stride;
         if (d.flags & SVT_HIP_TX_PIXEL16) {
-            const uint16_t *pr = (const uint16_t *)(base + d.pred_off);
-            uint16_t       *rc = (uint16_t *)(base + d.recon_off);
+            const uint16_t *pr = (const uint16_t *)(base + d.pred_off) + r0 * (ptrdiff_t)d.pred_stride + t;
+            uint16_t       *rc = (uint16_t *)(base + d.recon_off) + r0 * (ptrdiff_t)d.recon_stride + t;
 #pragma unroll
-            for (int r = 0; r < H; r++)
-                rc[(size_t)r * d.recon_stride + t] = clip_pixel_add(pr[(size_t)r * d.pred_stride + t], v[ud ? H - 1 - r : r], bd);
+            for (int r = 0; r < H; r++, pr += ps, rc += rs) *rc = clip_pixel_add(*pr, v[r], bd);
         } else {
-            const uint8_t *pr = base + d.pred_off;
-            uint8_t       *rc = base + d.recon_off;
+            const uint8_t *pr = base + d.pred_off + r0 * (ptrdiff_t)d.pred_stride + t;
+            uint8_t       *rc = base + d.recon_off + r0 * (ptrdiff_t)d.recon_stride + t;
 #pragma unroll
-            for (int r = 0; r < H; r++)
-                rc[(size_t)r * d.recon_stride + t] = (uint8_t)clip_pixel_add(pr[(size_t)r * d.pred_stride + t], v[ud ? H - 1 - r : r], 8);
+            for (int r = 0; r < H; r++, pr += ps, rc += rs) *rc = (uint8_t)clip_pixel_add(*pr, v[r], 8);
         }
     }
 }
@@ -520,16 +526,14 @@ __global__ __launch_bounds__(256) void handle64_kernel(int32_t *__restrict__ co,
 std::once_flag g_tables_once;
 int32_t        g_tables_rc = SVT_HIP_OK;
 void           upload_tables() {
-    int32_t cosv[4][64];
+    // the twiddles are compile-time constants (txfm_device.hpp); check the constexpr cosine against libm once
+    constexpr CosTable tab = make_cospi();
     for (int b = 0; b < 4; b++)
-        for (int j = 0; j < 64; j++) cosv[b][j] = (int32_t)llround(cos(M_PI * j / 128.0) * (double)(1 << (10 + b)));
-    // AV1 sinpi constants (inv_transforms.c:3226-3234), bits 10..13
-    const int32_t sinv[4][5] = {{0, 330, 621, 836, 951}, {0, 660, 1241, 1672, 1901}, {0, 1321, 2482, 3344, 3803}, {0, 2642, 4964, 6689, 7606}};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(d_cospi), cosv, sizeof(cosv)) != hipSuccess ||
-        hipMemcpyToSymbol(HIP_SYMBOL(d_sinpi), sinv, sizeof(sinv)) != hipSuccess) {
-        set_error("uploading transform constant tables failed");
-        g_tables_rc = SVT_HIP_ERR_RUNTIME;
-    }
+        for (int j = 0; j < 64; j++)
+            if (tab.v[b][j] != (int32_t)llround(cos(M_PI * j / 128.0) * (double)(1 << (10 + b)))) {
+                set_error("transform constant table self-check failed");
+                g_tables_rc = SVT_HIP_ERR_RUNTIME;
+            }
 }
 int32_t txfm_ready() {
     if (!ensure_init())

@@ -24,16 +24,41 @@
 namespace svthip {
 namespace txd {
 
+// Twiddle tables as compile-time constants: cospi[b][j] = round(cos(pi * j / 128) * 2^(10 + b)) (inv_transforms.c:3150-3224)
+// and the sinpi constants of the 4-point ADST (inv_transforms.c:3226-3234), bits 10..13.  After inlining every table index
+// is a constant expression, so each twiddle becomes an instruction literal instead of a scalar load the wave waits for.
+constexpr double cx_cos(double x) {  // Taylor series, x in [0, pi/2]: error below 1e-15
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k <= 16; k++) {
+        term *= -(x * x) / (double)((2 * k - 1) * (2 * k));
+        sum += term;
+    }
+    return sum;
+}
+struct CosTable {
+    int32_t v[4][64];
+};
+constexpr CosTable make_cospi() {
+    CosTable t{};
+    for (int b = 0; b < 4; b++)
+        for (int j = 0; j < 64; j++) t.v[b][j] = (int32_t)(cx_cos(3.14159265358979323846 * j / 128.0) * (double)(1 << (10 + b)) + 0.5);
+    return t;
+}
+struct SinTable {
+    int32_t v[4][5];
+};
 #if defined(__HIPCC__)
-__constant__ int32_t d_cospi[4][64];  // bits 10..13; uploaded by txfm_init_tables()
-__constant__ int32_t d_sinpi[4][5];
+#define TXD_CONST __device__ constexpr
 #else
-static int32_t d_cospi[4][64];
-static int32_t d_sinpi[4][5];
+#define TXD_CONST constexpr
 #endif
+TXD_CONST CosTable COSPI = make_cospi();
+TXD_CONST SinTable SINPI = {{{0, 330, 621, 836, 951}, {0, 660, 1241, 1672, 1901}, {0, 1321, 2482, 3344, 3803}, {0, 2642, 4964, 6689, 7606}}};
+static_assert(make_cospi().v[2][32] == 2896 && make_cospi().v[3][32] == 5793 && make_cospi().v[0][0] == 1024 && make_cospi().v[3][63] == 201,
+              "cospi table");
 
 struct Rot {
-    const int32_t *c;  // d_cospi[bit-10]
+    const int32_t *c;  // COSPI.v[bit - 10]
     int            bit;
     int            clamp;  // inverse only: clamp bits for additions (0 = none)
 };
@@ -277,7 +302,7 @@ TXD_FN void idct(typename A::T (&v)[N], const Rot &r) {
 template <class A>
 TXD_FN void fadst4(typename A::T (&v)[4], int bit) {
     using T = typename A::T;
-    const int32_t *s = d_sinpi[bit - 10];
+    const int32_t *s = SINPI.v[bit - 10];
     const T        x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
     if (A::all_zero4(x0, x1, x2, x3))
         return;  // all zero stays all zero
@@ -293,7 +318,7 @@ TXD_FN void fadst4(typename A::T (&v)[4], int bit) {
 template <class A>
 TXD_FN void iadst4(typename A::T (&v)[4], int bit) {
     using T = typename A::T;
-    const int32_t *s = d_sinpi[bit - 10];
+    const int32_t *s = SINPI.v[bit - 10];
     const T        x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
     if (A::all_zero4(x0, x1, x2, x3))
         return;
@@ -435,7 +460,7 @@ TXD_FN void identity(typename A::T (&v)[N]) {
 // kind: 0 DCT, 1 ADST (also FLIPADST: the flip is applied by the caller), 3 identity
 template <class A, int N>
 TXD_FN void fwd1d(typename A::T (&v)[N], int kind, int bit) {
-    const Rot r{d_cospi[bit - 10], bit, 0};
+    const Rot r{COSPI.v[bit - 10], bit, 0};
     if (kind == 0) {
         fdct<A, N>(v, r);
     } else if (kind == 3) {
@@ -447,7 +472,7 @@ TXD_FN void fwd1d(typename A::T (&v)[N], int kind, int bit) {
 }
 template <class A, int N>
 TXD_FN void inv1d(typename A::T (&v)[N], int kind, int clamp) {
-    const Rot r{d_cospi[2], 12, clamp};
+    const Rot r{COSPI.v[2], 12, clamp};
     if (kind == 0) {
         idct<A, N>(v, r);
     } else if (kind == 3) {

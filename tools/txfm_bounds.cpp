@@ -139,12 +139,6 @@ void inv_rows(int bd, int pass) {
 }  // namespace
 
 int main() {
-    for (int b = 0; b < 4; b++)
-        for (int j = 0; j < 64; j++) d_cospi[b][j] = (int32_t)llround(cos(M_PI * j / 128.0) * (double)(1 << (10 + b)));
-    static const int32_t sinv[4][5] = {{0, 330, 621, 836, 951}, {0, 660, 1241, 1672, 1901}, {0, 1321, 2482, 3344, 3803}, {0, 2642, 4964, 6689, 7606}};
-    for (int b = 0; b < 4; b++)
-        for (int j = 0; j < 5; j++) d_sinpi[b][j] = sinv[b][j];
-
     printf("// BEGIN GENERATED (tools/txfm_bounds.cpp)\n");
     printf("// largest input magnitude for which Fast == Exact: [log2(N) - 2][kind: DCT, ADST, identity][cos bit - 10]\n");
     printf("TXD_TABLE int32_t FWD_FAST_LIMIT[5][3][4] = {\n");
