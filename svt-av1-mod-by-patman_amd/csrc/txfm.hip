@@ -44,8 +44,9 @@ template <int W, int H>
 struct Geo {
     static constexpr int L  = cmax(W, H);
     static constexpr int PW = W + 1;
-    static constexpr int NT = cmin(256 / L, pow2floor(cmax(1, 12288 / (H * PW))));
+    static constexpr int NT = cmax(1, 64 / L);  // one wave per workgroup: its barriers cost nothing and waves never wait for each other
     static constexpr int IW = cmin(W, 32), IH = cmin(H, 32);
+    static constexpr int MINW = 1;  // waves per SIMD the register allocation aims for (6 for the 16-wide kernels spills: 1.74 vs 2.02 TB/s)
     static constexpr int WI = clog2(W) - 2, HI = clog2(H) - 2;
     static constexpr bool RECT = (W == 2 * H) || (H == 2 * W);
 };
@@ -221,7 +222,7 @@ __device__ __forceinline__ void coop_store_tile(const int32_t *__restrict__ lds,
 }
 
 template <int W, int H>
-__global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L)) void txfm_kernel(uint8_t *__restrict__ base,
+__global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) void txfm_kernel(uint8_t *__restrict__ base,
                                                                             const SvtHipTxfmDesc *__restrict__ descs,
                                                                             SvtHipTxfmResult *__restrict__ results,
                                                                             uint32_t n) {
