@@ -85,6 +85,16 @@ SVT_HIP_API void svt_av1_quantize_fp_qm_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr
 SVT_HIP_API void svt_av1_highbd_quantize_fp_hip(SVT_HIP_QARGS, int16_t log_scale);
 SVT_HIP_API void svt_av1_highbd_quantize_fp_qm_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
 
+/* Residual producer and transform-domain cost of the TPL dispenser / mode decision: svt_aom_subtract_block,
+ * svt_aom_highbd_subtract_block (common_dsp_rtcd.h:234-237; src8 / pred8 of the highbd form are uint16 planes) and
+ * svt_aom_satd (aom_dsp_rtcd.h:206-207). */
+SVT_HIP_API void svt_aom_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr,
+                                            ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride);
+SVT_HIP_API void svt_aom_highbd_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride,
+                                                   const uint8_t *src_ptr, ptrdiff_t src_stride, const uint8_t *pred_ptr,
+                                                   ptrdiff_t pred_stride, int bd);
+SVT_HIP_API int svt_aom_satd_hip(const int32_t *coeff, int length);
+
 /* ---------------------------------------------------------------------------------------------
  * Tier B — batched, fused transform block processing on device-resident data:
  *   residual --fwd txfm--> coeff --[64-pt: energy + repack]--> quantize --> qcoeff/dqcoeff/eob
@@ -105,7 +115,17 @@ enum { /* SvtHipTxfmDesc::flags */
     SVT_HIP_TX_FWD     = 1, /* run the forward transform from `residual_off` */
     SVT_HIP_TX_INV     = 2, /* run the inverse transform + add (needs dqcoeff: computed here or read from dqcoeff_off) */
     SVT_HIP_TX_PIXEL16 = 4, /* pred / recon are uint16 planes (else uint8, bit_depth must be 8) */
-    SVT_HIP_TX_FULLCOEFF = 8 /* coeff_off receives the complete [h][w] array even for 64-point sizes (no repack) */
+    SVT_HIP_TX_FULLCOEFF = 8, /* coeff_off receives the complete [h][w] array even for 64-point sizes (no repack) */
+    /* The residual is formed on the fly, svt_aom_subtract_block / svt_aom_highbd_subtract_block semantics
+     * (inter_prediction.c:35-60): residual_off / residual_stride address the SOURCE pixels, pred_off / pred_stride the
+     * prediction (uint8, or uint16 with SVT_HIP_TX_PIXEL16); strides in pixels. */
+    SVT_HIP_TX_SRC_PRED = 16,
+    /* result.satd = svt_aom_satd (common_dsp_rtcd.c:71-78) over the retained coefficients of the forward transform.
+     * FWD | SRC_PRED | SATD with DCT_DCT is the TPL dispenser's block cost (src_ops_process.c:734-748, 861-873): pass the
+     * sub-sampled transform size as w x h and the strides pre-shifted by subsample_tx exactly as the reference does, and
+     * shift the result left by subsample_tx.  (For sizes with a 64-point side the retained 32x32 block is summed once;
+     * the reference's length = 64*64 walk also re-reads the stale rows 16..31 of the un-repacked array.) */
+    SVT_HIP_TX_SATD = 32
 };
 
 typedef struct SvtHipTxfmDesc {
@@ -125,7 +145,8 @@ typedef struct SvtHipTxfmDesc {
 typedef struct SvtHipTxfmResult {
     uint64_t three_quad_energy; /* svt_handle_transformWxH return value (0 for sizes without a 64-point side) */
     uint16_t eob;
-    uint16_t pad_[3];
+    uint16_t pad_;
+    uint32_t satd; /* SVT_HIP_TX_SATD, else 0 */
 } SvtHipTxfmResult;
 
 SVT_HIP_API int32_t svt_hip_txfm_quant_batch(uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,

@@ -30,6 +30,14 @@ ORC_API void orc_quantize_fp(const int32_t *coeff, intptr_t n, const int16_t *ro
 ORC_API void orc_highbd_quantize_fp(const int32_t *coeff, intptr_t n, const int16_t *round, const int16_t *quant,
                                     int32_t *qcoeff, int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob_ptr,
                                     const int16_t *scan, const uint8_t *qm, const uint8_t *iqm, int log_scale);
+/* orc_residual.c */
+ORC_API void orc_subtract_block(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const uint8_t *src, ptrdiff_t src_stride,
+                                const uint8_t *pred, ptrdiff_t pred_stride);
+ORC_API void orc_highbd_subtract_block(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const uint16_t *src,
+                                       ptrdiff_t src_stride, const uint16_t *pred, ptrdiff_t pred_stride);
+ORC_API int     orc_satd(const int32_t *coeff, int length);
+ORC_API int64_t orc_tpl_block_cost(const uint8_t *src, int src_stride, const uint8_t *pred, int pred_stride, int size,
+                                   int subsample_tx, int pf_shape);
 #ifdef __cplusplus
 }
 #endif

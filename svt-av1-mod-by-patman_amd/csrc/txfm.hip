@@ -183,6 +183,12 @@ __device__ __forceinline__ uint32_t group_max(uint32_t v) {
     return v;
 }
 template <int L>
+__device__ __forceinline__ uint32_t group_sum32(uint32_t v) {
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int L>
 __device__ __forceinline__ uint64_t group_sum64(uint64_t v) {
 #pragma unroll
     for (int off = L / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -248,12 +254,28 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) 
     if (do_fwd) {
         if (live && t < W) {
             int32_t        v[H];
-            const int16_t *res = (const int16_t *)(base + d.residual_off);
-            {   // FLIPADST columns read the rows bottom-up: walk the pointer, the register index stays constant
+            {   // FLIPADST columns read the rows bottom-up: walk the pointers, the register index stays constant
                 const ptrdiff_t step = ud ? -(ptrdiff_t)d.residual_stride : (ptrdiff_t)d.residual_stride;
-                const int16_t  *rp   = res + (ud ? (ptrdiff_t)(H - 1) * d.residual_stride : 0) + t;
+                const ptrdiff_t row0 = (ud ? (ptrdiff_t)(H - 1) * d.residual_stride : 0) + t;
+                if (!(d.flags & SVT_HIP_TX_SRC_PRED)) {
+                    const int16_t *rp = (const int16_t *)(base + d.residual_off) + row0;
 #pragma unroll
-                for (int r = 0; r < H; r++, rp += step) v[r] = (int32_t)((uint32_t)(int32_t)*rp << sh0);
+                    for (int r = 0; r < H; r++, rp += step) v[r] = (int32_t)((uint32_t)(int32_t)*rp << sh0);
+                } else {  // residual = source - prediction (svt_aom_[highbd_]subtract_block), never materialised
+                    const ptrdiff_t pstep = ud ? -(ptrdiff_t)d.pred_stride : (ptrdiff_t)d.pred_stride;
+                    const ptrdiff_t prow0 = (ud ? (ptrdiff_t)(H - 1) * d.pred_stride : 0) + t;
+                    if (d.flags & SVT_HIP_TX_PIXEL16) {
+                        const uint16_t *sp = (const uint16_t *)(base + d.residual_off) + row0;
+                        const uint16_t *pp = (const uint16_t *)(base + d.pred_off) + prow0;
+#pragma unroll
+                        for (int r = 0; r < H; r++, sp += step, pp += pstep)
+                            v[r] = (int32_t)((uint32_t)(int32_t)(int16_t)(*sp - *pp) << sh0);
+                    } else {
+                        const uint8_t *sp = base + d.residual_off + row0, *pp = base + d.pred_off + prow0;
+#pragma unroll
+                        for (int r = 0; r < H; r++, sp += step, pp += pstep) v[r] = (int32_t)((uint32_t)((int32_t)*sp - (int32_t)*pp) << sh0);
+                    }
+                }
             }
             // 24-bit multiplies and 32-bit sums whenever the whole wave's inputs are small enough for them to be exact
             // (the limits leave room for the rounding term of the shift that follows)
@@ -312,6 +334,15 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) 
                     energy += (uint64_t)((int64_t)row[c] * (int64_t)row[c]);
         }
         energy = group_sum64<L>(energy);
+    }
+    // ---------------------------------------------------------------------- transform-domain cost (svt_aom_satd)
+    uint32_t satd = 0;
+    if (do_fwd && (d.flags & SVT_HIP_TX_SATD)) {
+        if (live && t < IH) {
+#pragma unroll
+            for (int c = 0; c < IW; c++) satd += (uint32_t)(row[c] < 0 ? -row[c] : row[c]);
+        }
+        satd = group_sum32<L>(satd);
     }
     // ---------------------------------------------------------------------- coefficients out / quantise
     uint32_t eob = 0;
@@ -380,7 +411,7 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) 
         SvtHipTxfmResult r;
         r.three_quad_energy = energy;
         r.eob               = (uint16_t)eob;
-        r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+        r.pad_ = 0, r.satd = satd;
         results[tb]                       = r;
     }
     // ---------------------------------------------------------------------- inverse: rows
@@ -486,7 +517,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(uint8_t *__restrict__ bas
     __syncthreads();
     if (threadIdx.x == 0) {
         SvtHipTxfmResult r;
-        r.three_quad_energy = 0, r.eob = (uint16_t)s_eob, r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+        r.three_quad_energy = 0, r.eob = (uint16_t)s_eob, r.pad_ = 0, r.satd = 0;
         results[blockIdx.x] = r;
     }
 }

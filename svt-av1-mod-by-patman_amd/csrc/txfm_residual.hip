@@ -1,0 +1,110 @@
+// txfm_residual.hip — the per-call (Tier A) forms of the residual producer and the transform-domain cost that sit either
+// side of the forward transform in the TPL dispenser and in mode decision:
+//   svt_aom_subtract_block / svt_aom_highbd_subtract_block   (reference: inter_prediction.c:35-60)
+//   svt_aom_satd                                              (reference: common_dsp_rtcd.c:71-78)
+// Host pointers in, host pointers out, ABI of the reference's RTCD slots (common_dsp_rtcd.h:234-237, aom_dsp_rtcd.h:206-207).
+// The batched path never calls these: txfm_kernel forms the residual from source and prediction itself
+// (SVT_HIP_TX_SRC_PRED) and returns the cost in its result record (SVT_HIP_TX_SATD).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/svt_hip_txfm.h"
+#include "common.hpp"
+
+using namespace svthip;
+
+namespace {
+
+// diff[r][c] = src[r][c] - pred[r][c], stored as int16 (wraps like the reference's assignment)
+template <class PIX>
+__global__ __launch_bounds__(256) void subtract_kernel(int rows, int cols, int16_t *__restrict__ diff, int diff_stride,
+                                                       const PIX *__restrict__ src, int src_stride, const PIX *__restrict__ pred,
+                                                       int pred_stride) {
+    const int n = rows * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = i / cols, c = i - r * cols;
+        diff[(size_t)r * diff_stride + c] = (int16_t)((int)src[(size_t)r * src_stride + c] - (int)pred[(size_t)r * pred_stride + c]);
+    }
+}
+
+// sum of |coeff[i]| in int arithmetic (wraps like the reference's int accumulator)
+__global__ __launch_bounds__(256) void satd_kernel(const int32_t *__restrict__ coeff, int length, int32_t *__restrict__ out) {
+    __shared__ uint32_t part[4];
+    uint32_t            acc = 0;
+    for (int i = threadIdx.x; i < length; i += 256) {
+        const int32_t v = coeff[i];
+        acc += (uint32_t)(v < 0 ? 0u - (uint32_t)v : (uint32_t)v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *out = (int32_t)(part[0] + part[1] + part[2] + part[3]);
+}
+
+void fatal(const char *what) {
+    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
+    abort();
+}
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+template <class PIX>
+void subtract_tier_a(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const PIX *src, ptrdiff_t src_stride, const PIX *pred,
+                     ptrdiff_t pred_stride) {
+    if (rows <= 0 || cols <= 0)
+        return;
+    if (!ensure_init())
+        fatal("subtract_block");
+    // dense staging: rows x cols of each operand
+    const size_t pix = (size_t)rows * cols, pb = up256(pix * sizeof(PIX)), db = up256(pix * 2);
+    Scratch     &sc  = tls_scratch();
+    uint8_t     *h = sc.host(2 * pb + db), *d = sc.device(2 * pb + db);
+    for (int r = 0; r < rows; r++) {
+        memcpy(h + (size_t)r * cols * sizeof(PIX), src + (ptrdiff_t)r * src_stride, (size_t)cols * sizeof(PIX));
+        memcpy(h + pb + (size_t)r * cols * sizeof(PIX), pred + (ptrdiff_t)r * pred_stride, (size_t)cols * sizeof(PIX));
+    }
+    hipStream_t st = resolve_stream(nullptr);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, h, 2 * pb, hipMemcpyHostToDevice, st));
+    const int blocks = (int)((pix + 255) / 256);
+    hipLaunchKernelGGL((subtract_kernel<PIX>), dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, rows, cols, (int16_t *)(d + 2 * pb),
+                       cols, (const PIX *)d, cols, (const PIX *)(d + pb), cols);
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + 2 * pb, d + 2 * pb, pix * 2, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    for (int r = 0; r < rows; r++) memcpy(diff + (ptrdiff_t)r * diff_stride, h + 2 * pb + (size_t)r * cols * 2, (size_t)cols * 2);
+}
+
+}  // namespace
+
+extern "C" void svt_aom_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr,
+                                           ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride) {
+    subtract_tier_a<uint8_t>(rows, cols, diff_ptr, diff_stride, src_ptr, src_stride, pred_ptr, pred_stride);
+}
+extern "C" void svt_aom_highbd_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr,
+                                                  ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride, int bd) {
+    (void)bd;
+    subtract_tier_a<uint16_t>(rows, cols, diff_ptr, diff_stride, (const uint16_t *)src_ptr, src_stride, (const uint16_t *)pred_ptr,
+                              pred_stride);
+}
+extern "C" int svt_aom_satd_hip(const int32_t *coeff, int length) {
+    if (length <= 0)
+        return 0;
+    if (!ensure_init())
+        fatal("satd");
+    const size_t cb = up256((size_t)length * 4);
+    Scratch     &sc = tls_scratch();
+    uint8_t     *h = sc.host(cb + 256), *d = sc.device(cb + 256);
+    memcpy(h, coeff, (size_t)length * 4);
+    hipStream_t st = resolve_stream(nullptr);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, h, (size_t)length * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(satd_kernel, dim3(1), dim3(256), 0, st, (const int32_t *)d, length, (int32_t *)(d + cb));
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + cb, d + cb, 4, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    return *(const int32_t *)(h + cb);
+}

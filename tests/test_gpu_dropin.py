@@ -202,3 +202,17 @@ def test_sgr_search_with_hip_leaves(dropin, ref):
     dropin.restore()
     for a, b in zip(*got):
         assert np.array_equal(a, b)
+
+
+def test_tpl_block_cost_with_hip_leaves(dropin, ref):
+    """The TPL dispenser's transform-domain cost (src_ops_process.c:734-748): svt_aom_subtract_block ->
+    svt_av1_wht_fwd_txfm (the reference's own dispatcher, which lands in the forward-transform pointers) -> svt_aom_satd,
+    first with the C leaves, then with the HIP ones installed."""
+    import test_residual_oracle as TR
+    got = []
+    for phase in ("c", "hip"):
+        if phase == "hip":
+            dropin.install()
+        got.append([TR.ref_tpl_cost(ref, *c) for c in TR.tpl_cases()])
+    dropin.restore()
+    assert len(got[0]) == 54 and got[0] == got[1]

@@ -57,6 +57,30 @@ def test_tier_a_fwd_inv(hip, orc, w, h):
             assert e1 == e2 and np.array_equal(co[:kw * kh], c2[:kw * kh])
 
 
+@pytest.mark.parametrize("w,h", [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 32), (64, 16)])
+def test_tier_a_fast_path_thresholds(hip, orc, w, h):
+    """The forward kernels switch to 24-bit multiplies when the largest input magnitude of a wave is below a proven limit
+    (txfm_device.hpp, FWD_FAST_LIMIT).  Sweep the residual magnitude across every such limit, with the sign patterns that
+    maximise the intermediate values, so that both arithmetic paths and their hand-over are compared with the oracle."""
+    rng = np.random.default_rng(4242 + w * 64 + h)
+    for tt in (0, 1, 4, 9, 10, 11):   # DCT_DCT, ADST_DCT, FLIPADST_DCT, IDTX, V_DCT, H_DCT
+        if not orc.orc_txfm_valid(w, h, tt):
+            continue
+        for mag in (60, 250, 700, 1023, 1500, 2300, 4100, 4200, 6000, 9000, 14000, 23000, 32767):
+            for pat in range(3):
+                if pat == 0:
+                    res = rng.integers(-mag, mag + 1, size=(h, w + 3))
+                elif pat == 1:
+                    res = np.full((h, w + 3), mag)
+                else:
+                    res = (rng.integers(0, 2, size=(h, w + 3)) * 2 - 1) * mag
+                res = res.astype(np.int16)
+                o1, o2 = np.zeros(w * h, np.int32), np.full(w * h, 5, np.int32)
+                orc.orc_fwd_txfm2d(P(res), P(o1), C.c_uint32(w + 3), w, h, tt, 10, 0)
+                getattr(hip, f"svt_av1_fwd_txfm2d_{w}x{h}_hip")(P(res), P(o2), C.c_uint32(w + 3), tt, C.c_uint8(10))
+                assert np.array_equal(o1, o2), (w, h, tt, mag, pat)
+
+
 def test_tier_a_golden(hip):
     """HIP == committed outputs of the reference's own transform functions."""
     import test_txfm_oracle as TT

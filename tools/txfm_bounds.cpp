@@ -103,6 +103,76 @@ bool inv_ok(int kind, double in_abs, int clamp) {
     return g_ok;
 }
 
+// ---- self test: the Fast arithmetic emulated on the host (24-bit sign-extended multiplies, wrapping 32-bit sums) must
+// agree with Exact for inputs up to the derived limits, and the inverse wherever INV_FAST_OK says so
+int32_t sx24(int32_t v) { return (int32_t)((uint32_t)v << 8) >> 8; }
+int32_t mul24e(int32_t a, int32_t b) { return (int32_t)((uint32_t)sx24(a) * (uint32_t)sx24(b)); }
+struct FastEmu {
+    using T = int32_t;
+    static T add(T a, T b) { return add32(a, b); }
+    static T sub(T a, T b) { return sub32(a, b); }
+    static T neg(T a) { return (int32_t)(0u - (uint32_t)a); }
+    static T mul(int32_t w, T a) { return mul24e(w, a); }
+    static T btf(int32_t w0, T a, int32_t w1, T b, int bit) {
+        return (int32_t)((uint32_t)mul24e(w0, a) + (uint32_t)mul24e(w1, b) + (1u << (bit - 1))) >> bit;
+    }
+    static T rs(T v, int bit) { return (int32_t)((uint32_t)v + (1u << (bit - 1))) >> bit; }
+    static T scale(T v, int32_t k, int bit) { return (int32_t)((uint32_t)mul24e(v, k) + (1u << (bit - 1))) >> bit; }
+    static T times(T v, int32_t k) { return mul24e(v, k); }
+    template <bool INV> static T clamp(T v, int bit) { return clampv<INV>(v, bit); }
+    static bool all_zero4(T a, T b, T c, T d) { return !(a | b | c | d); }
+};
+uint64_t g_rng = 88172645463325252ull;
+uint32_t rnd() {
+    g_rng ^= g_rng << 13, g_rng ^= g_rng >> 7, g_rng ^= g_rng << 17;
+    return (uint32_t)(g_rng >> 11);
+}
+template <int N>
+int selftest_n() {
+    static const int kinds[3] = {0, 1, 3};
+    int              bad = 0;
+    for (int k = 0; k < 3; k++) {
+        if (kinds[k] == 1 && N > 16)
+            continue;
+        for (int bit = 10; bit <= 13; bit++) {
+            const int32_t lim = (int32_t)std::min(fwd_limit<N>(kinds[k], bit), 2147483647.0);
+            for (int trial = 0; trial < 600; trial++) {
+                int32_t a[N], b[N];
+                for (int i = 0; i < N; i++) {
+                    const int32_t mag = trial % 3 == 0 ? lim : (int32_t)(rnd() % ((uint32_t)lim + 1u));
+                    a[i] = b[i] = (rnd() & 1) ? mag : -mag;
+                }
+                if (trial % 7 == 1)
+                    for (int i = 0; i < N; i++) a[i] = b[i] = (i & 1) ? -lim : lim;
+                if (trial % 7 == 2)
+                    for (int i = 0; i < N; i++) a[i] = b[i] = lim;
+                fwd1d<Exact, N>(a, kinds[k], bit);
+                fwd1d<FastEmu, N>(b, kinds[k], bit);
+                for (int i = 0; i < N; i++) bad += a[i] != b[i];
+            }
+        }
+        for (int bi = 0; bi < 3; bi++)
+            for (int pass = 0; pass < 2; pass++) {
+                const int bd = 8 + 2 * bi, in_bits = pass == 0 ? bd + 8 : std::max(bd + 6, 16);
+                const int clamp = pass == 0 ? (bd == 8 ? 16 : (bd == 10 ? 18 : 20)) : (bd == 12 ? 18 : 16);
+                if (!inv_ok<N>(kinds[k], ldexp(1.0, in_bits - 1), clamp))
+                    continue;
+                const int32_t hi = (1 << (in_bits - 1)) - 1;
+                for (int trial = 0; trial < 600; trial++) {
+                    int32_t a[N], b[N];
+                    for (int i = 0; i < N; i++) {
+                        const int32_t mag = trial % 3 == 0 ? hi : (int32_t)(rnd() % ((uint32_t)hi + 1u));
+                        a[i] = b[i] = (rnd() & 1) ? mag : -mag - 1;
+                    }
+                    inv1d<Exact, N>(a, kinds[k], clamp);
+                    inv1d<FastEmu, N>(b, kinds[k], clamp);
+                    for (int i = 0; i < N; i++) bad += a[i] != b[i];
+                }
+            }
+    }
+    return bad;
+}
+
 template <int N>
 void fwd_rows(const char *name) {
     static const int kinds[3] = {0, 1, 3};
@@ -138,7 +208,12 @@ void inv_rows(int bd, int pass) {
 
 }  // namespace
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-' && argv[1][2] == 's') {  // --selftest
+        const int bad = selftest_n<4>() + selftest_n<8>() + selftest_n<16>() + selftest_n<32>() + selftest_n<64>();
+        printf("selftest mismatches: %d\n", bad);
+        return bad != 0;
+    }
     printf("// BEGIN GENERATED (tools/txfm_bounds.cpp)\n");
     printf("// largest input magnitude for which Fast == Exact: [log2(N) - 2][kind: DCT, ADST, identity][cos bit - 10]\n");
     printf("TXD_TABLE int32_t FWD_FAST_LIMIT[5][3][4] = {\n");
