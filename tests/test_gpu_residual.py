@@ -61,11 +61,10 @@ def blank_desc():
 def test_tier_b_tpl_block_cost(hip, orc, size, ss):
     """One launch = the transform-domain cost of many TPL blocks: flags FWD | SRC_PRED | SATD, DCT_DCT, the sub-sampled
     transform size as w x h and the strides pre-shifted as the reference's call does."""
-    cases = [c for c in tpl_cases() if c[0] == size and c[1] == ss] * 9   # 81 blocks
+    cases = [(k, c) for k, c in enumerate(tpl_cases()) if c[0] == size and c[1] == ss] * 9   # 81 blocks
     gold = np.load(GOLD)["tpl_cost"]
-    all_cases = list(tpl_cases())
     ab, descs = ArenaBuilder(), []
-    for (_, _, pf, src, pred) in cases:
+    for _, (_, _, pf, src, pred) in cases:
         d = blank_desc()
         d.residual_off, d.residual_stride = ab.add(src), src.shape[1] << ss
         d.pred_off, d.pred_stride = ab.add(pred), pred.shape[1] << ss
@@ -73,10 +72,9 @@ def test_tier_b_tpl_block_cost(hip, orc, size, ss):
         d.flags = abi.TX_FWD | abi.TX_SRC_PRED | abi.TX_SATD
         descs.append(d)
     _, res = run_batch(hip, ab, descs, size, size >> ss)
-    for i, (_, _, pf, src, pred) in enumerate(cases):
+    for i, (k, (_, _, pf, src, pred)) in enumerate(cases):
         got = int(res[i, 12:16].view(np.uint32)[0]) << ss
         assert got == orc_tpl_cost(orc, size, ss, pf, src, pred), (size, ss, pf, i)
-        k = next(j for j, c in enumerate(all_cases) if c[0] == size and c[1] == ss and c[2] == pf and c[3] is src)
         assert got == int(gold[k])
 
 
