@@ -342,6 +342,48 @@ def bench_txfm(lib, dev, args, world, rank):
         alg = 14.0 * w * h * nblk
         per_size[f"{w}x{h}"] = {"blocks": nblk, "launch_ms": round(ms, 4), "GBps": round(alg / (ms * 1e-3) / 1e9, 1)}
         total_ms += ms
+    # the TPL dispenser's block cost on the same kernel (src_ops_process.c:734-748): 8-bit source and prediction in,
+    # residual formed in the kernel, forward DCT_DCT 16x16, SATD out — 2N + 16 algorithmic bytes per block; reported beside
+    # the headline sizes, not part of `value`
+    tpl = None
+    if True:
+        w = h = 16
+        bw, bh = W4 // w, H4 // h
+        nblk = bw * bh
+        off_src, off_prd = 0, W4 * H4
+        arena = torch.zeros(2 * W4 * H4 + 512, dtype=torch.uint8, device=dev)
+        src8 = rng.integers(0, 256, size=(H4, W4), dtype=np.uint8)
+        prd8 = np.clip(src8.astype(np.int16) + rng.integers(-12, 13, size=(H4, W4), dtype=np.int16), 0, 255).astype(np.uint8)
+        arena[off_src:off_src + W4 * H4] = torch.from_numpy(src8).to(dev).reshape(-1)
+        arena[off_prd:off_prd + W4 * H4] = torch.from_numpy(prd8).to(dev).reshape(-1)
+        descs = np.zeros(nblk, dtype=np.dtype(abi.TxfmDesc))
+        i = np.arange(nblk, dtype=np.uint64)
+        pix = (i // bw * h) * W4 + (i % bw) * w
+        for f in ("coeff_off", "qcoeff_off", "dqcoeff_off", "recon_off", "iscan_off", "qm_off", "iqm_off"):
+            descs[f] = abi.NO_OFFSET
+        descs["residual_off"], descs["residual_stride"] = off_src + pix, W4
+        descs["pred_off"], descs["pred_stride"] = off_prd + pix, W4
+        descs["tx_type"], descs["shape"], descs["bit_depth"], descs["quant_mode"] = 0, 0, 8, abi.QUANT_NONE
+        descs["flags"] = abi.TX_FWD | abi.TX_SRC_PRED | abi.TX_SATD
+        d_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
+        d_res = torch.zeros(nblk * 16, dtype=torch.uint8, device=dev)
+
+        def launch_tpl():
+            rc = lib.svt_hip_txfm_quant_batch(C.c_void_p(arena.data_ptr()), C.c_void_p(d_desc.data_ptr()), C.c_void_p(d_res.data_ptr()),
+                                              C.c_uint32(nblk), C.c_uint32(w), C.c_uint32(h), sp)
+            assert rc == 0, lib.svt_hip_last_error().decode()
+        for _ in range(args.warmup):
+            launch_tpl()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in evs:
+            a.record(stream)
+            launch_tpl()
+            b.record(stream)
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        tpl = {"blocks": nblk, "launch_ms": round(ms, 4), "GBps": round((2.0 * w * h + 16) * nblk / (ms * 1e-3) / 1e9, 1),
+               "blocks_per_s": round(nblk / (ms * 1e-3))}
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -356,7 +398,8 @@ def bench_txfm(lib, dev, args, world, rank):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total_ms / 4, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "4K 10-bit fwd/inv txfm2d + quantize (BASELINE.json configs[2]), fused kernel, one block size per launch",
-                       "width": W4, "height": HP, "pictures_per_launch": FR, "per_size": per_size},
+                       "width": W4, "height": HP, "pictures_per_launch": FR, "per_size": per_size,
+                       "tpl_block_cost_16x16_8bit": tpl},
             "roofline": {"bound": "hbm", "kernel": "txfm_kernel<16,16>", "achieved": k16["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(k16["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(14 * 256 * k16["blocks"]), "launch_ms": k16["launch_ms"],
