@@ -75,3 +75,58 @@ void orc_convolve_sr(const void *src, int32_t src_stride, void *dst, int32_t dst
             put(dst, (ptrdiff_t)y * dst_stride + x, is16, RND(res, bits), bd);
         }
 }
+
+/* Compound ("jnt") family: svt_av1_jnt_convolve_{2d,x,y,2d_copy}_c (inter_prediction.c:494-668) and the highbd set
+ * (inter_prediction.c:852-1035).  mode 1: first prediction, the offset intermediate goes to the ConvBufType buffer `cbuf`;
+ * mode 2: second prediction averaged with cbuf (do_average); mode 3: distance-weighted average (use_jnt_comp_avg, weights
+ * fwd / bck, DIST_PRECISION_BITS = 4); the averaged pixel goes to dst. */
+void orc_convolve_jnt(const void *src, int32_t src_stride, void *dst, int32_t dst_stride, int32_t w, int32_t h, const int16_t *fx,
+                      int32_t taps_x, const int16_t *fy, int32_t taps_y, int32_t round_0, int32_t round_1, int32_t bd, int32_t is16,
+                      uint16_t *cbuf, int32_t cbuf_stride, int32_t mode, int32_t fwd, int32_t bck) {
+    static int16_t im[(128 + 7) * 128];
+    const int      offset_bits = bd + 2 * FILTER_BITS - round_0, round_bits = 2 * FILTER_BITS - round_0 - round_1;
+    const int32_t  round_offset = (1 << (offset_bits - round_1)) + (1 << (offset_bits - round_1 - 1));
+    const int      fo_v = taps_y ? taps_y / 2 - 1 : 0, fo_h = taps_x ? taps_x / 2 - 1 : 0;
+    if (taps_x && taps_y) {
+        const int im_h = h + taps_y - 1;
+        for (int y = 0; y < im_h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 1 << (bd + FILTER_BITS - 1);
+                for (int k = 0; k < taps_x; k++) sum += fx[k] * px(src, (ptrdiff_t)(y - fo_v) * src_stride + x - fo_h + k, is16);
+                im[y * w + x] = (int16_t)(uint16_t)RND(sum, round_0);
+            }
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int32_t res;
+            if (taps_x && taps_y) {
+                int32_t sum = 1 << offset_bits;
+                for (int k = 0; k < taps_y; k++) sum += fy[k] * im[(y + k) * w + x];
+                res = (uint16_t)RND(sum, round_1); /* ConvBufType res */
+            } else if (taps_y) {
+                const int bits = FILTER_BITS - round_0;
+                res            = 0;
+                for (int k = 0; k < taps_y; k++) res += fy[k] * px(src, (ptrdiff_t)(y - fo_v + k) * src_stride + x, is16);
+                res *= (1 << bits);
+                res = RND(res, round_1) + round_offset;
+            } else if (taps_x) {
+                const int bits = FILTER_BITS - round_1;
+                res            = 0;
+                for (int k = 0; k < taps_x; k++) res += fx[k] * px(src, (ptrdiff_t)y * src_stride + x - fo_h + k, is16);
+                res = (1 << bits) * RND(res, round_0);
+                res += round_offset;
+            } else {
+                uint16_t r16 = (uint16_t)(px(src, (ptrdiff_t)y * src_stride + x, is16) << round_bits);
+                r16          = (uint16_t)(r16 + (uint16_t)round_offset);
+                res          = r16;
+            }
+            if (mode == 1) {
+                cbuf[(ptrdiff_t)y * cbuf_stride + x] = (uint16_t)res;
+            } else {
+                int32_t tmp = cbuf[(ptrdiff_t)y * cbuf_stride + x];
+                tmp         = mode == 3 ? (tmp * fwd + res * bck) >> 4 : (tmp + res) >> 1;
+                tmp -= round_offset;
+                put(dst, (ptrdiff_t)y * dst_stride + x, is16, RND(tmp, round_bits), bd);
+            }
+        }
+}

@@ -60,6 +60,9 @@ ORC_API void orc_wiener_convolve_add_src(const void *src, int32_t src_stride, vo
 ORC_API void orc_convolve_sr(const void *src, int32_t src_stride, void *dst, int32_t dst_stride, int32_t w, int32_t h,
                              const int16_t *fx, int32_t taps_x, const int16_t *fy, int32_t taps_y, int32_t round_0,
                              int32_t round_1, int32_t bd, int32_t is16);
+ORC_API void orc_convolve_jnt(const void *src, int32_t src_stride, void *dst, int32_t dst_stride, int32_t w, int32_t h, const int16_t *fx,
+                              int32_t taps_x, const int16_t *fy, int32_t taps_y, int32_t round_0, int32_t round_1, int32_t bd,
+                              int32_t is16, uint16_t *cbuf, int32_t cbuf_stride, int32_t mode, int32_t fwd, int32_t bck);
 #ifdef __cplusplus
 }
 #endif
