@@ -239,4 +239,6 @@ class InterpFilterParams(C.Structure):   # SvtHipInterpFilterParams == InterpFil
 class ConvolveDesc(C.Structure):         # SvtHipConvolveDesc (include/svt_hip_inter.h)
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_stride", C.c_uint32), ("dst_stride", C.c_uint32), ("w", C.c_uint16),
                 ("h", C.c_uint16), ("filter_x", C.c_int16 * 8), ("filter_y", C.c_int16 * 8), ("taps_x", C.c_uint8), ("taps_y", C.c_uint8),
-                ("round_0", C.c_uint8), ("round_1", C.c_uint8), ("bit_depth", C.c_uint8), ("is_16bit", C.c_uint8), ("pad_", C.c_uint8 * 6)]
+                ("round_0", C.c_uint8), ("round_1", C.c_uint8), ("bit_depth", C.c_uint8), ("is_16bit", C.c_uint8), ("compound", C.c_uint8),
+                ("fwd_offset", C.c_uint8), ("bck_offset", C.c_uint8), ("pad_", C.c_uint8 * 3), ("cbuf", C.c_void_p),
+                ("cbuf_stride", C.c_uint32), ("pad2_", C.c_uint32)]

@@ -58,3 +58,33 @@ def ref_plane(rng, w, h, bd, is16, kind):
 
 
 SIZES = [(4, 4), (8, 8), (16, 8), (8, 16), (32, 32), (64, 64), (128, 64), (64, 128), (128, 128), (4, 16), (16, 64)]
+
+
+def conv_rounds_compound(bd):
+    """get_conv_params_no_round with is_compound = 1 (convolve.h:39-63)"""
+    r0, r1 = 3, 7
+    rng = bd + 7 - r0 + 2
+    if rng > 16:
+        r0 += rng - 16
+    return r0, r1
+
+
+JNT_MODES = ("2d", "x", "y", "2d_copy")
+# quant_dist_lookup_table weights (fwd, bck) the reference uses for distance-weighted compounds (inter_prediction.c: the
+# pairs sum to 16)
+DIST_WEIGHTS = [(9, 7), (11, 5), (12, 4), (13, 3), (7, 9), (5, 11), (4, 12), (3, 13), (8, 8)]
+
+
+def jnt_cases(bd, is16, n=40, seed=0):
+    """(w, h, mode, table index, sx, sy, plane0, at0, plane1, at1, averaging mode 2|3, fwd, bck)"""
+    rng = np.random.default_rng(7000 + bd + seed)
+    for trial in range(n):
+        w, h = SIZES[trial % len(SIZES)]
+        ti = trial % 3
+        sx, sy = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+        mode = trial % 4
+        p0, a0 = ref_plane(rng, w, h, bd, is16, (0, 2, 1)[trial % 3])
+        p1, a1 = ref_plane(rng, w, h, bd, is16, (2, 0, 1)[trial % 3])
+        avg = 3 if trial % 2 else 2
+        fwd, bck = DIST_WEIGHTS[trial % len(DIST_WEIGHTS)]
+        yield w, h, mode, ti, sx, sy, p0, a0, p1, a1, avg, fwd, bck

@@ -57,3 +57,58 @@ def test_convolve_oracle_vs_golden(orc):
         tx, ty = (8 if mode in (0, 1) else 0), (8 if mode in (0, 2) else 0)
         orc.orc_convolve_sr(V(at), plane.shape[1], P(o), w, w, h, V(tab[sx].ctypes.data), tx, V(tab[sy].ctypes.data), ty, r0, r1, bd, is16)
         assert np.array_equal(o, g[f"c{i}_out"]), i
+
+
+def run_orc_jnt(orc, c, bd, is16):
+    """both predictions of one compound block through the oracle: returns (conv buffer after the first, pixels after the second)"""
+    w, h, mode, ti, sx, sy, p0, a0, p1, a1, avg, fwd, bck = c
+    tab = np.array(K.TABLES[list(K.TABLES)[ti]], np.int16)
+    r0, r1 = K.conv_rounds_compound(bd)
+    tx, ty = (8 if mode in (0, 1) else 0), (8 if mode in (0, 2) else 0)
+    cb = np.zeros((h, w + 5), np.uint16)
+    out = np.zeros((h, w + 3), p0.dtype)
+    orc.orc_convolve_jnt(V(a0), p0.shape[1], P(out), w + 3, w, h, V(tab[sx].ctypes.data), tx, V(tab[sy].ctypes.data), ty, r0, r1, bd, is16,
+                         P(cb), w + 5, 1, 0, 0)
+    first = cb.copy()
+    orc.orc_convolve_jnt(V(a1), p1.shape[1], P(out), w + 3, w, h, V(tab[sy].ctypes.data), tx, V(tab[sx].ctypes.data), ty, r0, r1, bd, is16,
+                         P(cb), w + 5, avg, fwd, bck)
+    return first, out
+
+
+def run_fn_jnt(fns, c, bd, is16, CP, FP):
+    """the same through functions with the reference's signatures (the reference's own, or the HIP Tier A leaves)"""
+    w, h, mode, ti, sx, sy, p0, a0, p1, a1, avg, fwd, bck = c
+    tab = K.kernel_table(list(K.TABLES)[ti])[0]
+    r0, r1 = K.conv_rounds_compound(bd)
+    cb = np.zeros((h, w + 5), np.uint16)
+    out = np.zeros((h, w + 3), p0.dtype)
+    fp = FP(tab.ctypes.data, 8, 16, ti)
+    cp = CP(do_average=0, dst=cb.ctypes.data, dst_stride=w + 5, round_0=r0, round_1=r1, is_compound=1)
+    tail = [bd] if is16 else []
+    fns[mode](*([V(a0), p0.shape[1], P(out), w + 3, w, h, C.byref(fp), C.byref(fp), sx, sy, C.byref(cp)] + tail))
+    first = cb.copy()
+    cp.do_average, cp.use_jnt_comp_avg, cp.fwd_offset, cp.bck_offset = 1, int(avg == 3), fwd, bck
+    fns[mode](*([V(a1), p1.shape[1], P(out), w + 3, w, h, C.byref(fp), C.byref(fp), sy, sx, C.byref(cp)] + tail))
+    return first, out
+
+
+@pytest.mark.parametrize("bd,is16", [(8, 0), (10, 1), (12, 1)])
+def test_convolve_jnt(orc, ref, bd, is16):
+    sig8 = (V, C.c_int32, V, C.c_int32, C.c_int32, C.c_int32, V, V, C.c_int32, C.c_int32, V)
+    fns = [L.rtcd(ref, (f"svt_av1_highbd_jnt_convolve_{m}" if is16 else f"svt_av1_jnt_convolve_{m}"), None,
+                  *(sig8 + ((C.c_int32,) if is16 else ()))) for m in K.JNT_MODES]
+    for i, c in enumerate(K.jnt_cases(bd, is16)):
+        f1, o1 = run_fn_jnt(fns, c, bd, is16, ConvolveParams, K.InterpFilterParams)
+        f2, o2 = run_orc_jnt(orc, c, bd, is16)
+        assert np.array_equal(f1, f2) and np.array_equal(o1, o2), (i, c[:6])
+
+
+def test_convolve_jnt_oracle_vs_golden(orc):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convolve_jnt.npz"))
+    k = 0
+    for bd, is16 in ((8, 0), (10, 1)):
+        for c in K.jnt_cases(bd, is16, n=16, seed=1):
+            f, o = run_orc_jnt(orc, c, bd, is16)
+            assert np.array_equal(f[:, :c[0]], g[f"first{k}"]) and np.array_equal(o[:, :c[0]], g[f"out{k}"]), k
+            k += 1

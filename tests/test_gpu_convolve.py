@@ -95,3 +95,75 @@ def test_golden(hip):
         fn = getattr(hip, f"svt_av1_highbd_convolve_{MODES[mode]}_hip" if is16 else f"svt_av1_convolve_{MODES[mode]}_hip")
         fn(*([V(at), plane.shape[1], P(o), w, w, h, C.byref(fp), C.byref(fp), sx, sy, C.byref(cp)] + ([bd] if is16 else [])))
         assert np.array_equal(o, g[f"c{i}_out"]), i
+
+
+@pytest.mark.parametrize("bd,is16", [(8, 0), (10, 1), (12, 1)])
+def test_tier_a_compound(hip, orc, bd, is16):
+    """svt_av1_(highbd_)jnt_convolve_{2d,x,y,2d_copy}_hip: first prediction into the ConvBufType buffer, second prediction
+    averaged (plain / distance-weighted) into pixels — both steps against the oracle."""
+    import test_convolve_oracle as T
+    fns = [getattr(hip, f"svt_av1_highbd_jnt_convolve_{m}_hip" if is16 else f"svt_av1_jnt_convolve_{m}_hip") for m in K.JNT_MODES]
+    for i, c in enumerate(K.jnt_cases(bd, is16)):
+        f1, o1 = T.run_fn_jnt(fns, c, bd, is16, abi.ConvolveParams, abi.InterpFilterParams)
+        f2, o2 = T.run_orc_jnt(orc, c, bd, is16)
+        assert np.array_equal(f1, f2) and np.array_equal(o1, o2), (i, c[:6])
+
+
+def test_compound_golden(hip):
+    import test_convolve_oracle as T
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convolve_jnt.npz"))
+    k = 0
+    for bd, is16 in ((8, 0), (10, 1)):
+        fns = [getattr(hip, f"svt_av1_highbd_jnt_convolve_{m}_hip" if is16 else f"svt_av1_jnt_convolve_{m}_hip") for m in K.JNT_MODES]
+        for c in K.jnt_cases(bd, is16, n=16, seed=1):
+            f, o = T.run_fn_jnt(fns, c, bd, is16, abi.ConvolveParams, abi.InterpFilterParams)
+            assert np.array_equal(f[:, :c[0]], g[f"first{k}"]) and np.array_equal(o[:, :c[0]], g[f"out{k}"]), k
+            k += 1
+
+
+@pytest.mark.parametrize("bd,is16", [(8, 0), (10, 1)])
+def test_tier_b_compound_batch(hip, orc, bd, is16):
+    """Compound prediction of a tiled picture: one launch for every block's first reference (into a picture-sized
+    ConvBufType plane), one for the second reference with the average, both from device-resident reference planes."""
+    rng = np.random.default_rng(640 + bd)
+    W, H = 512, 256
+    p0, a0 = K.ref_plane(rng, W, H, bd, is16, 0)
+    p1, a1 = K.ref_plane(rng, W, H, bd, is16, 2)
+    d0, d1 = device.DeviceBuffer(hip, p0.nbytes), device.DeviceBuffer(hip, p1.nbytes)
+    d0.upload(p0), d1.upload(p1)
+    o0, o1 = a0 - p0.ctypes.data, a1 - p1.ctypes.data
+    d_out, d_cb = device.DeviceBuffer(hip, W * H * p0.itemsize), device.DeviceBuffer(hip, W * H * 2)
+    d_out.fill(0), d_cb.fill(0)
+    r0, r1 = K.conv_rounds_compound(bd)
+    tabs = [np.array(K.TABLES[n], np.int16) for n in K.TABLES]
+    first, second = [], []
+    want, cb = np.zeros((H, W), p0.dtype), np.zeros((H, W), np.uint16)
+    for y in range(0, H, 64):
+        for x in range(0, W, 64):
+            bs = int(rng.choice([8, 16, 32, 64]))
+            for yy in range(y, y + 64, bs):
+                for xx in range(x, x + 64, bs):
+                    avg = int(rng.choice([2, 3]))
+                    fwd, bck = K.DIST_WEIGHTS[int(rng.integers(0, len(K.DIST_WEIGHTS)))]
+                    for ref_i, (dev, off, plane, at, lst) in enumerate(((d0, o0, p0, a0, first), (d1, o1, p1, a1, second))):
+                        mvx, mvy = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+                        sx, sy = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+                        mode = int(rng.integers(0, 4))
+                        tx, ty = (8 if mode in (0, 1) else 0), (8 if mode in (0, 2) else 0)
+                        t = tabs[int(rng.integers(0, 3))]
+                        so = ((yy + mvy) * plane.shape[1] + xx + mvx) * plane.itemsize
+                        comp = 1 if ref_i == 0 else avg
+                        lst.append(abi.ConvolveDesc(dev.ptr + off + so, d_out.ptr + (yy * W + xx) * plane.itemsize, plane.shape[1], W, bs, bs,
+                                                    (C.c_int16 * 8)(*t[sx]), (C.c_int16 * 8)(*t[sy]), tx, ty, r0, r1, bd, is16, comp, fwd, bck,
+                                                    (C.c_uint8 * 3)(), d_cb.ptr + (yy * W + xx) * 2, W, 0))
+                        orc.orc_convolve_jnt(V(at + so), plane.shape[1], V(want.ctypes.data + (yy * W + xx) * plane.itemsize), W, bs, bs,
+                                             V(t[sx].ctypes.data), tx, V(t[sy].ctypes.data), ty, r0, r1, bd, is16,
+                                             V(cb.ctypes.data + (yy * W + xx) * 2), W, comp, fwd, bck)
+    for lst in (first, second):
+        arr = (abi.ConvolveDesc * len(lst))(*lst)
+        d_desc = device.DeviceBuffer(hip, C.sizeof(arr))
+        d_desc.upload(np.frombuffer(arr, np.uint8))
+        device.check(hip, hip.svt_hip_convolve_batch(V(d_desc.ptr), len(lst), None), "convolve_batch")
+        device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+    assert np.array_equal(d_cb.download(np.uint16, (H, W)), cb)
+    assert np.array_equal(d_out.download(p0.dtype, (H, W)), want)
