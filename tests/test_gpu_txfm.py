@@ -261,3 +261,85 @@ def test_quantize_batch(hip, orc):
         assert np.array_equal(out[d.qcoeff_off:d.qcoeff_off + 4 * n].view(np.int32), qc)
         assert np.array_equal(out[d.dqcoeff_off:d.dqcoeff_off + 4 * n].view(np.int32), dq)
         assert int(res_raw[i, 8:10].view(np.uint16)[0]) == eob
+
+
+@pytest.mark.parametrize("w,h", [(8, 8), (16, 16), (32, 32), (64, 64)])
+def test_tier_b_4k_frame_properties(hip, orc, w, h):
+    """BASELINE.json configs[2] size: every luma transform block of one 3840x2160 10-bit picture through the fused kernel in
+    one launch.  Checked through (a) a random sample of blocks against the oracle pipeline, (b) order independence: the same
+    blocks launched in a permuted descriptor order give byte-identical coefficient, eob and reconstruction data."""
+    W4, H4, bd = 3840, 2160, 10
+    rng = np.random.default_rng(2160 + w)
+    resid = (rng.integers(-400, 401, size=(H4, W4)) // rng.integers(1, 9, size=(H4, W4))).astype(np.int16)
+    pred = rng.integers(0, 1 << bd, size=(H4, W4), dtype=np.uint16)
+    bw, bh = W4 // w, H4 // h
+    nblk = bw * bh
+    iw, ih = min(w, 32), min(h, 32)
+    n = iw * ih
+    off_res, off_pred = 0, W4 * H4 * 2
+    off_rec, off_q = off_pred + W4 * H4 * 2, off_pred + 2 * W4 * H4 * 2
+    off_dq = off_q + nblk * n * 4
+    off_iscan = off_dq + nblk * n * 4
+    total = off_iscan + n * 2 + 512
+    scan = rng.permutation(n).astype(np.int16)
+    iscan = np.empty(n, np.int16)
+    iscan[scan] = np.arange(n)
+    tq = T.quant_tables(rng, bd)
+    ls = 2 if w == 64 else (1 if w == 32 else 0)
+    types = [tt for tt in range(16) if orc.orc_txfm_valid(w, h, tt)]
+    i = np.arange(nblk, dtype=np.uint64)
+    pix = (i // bw * h) * W4 + (i % bw) * w
+    descs = np.zeros(nblk, dtype=np.dtype(abi.TxfmDesc))
+    descs["residual_off"], descs["residual_stride"] = off_res + pix * 2, W4
+    descs["coeff_off"] = abi.NO_OFFSET
+    descs["qcoeff_off"], descs["dqcoeff_off"] = off_q + i * (n * 4), off_dq + i * (n * 4)
+    descs["pred_off"], descs["recon_off"], descs["pred_stride"], descs["recon_stride"] = off_pred + pix * 2, off_rec + pix * 2, W4, W4
+    descs["iscan_off"], descs["qm_off"], descs["iqm_off"] = off_iscan, abi.NO_OFFSET, abi.NO_OFFSET
+    for k in range(2):
+        descs["zbin"][:, k], descs["round"][:, k], descs["quant"][:, k] = int(tq["zbin"][k]), int(tq["round"][k]), int(tq["quant"][k])
+        descs["quant_shift"][:, k], descs["dequant"][:, k] = int(tq["qshift"][k]), int(tq["dequant"][k])
+    descs["tx_type"] = np.array(types, np.uint8)[(i * 7 + i // bw) % len(types)]
+    descs["shape"], descs["bit_depth"], descs["quant_mode"], descs["log_scale"] = 0, bd, abi.QUANT_B_HBD, ls
+    descs["flags"] = abi.TX_FWD | abi.TX_INV | abi.TX_PIXEL16 | abi.TX_SATD
+    darena = device.DeviceBuffer(hip, total)
+    ddesc = device.DeviceBuffer(hip, descs.nbytes)
+    dres = device.DeviceBuffer(hip, 16 * nblk)
+
+    def run(order):
+        darena.fill(0)
+        for off, a in ((off_res, resid), (off_pred, pred), (off_iscan, iscan)):
+            device.check(hip, hip.svt_hip_upload(V(darena.ptr + off), P(a), C.c_size_t(a.nbytes), None), "svt_hip_upload")
+        device.check(hip, hip.svt_hip_stream_sync(None), "svt_hip_stream_sync")
+        ddesc.upload(np.ascontiguousarray(descs[order]).view(np.uint8))
+        device.check(hip, hip.svt_hip_txfm_quant_batch(V(darena.ptr), V(ddesc.ptr), V(dres.ptr), C.c_uint32(nblk), C.c_uint32(w),
+                                                       C.c_uint32(h), None), "svt_hip_txfm_quant_batch")
+        out = darena.download(np.uint8, (total,))
+        res = dres.download(np.uint8, (nblk, 16))
+        back = np.empty_like(res)
+        back[order] = res                      # result i belongs to descriptor order[i]
+        return out, back
+
+    ident = np.arange(nblk)
+    out, res = run(ident)
+    out2, res2 = run(rng.permutation(nblk))
+    assert np.array_equal(out[off_rec:off_iscan], out2[off_rec:off_iscan]) and np.array_equal(res, res2)
+    rec_plane = out[off_rec:off_rec + W4 * H4 * 2].view(np.uint16).reshape(H4, W4)
+    orc.orc_satd.restype = C.c_int
+    for b in rng.choice(nblk, size=60, replace=False):
+        by, bx = (b // bw) * h, (b % bw) * w
+        tt = int(descs["tx_type"][b])
+        r = np.ascontiguousarray(resid[by:by + h, bx:bx + w])
+        co = np.zeros(w * h, np.int32)
+        orc.orc_fwd_txfm2d(P(r), P(co), C.c_uint32(w), w, h, tt, bd, 0)
+        if max(w, h) == 64:
+            orc.orc_handle_transform64.restype = C.c_uint64
+            orc.orc_handle_transform64(P(co), w, h)
+        co = co[:n].copy()
+        qc, dq, eob = T.orc_quant(orc, 2, dict(n=n, ls=ls, coeff=co, scan=scan, iscan=iscan, qm=None, iqm=None, t=tq))
+        p = np.ascontiguousarray(pred[by:by + h, bx:bx + w])
+        rec = np.zeros((h, w), np.uint16)
+        orc.orc_inv_txfm2d_add(P(dq), P(p), w, P(rec), w, w, h, tt, bd)
+        assert np.array_equal(out[off_q + b * n * 4:off_q + (b + 1) * n * 4].view(np.int32), qc), ("qcoeff", b)
+        assert np.array_equal(out[off_dq + b * n * 4:off_dq + (b + 1) * n * 4].view(np.int32), dq), ("dqcoeff", b)
+        assert int(res[b, 8:10].view(np.uint16)[0]) == eob and int(res[b, 12:16].view(np.uint32)[0]) == orc.orc_satd(P(co), n), ("eob/satd", b)
+        assert np.array_equal(rec_plane[by:by + h, bx:bx + w], rec), ("recon", b)
