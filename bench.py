@@ -323,7 +323,7 @@ def bench_txfm(lib, dev, args, world, rank):
         descs["log_scale"] = 2 if w == 64 else (1 if w == 32 else 0)
         descs["flags"] = abi.TX_FWD | abi.TX_INV | abi.TX_PIXEL16
         d_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
-        d_res = torch.zeros(nblk * 16, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(nblk * abi.TXFM_RESULT_BYTES, dtype=torch.uint8, device=dev)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
         def launch():
@@ -366,7 +366,7 @@ def bench_txfm(lib, dev, args, world, rank):
         descs["tx_type"], descs["shape"], descs["bit_depth"], descs["quant_mode"] = 0, 0, 8, abi.QUANT_NONE
         descs["flags"] = abi.TX_FWD | abi.TX_SRC_PRED | abi.TX_SATD
         d_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
-        d_res = torch.zeros(nblk * 16, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(nblk * abi.TXFM_RESULT_BYTES, dtype=torch.uint8, device=dev)
 
         def launch_tpl():
             rc = lib.svt_hip_txfm_quant_batch(C.c_void_p(arena.data_ptr()), C.c_void_p(d_desc.data_ptr()), C.c_void_p(d_res.data_ptr()),

@@ -94,6 +94,13 @@ SVT_HIP_API void svt_aom_highbd_subtract_block_hip(int rows, int cols, int16_t *
                                                    const uint8_t *src_ptr, ptrdiff_t src_stride, const uint8_t *pred_ptr,
                                                    ptrdiff_t pred_stride, int bd);
 SVT_HIP_API int svt_aom_satd_hip(const int32_t *coeff, int length);
+/* Transform-domain distortion of the full loop: svt_full_distortion_kernel32_bits and its cbf-zero form
+ * (common_dsp_rtcd.h:166-167, pic_operators.c:150-221); distortion_result = {residual, prediction}. */
+SVT_HIP_API void svt_full_distortion_kernel32_bits_hip(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff,
+                                                       uint32_t recon_coeff_stride, uint64_t distortion_result[2],
+                                                       uint32_t area_width, uint32_t area_height);
+SVT_HIP_API void svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2],
+                                                                uint32_t area_width, uint32_t area_height);
 
 /* ---------------------------------------------------------------------------------------------
  * Tier B — batched, fused transform block processing on device-resident data:
@@ -139,18 +146,29 @@ typedef struct SvtHipTxfmDesc {
     uint32_t pred_stride, recon_stride; /* in pixels */
     int16_t  zbin[2], round[2], quant[2], quant_shift[2], dequant[2]; /* [0] DC, [1] AC */
     uint8_t  tx_type, shape /* 0 full, 1 N2, 2 N4 */, bit_depth, quant_mode, log_scale, flags;
-    uint8_t  pad_[2];
+    uint8_t  dist_w, dist_h; /* svt_hip_txfm_distortion_batch: cropped_tx_width / cropped_tx_height of the caller
+                              * (0 = min(w,32) / min(h,32)) */
 } SvtHipTxfmDesc;
 
 typedef struct SvtHipTxfmResult {
     uint64_t three_quad_energy; /* svt_handle_transformWxH return value (0 for sizes without a 64-point side) */
     uint16_t eob;
     uint16_t pad_;
-    uint32_t satd; /* SVT_HIP_TX_SATD, else 0 */
+    uint32_t satd;            /* SVT_HIP_TX_SATD, else 0 */
+    uint64_t dist_residual;   /* svt_hip_txfm_distortion_batch: distortion[DIST_CALC_RESIDUAL] = sum (coeff - dqcoeff)^2 */
+    uint64_t dist_prediction; /*                                distortion[DIST_CALC_PREDICTION] = sum coeff^2; else 0 */
 } SvtHipTxfmResult;
 
 SVT_HIP_API int32_t svt_hip_txfm_quant_batch(uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
                                              uint32_t n_blocks, uint32_t w, uint32_t h, void *stream);
+
+/* Transform-domain distortion of the same blocks, what svt_aom_full_loop_core reads right after the quantiser
+ * (svt_aom_picture_full_distortion32_bits_single, pic_operators.c:150-234): for every descriptor with coeff_off and
+ * dqcoeff_off set, result.dist_residual / dist_prediction over the dist_w x dist_h top-left area of the retained
+ * coefficient block.  Run it after svt_hip_txfm_quant_batch on the same stream with the same arguments (that call
+ * writes the coefficient arrays and zeroes the two fields). */
+SVT_HIP_API int32_t svt_hip_txfm_distortion_batch(const uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
+                                                  uint32_t n_blocks, uint32_t w, uint32_t h, void *stream);
 
 /* Stand-alone batched quantiser over device coefficient arrays (same descriptor; coeff_off is the INPUT). */
 SVT_HIP_API int32_t svt_hip_quantize_batch(uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,

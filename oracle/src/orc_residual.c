@@ -47,3 +47,16 @@ ORC_API int64_t orc_tpl_block_cost(const uint8_t *src, int src_stride, const uin
     orc_fwd_txfm2d(diff, coeff, (uint32_t)(size << subsample_tx), size, rows, 0 /* DCT_DCT */, 8, pf_shape);
     return (int64_t)orc_satd(coeff, (size * size) >> subsample_tx) << subsample_tx;
 }
+
+/* svt_full_distortion_kernel32_bits_c / svt_full_distortion_kernel_cbf_zero32_bits_c (Source/Lib/Codec/pic_operators.c:150-221):
+ * out[0] = sum (coeff - recon)^2 (recon == NULL: sum coeff^2), out[1] = sum coeff^2 over a w x h area */
+ORC_API void orc_full_distortion32(const int32_t *coeff, uint32_t coeff_stride, const int32_t *recon, uint32_t recon_stride,
+                                   uint64_t out[2], uint32_t w, uint32_t h) {
+    uint64_t res = 0, prd = 0;
+    for (uint32_t r = 0; r < h; r++)
+        for (uint32_t c = 0; c < w; c++) {
+            const int64_t v = coeff[(size_t)r * coeff_stride + c], e = v - (recon ? (int64_t)recon[(size_t)r * recon_stride + c] : 0);
+            res += (uint64_t)(e * e), prd += (uint64_t)(v * v);
+        }
+    out[0] = res, out[1] = prd;
+}

@@ -36,6 +36,8 @@ ORC_API void orc_subtract_block(int rows, int cols, int16_t *diff, ptrdiff_t dif
 ORC_API void orc_highbd_subtract_block(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const uint16_t *src,
                                        ptrdiff_t src_stride, const uint16_t *pred, ptrdiff_t pred_stride);
 ORC_API int     orc_satd(const int32_t *coeff, int length);
+ORC_API void    orc_full_distortion32(const int32_t *coeff, uint32_t coeff_stride, const int32_t *recon, uint32_t recon_stride,
+                                      uint64_t out[2], uint32_t w, uint32_t h);
 ORC_API int64_t orc_tpl_block_cost(const uint8_t *src, int src_stride, const uint8_t *pred, int pred_stride, int size,
                                    int subsample_tx, int pf_shape);
 #ifdef __cplusplus

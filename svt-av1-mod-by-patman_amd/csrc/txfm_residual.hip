@@ -47,6 +47,48 @@ __global__ __launch_bounds__(256) void satd_kernel(const int32_t *__restrict__ c
         *out = (int32_t)(part[0] + part[1] + part[2] + part[3]);
 }
 
+// {sum (coeff - recon)^2, sum coeff^2} over an area (recon == nullptr: the cbf-zero form, both entries = sum coeff^2)
+__global__ __launch_bounds__(256) void full_distortion_kernel(const int32_t *__restrict__ coeff, int cs, const int32_t *__restrict__ recon,
+                                                              int rs, int w, int h, uint64_t *__restrict__ out) {
+    __shared__ uint64_t part[2][4];
+    uint64_t            a = 0, b = 0;
+    for (int i = threadIdx.x; i < w * h; i += 256) {
+        const int     r = i / w, c = i - r * w;
+        const int64_t v = coeff[(size_t)r * cs + c], e = v - (recon ? (int64_t)recon[(size_t)r * rs + c] : 0);
+        a += (uint64_t)(e * e), b += (uint64_t)(v * v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64), b += __shfl_xor(b, off, 64);
+    if ((threadIdx.x & 63) == 0)
+        part[0][threadIdx.x >> 6] = a, part[1][threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[0] = part[0][0] + part[0][1] + part[0][2] + part[0][3], out[1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+}
+
+// one wave per transform block: distortion of the stored coefficient / de-quantised arrays (row pitch = retained width)
+__global__ __launch_bounds__(256) void distortion_batch_kernel(const uint8_t *__restrict__ base, const SvtHipTxfmDesc *__restrict__ descs,
+                                                               SvtHipTxfmResult *__restrict__ results, uint32_t n, int iw, int ih) {
+    const uint32_t tb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tb >= n)
+        return;
+    const SvtHipTxfmDesc &d = descs[tb];
+    uint64_t              a = 0, b = 0;
+    if (d.coeff_off != SVT_HIP_NO_OFFSET && d.dqcoeff_off != SVT_HIP_NO_OFFSET && !(d.flags & SVT_HIP_TX_FULLCOEFF)) {
+        const int32_t *co = (const int32_t *)(base + d.coeff_off), *dq = (const int32_t *)(base + d.dqcoeff_off);
+        const int      dw = d.dist_w ? (d.dist_w < iw ? d.dist_w : iw) : iw, dh = d.dist_h ? (d.dist_h < ih ? d.dist_h : ih) : ih;
+        for (int i = lane; i < dw * dh; i += 64) {
+            const int     r = i / dw, c = i - r * dw;
+            const int64_t v = co[r * iw + c], e = v - (int64_t)dq[r * iw + c];
+            a += (uint64_t)(e * e), b += (uint64_t)(v * v);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64), b += __shfl_xor(b, off, 64);
+    if (lane == 0)
+        results[tb].dist_residual = a, results[tb].dist_prediction = b;
+}
+
 void fatal(const char *what) {
     fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
     abort();
@@ -107,4 +149,56 @@ extern "C" int svt_aom_satd_hip(const int32_t *coeff, int length) {
     SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + cb, d + cb, 4, hipMemcpyDeviceToHost, st));
     SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
     return *(const int32_t *)(h + cb);
+}
+
+namespace {
+void distortion_tier_a(const int32_t *coeff, uint32_t cs, const int32_t *recon, uint32_t rs, uint64_t out[2], uint32_t w, uint32_t h) {
+    out[0] = out[1] = 0;
+    if (!w || !h)
+        return;
+    if (!ensure_init())
+        fatal("full_distortion");
+    const size_t n = (size_t)w * h, cb = up256(n * 4);
+    Scratch     &sc = tls_scratch();
+    uint8_t     *hh = sc.host(2 * cb + 256), *d = sc.device(2 * cb + 256);
+    for (uint32_t r = 0; r < h; r++) {
+        memcpy(hh + (size_t)r * w * 4, coeff + (size_t)r * cs, (size_t)w * 4);
+        if (recon)
+            memcpy(hh + cb + (size_t)r * w * 4, recon + (size_t)r * rs, (size_t)w * 4);
+    }
+    hipStream_t st = resolve_stream(nullptr);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, hh, recon ? 2 * cb : cb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(full_distortion_kernel, dim3(1), dim3(256), 0, st, (const int32_t *)d, (int)w, recon ? (const int32_t *)(d + cb) : nullptr,
+                       (int)w, (int)w, (int)h, (uint64_t *)(d + 2 * cb));
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(hh + 2 * cb, d + 2 * cb, 16, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    memcpy(out, hh + 2 * cb, 16);
+}
+}  // namespace
+
+extern "C" void svt_full_distortion_kernel32_bits_hip(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride,
+                                                      uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) {
+    distortion_tier_a(coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height);
+}
+extern "C" void svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2],
+                                                               uint32_t area_width, uint32_t area_height) {
+    distortion_tier_a(coeff, coeff_stride, nullptr, 0, distortion_result, area_width, area_height);
+}
+
+extern "C" int32_t svt_hip_txfm_distortion_batch(const uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
+                                                 uint32_t n_blocks, uint32_t w, uint32_t h, void *stream) {
+    const bool ok_w = w == 4 || w == 8 || w == 16 || w == 32 || w == 64, ok_h = h == 4 || h == 8 || h == 16 || h == 32 || h == 64;
+    if (!d_base || !d_desc || !d_result || !ok_w || !ok_h) {
+        set_error("svt_hip_txfm_distortion_batch: bad argument");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    if (n_blocks == 0)
+        return SVT_HIP_OK;
+    hipLaunchKernelGGL(distortion_batch_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, resolve_stream(stream), d_base, d_desc, d_result,
+                       n_blocks, (int)(w < 32 ? w : 32), (int)(h < 32 ? h : 32));
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
 }

@@ -133,6 +133,9 @@ def load():
     """Load libsvtav1_hip.so (built by __graft_entry__.build()).  No fallback."""
     global _lib
     if _lib is None:
+        # tuning aid: SVTAV1_HIP_LIB names another build of the SAME library (kernel variants side by side in one GPU call)
+        global LIB_PATH
+        LIB_PATH = os.environ.get("SVTAV1_HIP_LIB", LIB_PATH)
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(the HIP path has no CPU fallback)")
@@ -154,6 +157,7 @@ SVT_HIP_ERR_BAD_PARAMETER = 0x80001005 - (1 << 32)
 SVT_HIP_ERR_RUNTIME = 0x80001001 - (1 << 32)
 QUANT_NONE, QUANT_B, QUANT_B_HBD, QUANT_FP, QUANT_FP_HBD = range(5)
 TX_FWD, TX_INV, TX_PIXEL16, TX_FULLCOEFF, TX_SRC_PRED, TX_SATD = 1, 2, 4, 8, 16, 32
+TXFM_RESULT_BYTES = 32
 
 
 class TxfmDesc(C.Structure):
@@ -164,11 +168,12 @@ class TxfmDesc(C.Structure):
                 ("zbin", C.c_int16 * 2), ("round", C.c_int16 * 2), ("quant", C.c_int16 * 2),
                 ("quant_shift", C.c_int16 * 2), ("dequant", C.c_int16 * 2),
                 ("tx_type", C.c_uint8), ("shape", C.c_uint8), ("bit_depth", C.c_uint8), ("quant_mode", C.c_uint8),
-                ("log_scale", C.c_uint8), ("flags", C.c_uint8), ("pad_", C.c_uint8 * 2)]
+                ("log_scale", C.c_uint8), ("flags", C.c_uint8), ("dist_w", C.c_uint8), ("dist_h", C.c_uint8)]
 
 
 class TxfmResult(C.Structure):
-    _fields_ = [("three_quad_energy", C.c_uint64), ("eob", C.c_uint16), ("pad_", C.c_uint16), ("satd", C.c_uint32)]
+    _fields_ = [("three_quad_energy", C.c_uint64), ("eob", C.c_uint16), ("pad_", C.c_uint16), ("satd", C.c_uint32),
+                ("dist_residual", C.c_uint64), ("dist_prediction", C.c_uint64)]
 
 
 class CdefList(C.Structure):

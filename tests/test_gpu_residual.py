@@ -11,7 +11,7 @@ import pytest
 import tx_cases as T
 from svtav1_hip import abi, device
 from test_gpu_txfm import ArenaBuilder
-from test_residual_oracle import GOLD, PD, orc_subtract, orc_tpl_cost, subtract_cases, tpl_cases
+from test_residual_oracle import GOLD, PD, distortion_cases, orc_subtract, orc_tpl_cost, subtract_cases, tpl_cases
 from tx_cases import P, V
 
 pytestmark = pytest.mark.gpu
@@ -37,6 +37,17 @@ def test_tier_a_subtract_and_satd(hip, orc):
     assert hip.svt_aom_satd_hip(P(np.zeros(4, np.int32)), 0) == 0
 
 
+def test_tier_a_full_distortion(hip, orc):
+    for w, h, co, rr in distortion_cases():
+        a, b = np.zeros(2, np.uint64), np.zeros(2, np.uint64)
+        hip.svt_full_distortion_kernel32_bits_hip(P(co), co.shape[1], P(rr), rr.shape[1], P(a), w, h)
+        orc.orc_full_distortion32(P(co), co.shape[1], P(rr), rr.shape[1], P(b), w, h)
+        assert np.array_equal(a, b), (w, h)
+        hip.svt_full_distortion_kernel_cbf_zero32_bits_hip(P(co), co.shape[1], P(a), w, h)
+        orc.orc_full_distortion32(P(co), co.shape[1], None, 0, P(b), w, h)
+        assert np.array_equal(a, b), (w, h, "cbf0")
+
+
 def run_batch(hip, ab, descs, w, h):
     arena = ab.build()
     darena = device.DeviceBuffer(hip, arena.nbytes + 256)
@@ -44,10 +55,10 @@ def run_batch(hip, ab, descs, w, h):
     darr = (abi.TxfmDesc * len(descs))(*descs)
     ddesc = device.DeviceBuffer(hip, C.sizeof(darr))
     ddesc.upload(np.frombuffer(darr, dtype=np.uint8))
-    dres = device.DeviceBuffer(hip, 16 * len(descs))
+    dres = device.DeviceBuffer(hip, abi.TXFM_RESULT_BYTES * len(descs))
     device.check(hip, hip.svt_hip_txfm_quant_batch(V(darena.ptr), V(ddesc.ptr), V(dres.ptr), C.c_uint32(len(descs)), C.c_uint32(w),
                                                    C.c_uint32(h), None), "svt_hip_txfm_quant_batch")
-    return darena.download(np.uint8, (arena.nbytes,)), dres.download(np.uint8, (len(descs), 16))
+    return darena.download(np.uint8, (arena.nbytes,)), dres.download(np.uint8, (len(descs), abi.TXFM_RESULT_BYTES))
 
 
 def blank_desc():

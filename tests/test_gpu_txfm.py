@@ -183,6 +183,8 @@ def test_tier_b_fused_batch(hip, orc, w, h):
             d.quant_shift[k], d.dequant[k] = int(tq["qshift"][k]), int(tq["dequant"][k])
         d.tx_type, d.shape, d.bit_depth, d.quant_mode, d.log_scale = tt, shape, bd, mode, ls
         d.flags = abi.TX_FWD | abi.TX_INV | (abi.TX_PIXEL16 if pix16 else 0)
+        if i % 6 == 1:      # a block cut by the picture edge: the caller's cropped_tx_width / cropped_tx_height
+            d.dist_w, d.dist_h = max(1, iw - 3), max(1, ih // 2)
         descs.append(d)
         # oracle pipeline
         co = np.zeros(w * h, np.int32)
@@ -202,11 +204,13 @@ def test_tier_b_fused_batch(hip, orc, w, h):
     darr = (abi.TxfmDesc * n_tb)(*descs)
     ddesc = device.DeviceBuffer(hip, C.sizeof(darr))
     ddesc.upload(np.frombuffer(darr, dtype=np.uint8))
-    dres = device.DeviceBuffer(hip, 16 * n_tb)
+    dres = device.DeviceBuffer(hip, abi.TXFM_RESULT_BYTES * n_tb)
     device.check(hip, hip.svt_hip_txfm_quant_batch(V(darena.ptr), V(ddesc.ptr), V(dres.ptr), C.c_uint32(n_tb), C.c_uint32(w),
                                                    C.c_uint32(h), None), "svt_hip_txfm_quant_batch")
+    device.check(hip, hip.svt_hip_txfm_distortion_batch(V(darena.ptr), V(ddesc.ptr), V(dres.ptr), C.c_uint32(n_tb), C.c_uint32(w),
+                                                        C.c_uint32(h), None), "svt_hip_txfm_distortion_batch")
     out = darena.download(np.uint8, (arena.nbytes,))
-    res_raw = dres.download(np.uint8, (n_tb, 16))
+    res_raw = dres.download(np.uint8, (n_tb, abi.TXFM_RESULT_BYTES))
     for i, (co, qc, dq, eob, energy, rec, pix16, d) in enumerate(expect):
         g = lambda off, cnt, dt: out[off:off + cnt * np.dtype(dt).itemsize].view(dt)
         if d.coeff_off != abi.NO_OFFSET:
@@ -217,6 +221,10 @@ def test_tier_b_fused_batch(hip, orc, w, h):
         assert int(res_raw[i, :8].view(np.uint64)[0]) == energy, ("energy", i)
         got = g(d.recon_off, h * (w + 4), np.uint16 if pix16 else np.uint8).reshape(h, w + 4)
         assert np.array_equal(got[:, :w], rec[:, :w]), ("recon", i)
+        want = np.zeros(2, np.uint64)
+        if d.coeff_off != abi.NO_OFFSET:   # svt_aom_picture_full_distortion32_bits_single over the (cropped) area
+            orc.orc_full_distortion32(P(co), iw, P(dq), iw, P(want), d.dist_w or iw, d.dist_h or ih)
+        assert np.array_equal(res_raw[i, 16:32].view(np.uint64), want), ("distortion", i)
 
 
 def test_quantize_batch(hip, orc):
@@ -251,11 +259,11 @@ def test_quantize_batch(hip, orc):
     darr = (abi.TxfmDesc * n_tb)(*descs)
     ddesc = device.DeviceBuffer(hip, C.sizeof(darr))
     ddesc.upload(np.frombuffer(darr, dtype=np.uint8))
-    dres = device.DeviceBuffer(hip, 16 * n_tb)
+    dres = device.DeviceBuffer(hip, abi.TXFM_RESULT_BYTES * n_tb)
     device.check(hip, hip.svt_hip_quantize_batch(V(darena.ptr), V(ddesc.ptr), V(dres.ptr), C.c_uint32(n_tb), C.c_uint32(n), None),
                  "svt_hip_quantize_batch")
     out = darena.download(np.uint8, (arena.nbytes,))
-    res_raw = dres.download(np.uint8, (n_tb, 16))
+    res_raw = dres.download(np.uint8, (n_tb, abi.TXFM_RESULT_BYTES))
     for i, (qc, dq, eob) in enumerate(expect):
         d = descs[i]
         assert np.array_equal(out[d.qcoeff_off:d.qcoeff_off + 4 * n].view(np.int32), qc)
@@ -303,7 +311,7 @@ def test_tier_b_4k_frame_properties(hip, orc, w, h):
     descs["flags"] = abi.TX_FWD | abi.TX_INV | abi.TX_PIXEL16 | abi.TX_SATD
     darena = device.DeviceBuffer(hip, total)
     ddesc = device.DeviceBuffer(hip, descs.nbytes)
-    dres = device.DeviceBuffer(hip, 16 * nblk)
+    dres = device.DeviceBuffer(hip, abi.TXFM_RESULT_BYTES * nblk)
 
     def run(order):
         darena.fill(0)
@@ -314,7 +322,7 @@ def test_tier_b_4k_frame_properties(hip, orc, w, h):
         device.check(hip, hip.svt_hip_txfm_quant_batch(V(darena.ptr), V(ddesc.ptr), V(dres.ptr), C.c_uint32(nblk), C.c_uint32(w),
                                                        C.c_uint32(h), None), "svt_hip_txfm_quant_batch")
         out = darena.download(np.uint8, (total,))
-        res = dres.download(np.uint8, (nblk, 16))
+        res = dres.download(np.uint8, (nblk, abi.TXFM_RESULT_BYTES))
         back = np.empty_like(res)
         back[order] = res                      # result i belongs to descriptor order[i]
         return out, back

@@ -94,3 +94,29 @@ def test_golden(orc):
         assert np.array_equal(gold[f"sub{i}"], orc_subtract(orc, rows, cols, ds, s, p, hbd)[:, :cols]), i
     costs = [orc_tpl_cost(orc, *c) for c in tpl_cases()]
     assert np.array_equal(gold["tpl_cost"], np.array(costs, np.int64))
+
+
+def distortion_cases():
+    rng = np.random.default_rng(717)
+    for k in range(20):
+        w, h = int(rng.choice([4, 8, 16, 32, 11])), int(rng.choice([4, 8, 16, 32, 7]))
+        cs, rs = w + int(rng.integers(0, 5)), w + int(rng.integers(0, 5))
+        mag = int(rng.choice([40, 3000, 1 << 17, 1 << 24]))
+        co = rng.integers(-mag, mag + 1, size=(h, cs)).astype(np.int32)
+        rc = (co[:, :w] + rng.integers(-mag // 8 - 1, mag // 8 + 2, size=(h, w))).astype(np.int32)
+        rr = np.zeros((h, rs), np.int32)
+        rr[:, :w] = rc
+        yield w, h, co, rr
+
+
+def test_full_distortion_vs_reference(orc, ref):
+    f32 = rtcd(ref, "svt_full_distortion_kernel32_bits", None, V, C.c_uint32, V, C.c_uint32, V, C.c_uint32, C.c_uint32)
+    fz = rtcd(ref, "svt_full_distortion_kernel_cbf_zero32_bits", None, V, C.c_uint32, V, C.c_uint32, C.c_uint32)
+    for w, h, co, rr in distortion_cases():
+        a, b = np.zeros(2, np.uint64), np.zeros(2, np.uint64)
+        f32(co.ctypes.data, co.shape[1], rr.ctypes.data, rr.shape[1], a.ctypes.data, w, h)
+        orc.orc_full_distortion32(P(co), co.shape[1], P(rr), rr.shape[1], P(b), w, h)
+        assert np.array_equal(a, b), (w, h)
+        fz(co.ctypes.data, co.shape[1], a.ctypes.data, w, h)
+        orc.orc_full_distortion32(P(co), co.shape[1], None, 0, P(b), w, h)
+        assert np.array_equal(a, b), (w, h, "cbf0")
