@@ -6,9 +6,10 @@
 // y[k] = dgd(sample + tap k) - avg.  Here the RAW second moments are accumulated instead and the mean is folded in at the
 // end (exact integer algebra: sum (a - m)(b - m) = sum ab - m sum a - m sum b + N m^2), so no pre-pass over the unit is
 // needed for `avg`.  One workgroup owns a 64 x 32 tile of the unit, staged in LDS with its border; a thread owns one
-// pair of tap COLUMNS (c1 <= c2): per sample it reads the 7 + 7 vertical taps of its two columns and does the 49
-// multiply-accumulates of that 7 x 7 block of H in registers (int32 partials, flushed per tile to int64).  28 column
-// pairs + 7 column-by-source blocks x 7 sample slices fill the 256 lanes.
+// pair of tap COLUMNS (c1 <= c2): per PAIR of horizontally adjacent samples it reads the 7 + 7 vertical taps of its two
+// columns (one aligned 32-bit LDS read per tap: the tile is kept twice, the second copy shifted by one sample) and does
+// the 49 multiply-accumulates of that 7 x 7 block of H as 49 v_dot2_u32_u16 in registers (uint32 partials, flushed per
+// tile to int64).  28 column pairs + 7 column-by-source blocks x 7 sample slices fill the 256 lanes.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +28,8 @@ __device__ __forceinline__ int32_t ldpx(const void *p, size_t idx, int is16) {
     return is16 ? ((const uint16_t *)p)[idx] : ((const uint8_t *)p)[idx];
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 struct StatsAux {  // raw first moments of one unit
     long long S[W2MAX];  // sum of dgd at tap k
     long long sum_src, n;
@@ -41,8 +44,11 @@ __global__ __launch_bounds__(256) void wiener_stats_kernel(const SvtHipWienerUni
     constexpr int NPAIR = WIN * (WIN + 1) / 2, NJOB = NPAIR + WIN + 1;  // column pairs, column x source, source sum
     constexpr int NSL = 256 / NJOB;                                      // sample slices
     constexpr int DP = TW + 2 * 3 + 2;
-    __shared__ uint16_t  d[(TH + 2 * 3) * DP];
-    __shared__ uint16_t  s[TH * TW];
+    // d1 is d shifted left by one sample: a thread whose column offset is odd reads its sample PAIRS from d1, so that every
+    // pair is one aligned 32-bit LDS read
+    __shared__ __attribute__((aligned(4))) uint16_t d[(TH + 2 * 3) * DP];
+    __shared__ __attribute__((aligned(4))) uint16_t d1[(TH + 2 * 3) * DP];
+    __shared__ __attribute__((aligned(4))) uint16_t s[TH * TW];
     __shared__ long long Hl[W2 * W2], Ml[W2], Sl[W2], misc[2];  // this workgroup's totals (int64), flushed once at the end
     const SvtHipWienerUnit u = units[blockIdx.z];
     const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
@@ -72,28 +78,39 @@ __global__ __launch_bounds__(256) void wiener_stats_kernel(const SvtHipWienerUni
         __syncthreads();  // previous chunk fully consumed (and the zeroing above done)
         for (int idx = threadIdx.x; idx < (tv + 2 * HALF) * (tw + 2 * HALF); idx += 256) {
             const int r = idx / (tw + 2 * HALF), c = idx - r * (tw + 2 * HALF);
-            d[r * DP + c] = (uint16_t)ldpx(u.dgd, (size_t)((ptrdiff_t)(u.v_start + y0 + r - HALF) * u.dgd_stride + (u.h_start + x0 + c - HALF)), is16);
+            const uint16_t v = (uint16_t)ldpx(u.dgd, (size_t)((ptrdiff_t)(u.v_start + y0 + r - HALF) * u.dgd_stride + (u.h_start + x0 + c - HALF)), is16);
+            d[r * DP + c] = v;
+            if (c)
+                d1[r * DP + c - 1] = v;
         }
         for (int idx = threadIdx.x; idx < npx; idx += 256) {
             const int r = idx / tw, c = idx - r * tw;
             s[r * TW + c] = (uint16_t)ldpx(u.src, (size_t)((ptrdiff_t)(u.v_start + y0 + r) * u.src_stride + (u.h_start + x0 + c)), is16);
         }
         __syncthreads();
+        // Two horizontally adjacent samples per step: each multiply-accumulate of the block is one v_dot2_u32_u16 over the
+        // pair.  hw = pairs per row; the partner of the last sample of an odd-width tile is masked to zero.
+        const int hw = (tw + 1) >> 1, npair = tv * hw;
         if (job < NPAIR) {
-            int32_t acc[WIN][WIN];
+            uint32_t acc[WIN][WIN];
 #pragma unroll
             for (int a = 0; a < WIN; a++)
 #pragma unroll
                 for (int b = 0; b < WIN; b++) acc[a][b] = 0;
-            for (int pi = sl; pi < npx; pi += NSL) {
-                const int r = pi / tw, c = pi - r * tw;
-                int32_t   va[WIN], vb[WIN];
+            const uint16_t *ta = (c1 & 1) ? d1 - 1 : d, *tb = (c2 & 1) ? d1 - 1 : d;
+            for (int pj = sl; pj < npair; pj += NSL) {
+                const int      r = pj / hw, c = 2 * (pj - r * hw);
+                const uint32_t mask = c + 1 < tw ? 0xffffffffu : 0x0000ffffu;
+                u16x2          va[WIN], vb[WIN];
 #pragma unroll
-                for (int k = 0; k < WIN; k++) va[k] = d[(r + k) * DP + c + c1], vb[k] = d[(r + k) * DP + c + c2];
+                for (int k = 0; k < WIN; k++) {
+                    va[k] = __builtin_bit_cast(u16x2, *(const uint32_t *)&ta[(r + k) * DP + c + c1] & mask);
+                    vb[k] = __builtin_bit_cast(u16x2, *(const uint32_t *)&tb[(r + k) * DP + c + c2]);
+                }
 #pragma unroll
                 for (int a = 0; a < WIN; a++)
 #pragma unroll
-                    for (int b = 0; b < WIN; b++) acc[a][b] += (int32_t)__umul24((uint32_t)va[a], (uint32_t)vb[b]);  // samples < 2^16
+                    for (int b = 0; b < WIN; b++) acc[a][b] = __builtin_amdgcn_udot2(va[a], vb[b], acc[a][b], false);
             }
             // tap index = column * WIN + row (restoration_pick.c:686-691); only the upper triangle k <= l is kept
 #pragma unroll
@@ -102,25 +119,28 @@ __global__ __launch_bounds__(256) void wiener_stats_kernel(const SvtHipWienerUni
                 for (int b = 0; b < WIN; b++) {
                     const int k = c1 * WIN + a, l = c2 * WIN + b;
                     if (k <= l && acc[a][b])
-                        atomicAdd((unsigned long long *)&Hl[k * W2 + l], (unsigned long long)(long long)acc[a][b]);
+                        atomicAdd((unsigned long long *)&Hl[k * W2 + l], (unsigned long long)acc[a][b]);
                 }
         } else if (job < NPAIR + WIN) {
-            int32_t t[WIN], f[WIN];
+            uint32_t t[WIN], f[WIN];
 #pragma unroll
             for (int a = 0; a < WIN; a++) t[a] = 0, f[a] = 0;
-            for (int pi = sl; pi < npx; pi += NSL) {
-                const int     r = pi / tw, c = pi - r * tw;
-                const int32_t x = s[r * TW + c];
+            const uint16_t *ta = (c1 & 1) ? d1 - 1 : d;
+            for (int pj = sl; pj < npair; pj += NSL) {
+                const int      r = pj / hw, c = 2 * (pj - r * hw);
+                const uint32_t mask = c + 1 < tw ? 0xffffffffu : 0x0000ffffu;
+                const u16x2    x = __builtin_bit_cast(u16x2, *(const uint32_t *)&s[r * TW + c] & mask);
+                const u16x2    one = __builtin_bit_cast(u16x2, 0x00010001u & mask);
 #pragma unroll
                 for (int k = 0; k < WIN; k++) {
-                    const int32_t v = d[(r + k) * DP + c + c1];
-                    t[k] += (int32_t)__umul24((uint32_t)v, (uint32_t)x), f[k] += v;
+                    const u16x2 v = __builtin_bit_cast(u16x2, *(const uint32_t *)&ta[(r + k) * DP + c + c1]);
+                    t[k] = __builtin_amdgcn_udot2(v, x, t[k], false), f[k] = __builtin_amdgcn_udot2(v, one, f[k], false);
                 }
             }
 #pragma unroll
             for (int a = 0; a < WIN; a++) {
-                atomicAdd((unsigned long long *)&Ml[c1 * WIN + a], (unsigned long long)(long long)t[a]);
-                atomicAdd((unsigned long long *)&Sl[c1 * WIN + a], (unsigned long long)(long long)f[a]);
+                atomicAdd((unsigned long long *)&Ml[c1 * WIN + a], (unsigned long long)t[a]);
+                atomicAdd((unsigned long long *)&Sl[c1 * WIN + a], (unsigned long long)f[a]);
             }
         } else if (job == NPAIR + WIN) {
             long long ss = 0;
