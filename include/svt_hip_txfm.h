@@ -154,20 +154,18 @@ typedef struct SvtHipTxfmResult {
     uint64_t three_quad_energy; /* svt_handle_transformWxH return value (0 for sizes without a 64-point side) */
     uint16_t eob;
     uint16_t pad_;
-    uint32_t satd;            /* SVT_HIP_TX_SATD, else 0 */
-    uint64_t dist_residual;   /* svt_hip_txfm_distortion_batch: distortion[DIST_CALC_RESIDUAL] = sum (coeff - dqcoeff)^2 */
-    uint64_t dist_prediction; /*                                distortion[DIST_CALC_PREDICTION] = sum coeff^2; else 0 */
+    uint32_t satd; /* SVT_HIP_TX_SATD, else 0 */
 } SvtHipTxfmResult;
 
 SVT_HIP_API int32_t svt_hip_txfm_quant_batch(uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
                                              uint32_t n_blocks, uint32_t w, uint32_t h, void *stream);
 
 /* Transform-domain distortion of the same blocks, what svt_aom_full_loop_core reads right after the quantiser
- * (svt_aom_picture_full_distortion32_bits_single, pic_operators.c:150-234): for every descriptor with coeff_off and
- * dqcoeff_off set, result.dist_residual / dist_prediction over the dist_w x dist_h top-left area of the retained
- * coefficient block.  Run it after svt_hip_txfm_quant_batch on the same stream with the same arguments (that call
- * writes the coefficient arrays and zeroes the two fields). */
-SVT_HIP_API int32_t svt_hip_txfm_distortion_batch(const uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
+ * (svt_aom_picture_full_distortion32_bits_single, pic_operators.c:150-234): d_distortion[i] = {DIST_CALC_RESIDUAL =
+ * sum (coeff - dqcoeff)^2, DIST_CALC_PREDICTION = sum coeff^2} over the dist_w x dist_h top-left area of the retained
+ * coefficient block of descriptor i ({0, 0} when it has no coeff_off / dqcoeff_off).  Run it after
+ * svt_hip_txfm_quant_batch on the same stream with the same descriptors (that call writes the coefficient arrays). */
+SVT_HIP_API int32_t svt_hip_txfm_distortion_batch(const uint8_t *d_base, const SvtHipTxfmDesc *d_desc, uint64_t (*d_distortion)[2],
                                                   uint32_t n_blocks, uint32_t w, uint32_t h, void *stream);
 
 /* Stand-alone batched quantiser over device coefficient arrays (same descriptor; coeff_off is the INPUT). */

@@ -412,7 +412,6 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) 
         r.three_quad_energy = energy;
         r.eob               = (uint16_t)eob;
         r.pad_ = 0, r.satd = satd;
-        r.dist_residual = 0, r.dist_prediction = 0;  // filled by svt_hip_txfm_distortion_batch
         results[tb]                       = r;
     }
     // ---------------------------------------------------------------------- inverse: rows
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(uint8_t *__restrict__ bas
     __syncthreads();
     if (threadIdx.x == 0) {
         SvtHipTxfmResult r;
-        r.three_quad_energy = 0, r.eob = (uint16_t)s_eob, r.pad_ = 0, r.satd = 0, r.dist_residual = 0, r.dist_prediction = 0;
+        r.three_quad_energy = 0, r.eob = (uint16_t)s_eob, r.pad_ = 0, r.satd = 0;
         results[blockIdx.x] = r;
     }
 }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void full_distortion_kernel(const int32_t *__r
 
 // one wave per transform block: distortion of the stored coefficient / de-quantised arrays (row pitch = retained width)
 __global__ __launch_bounds__(256) void distortion_batch_kernel(const uint8_t *__restrict__ base, const SvtHipTxfmDesc *__restrict__ descs,
-                                                               SvtHipTxfmResult *__restrict__ results, uint32_t n, int iw, int ih) {
+                                                               uint64_t (*__restrict__ results)[2], uint32_t n, int iw, int ih) {
     const uint32_t tb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tb >= n)
         return;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void distortion_batch_kernel(const uint8_t *__
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64), b += __shfl_xor(b, off, 64);
     if (lane == 0)
-        results[tb].dist_residual = a, results[tb].dist_prediction = b;
+        results[tb][0] = a, results[tb][1] = b;
 }
 
 void fatal(const char *what) {
@@ -186,7 +186,7 @@ extern "C" void svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, u
     distortion_tier_a(coeff, coeff_stride, nullptr, 0, distortion_result, area_width, area_height);
 }
 
-extern "C" int32_t svt_hip_txfm_distortion_batch(const uint8_t *d_base, const SvtHipTxfmDesc *d_desc, SvtHipTxfmResult *d_result,
+extern "C" int32_t svt_hip_txfm_distortion_batch(const uint8_t *d_base, const SvtHipTxfmDesc *d_desc, uint64_t (*d_result)[2],
                                                  uint32_t n_blocks, uint32_t w, uint32_t h, void *stream) {
     const bool ok_w = w == 4 || w == 8 || w == 16 || w == 32 || w == 64, ok_h = h == 4 || h == 8 || h == 16 || h == 32 || h == 64;
     if (!d_base || !d_desc || !d_result || !ok_w || !ok_h) {

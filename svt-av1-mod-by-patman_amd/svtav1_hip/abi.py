@@ -157,7 +157,7 @@ SVT_HIP_ERR_BAD_PARAMETER = 0x80001005 - (1 << 32)
 SVT_HIP_ERR_RUNTIME = 0x80001001 - (1 << 32)
 QUANT_NONE, QUANT_B, QUANT_B_HBD, QUANT_FP, QUANT_FP_HBD = range(5)
 TX_FWD, TX_INV, TX_PIXEL16, TX_FULLCOEFF, TX_SRC_PRED, TX_SATD = 1, 2, 4, 8, 16, 32
-TXFM_RESULT_BYTES = 32
+TXFM_RESULT_BYTES = 16
 
 
 class TxfmDesc(C.Structure):
@@ -172,8 +172,7 @@ class TxfmDesc(C.Structure):
 
 
 class TxfmResult(C.Structure):
-    _fields_ = [("three_quad_energy", C.c_uint64), ("eob", C.c_uint16), ("pad_", C.c_uint16), ("satd", C.c_uint32),
-                ("dist_residual", C.c_uint64), ("dist_prediction", C.c_uint64)]
+    _fields_ = [("three_quad_energy", C.c_uint64), ("eob", C.c_uint16), ("pad_", C.c_uint16), ("satd", C.c_uint32)]
 
 
 class CdefList(C.Structure):
