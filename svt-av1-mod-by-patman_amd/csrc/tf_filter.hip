@@ -1,0 +1,176 @@
+// tf_filter.hip — the temporal filter's accumulate / normalise stage on gfx950.
+// Replaces svt_av1_apply_temporal_filter_planewise_medium_c / _hbd_c (temporal_filtering.c:999-1330),
+// svt_aom_apply_filtering_central_c / _highbd_c (:349-420) and svt_aom_get_final_filtered_pixels_c (:2578-2650).
+// One workgroup per 32x32 luma block (+ its chroma): the four quadrant squared-error sums by wave reductions, the four
+// fixed-point weights on one lane (sqrt_fast, the exp(-x/16) table), then every lane adds weight * prediction into the
+// accumulator and the weight into the counter.  Everything is 32-bit integer arithmetic as in the reference.
+#include <cmath>
+#include <mutex>
+
+#include "../../include/svt_hip_tf.h"
+#include "common.hpp"
+
+using namespace svthip;
+
+namespace {
+
+__constant__ uint32_t d_exp_fp16[113];  // 65536 * exp(-i / 16), truncated (the reference's expf_tab_fp16)
+__device__ const uint32_t SQRT_FP16[16] = {0,      65536,  92681,  113511, 131072, 146542, 160529, 173391,
+                                           185363, 196608, 207243, 217358, 227023, 236293, 245213, 253819};  // (uint32)(sqrt(i) * 65536)
+
+__device__ __forceinline__ uint32_t ldpx(const void *p, size_t i, int is16) {
+    return is16 ? ((const uint16_t *)p)[i] : ((const uint8_t *)p)[i];
+}
+__device__ __forceinline__ uint32_t sqrt_fast(uint32_t x) {  // temporal_filtering.c:705-714
+    if (x > 15) {
+        const int log2_half = (31 - __clz((int)x)) >> 1, mul2 = log2_half << 1;
+        return SQRT_FP16[x >> (mul2 - 2)] >> (17 - log2_half);
+    }
+    return SQRT_FP16[x] >> 16;
+}
+
+__global__ __launch_bounds__(256) void tf_accumulate_kernel(const SvtHipTfBlock *__restrict__ blocks) {
+    __shared__ SvtHipTfBlock b;
+    __shared__ uint32_t      qsum[4], luma_err[4], weight[4];
+    for (uint32_t i = threadIdx.x; i < sizeof(SvtHipTfBlock) / 4; i += 256) ((uint32_t *)&b)[i] = ((const uint32_t *)&blocks[blockIdx.x])[i];
+    __syncthreads();
+    const int is16 = b.is_16bit, shift = is16 ? (b.bit_depth - 8) * 2 : 0;
+    for (int pl = 0; pl < (b.chroma ? 3 : 1); pl++) {
+        const uint32_t bw = pl ? 32u >> b.ss_x : 32u, bh = pl ? 32u >> b.ss_y : 32u, hw = bw >> 1, hh = bh >> 1;
+        if (threadIdx.x < 4)
+            qsum[threadIdx.x] = 0;
+        __syncthreads();
+        // squared-error sums of the four quadrants (calculate_squared_errors_sum[_highbd])
+        uint32_t part[4] = {0, 0, 0, 0};
+        for (uint32_t i = threadIdx.x; i < bw * bh; i += 256) {
+            const uint32_t r = i / bw, c = i - r * bw;
+            const int32_t  d = (int32_t)ldpx(b.src[pl], (size_t)r * b.src_stride[pl] + c, is16) -
+                (int32_t)ldpx(b.pred[pl], (size_t)r * b.pred_stride[pl] + c, is16);
+            const uint32_t q = (r >= hh ? 2u : 0u) + (c >= hw ? 1u : 0u);
+            const uint32_t e = (uint32_t)(d * d);
+            part[0] += q == 0 ? e : 0, part[1] += q == 1 ? e : 0, part[2] += q == 2 ? e : 0, part[3] += q == 3 ? e : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t v = part[q];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if ((threadIdx.x & 63) == 0)
+                atomicAdd(&qsum[q], v);
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {  // one lane per quadrant: the weight (temporal_filtering.c:1009-1099)
+            const int      q = threadIdx.x, k = b.split ? q : 0;
+            const uint32_t th0 = (uint32_t)(((int)b.mv_dist_th << 16) / 10), dist_th = th0 > (1u << 16) ? th0 : (1u << 16);
+            const int32_t  col = b.mv_x[k], row = b.mv_y[k];
+            const uint32_t dist = sqrt_fast(((uint32_t)(col * col + row * row)) << 8);
+            uint32_t       d_factor = (dist << 12) / (dist_th >> 8);
+            d_factor                = d_factor > (1u << 8) ? d_factor : (1u << 8);
+            const uint32_t blk_err = b.split ? (uint32_t)(is16 ? b.block_error[q] >> 4 : b.block_error[q])
+                                             : (uint32_t)(b.block_error[0] >> (is16 ? 6 : 2));
+            const uint32_t decay = b.split ? b.decay_factor_fp16[pl] : b.decay_factor_fp16[pl] << 1;
+            uint32_t       win = ((((qsum[q] >> shift) << 4) / hw) << 4) / hh;
+            if (pl)
+                win = (win * 5 + luma_err[q]) / 6;
+            else
+                luma_err[q] = win;
+            const uint32_t combined = (win * 5 + blk_err) / 6;  // TF_WINDOW_BLOCK_BALANCE_WEIGHT = 5
+            const uint64_t avg_err  = (uint64_t)((combined >> 3) * (d_factor >> 3));
+            const uint32_t den = (decay >> 10) > 1 ? (decay >> 10) : 1;
+            uint32_t       sd  = (uint32_t)(avg_err / den);
+            sd                 = sd < 7 * 16 ? sd : 7 * 16;
+            weight[q]          = (d_exp_fp16[sd] * 1000u) >> 16;  // TF_WEIGHT_SCALE
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < bw * bh; i += 256) {
+            const uint32_t r = i / bw, c = i - r * bw;
+            const uint32_t w = weight[(r >= bh / 2 ? 2u : 0u) + (c >= bw / 2 ? 1u : 0u)];
+            const size_t   k = (size_t)r * b.pred_stride[pl] + c;
+            b.count[pl][k]   = (uint16_t)(b.count[pl][k] + w);
+            b.accum[pl][k] += w * ldpx(b.pred[pl], k, is16);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void tf_central_kernel(const SvtHipTfBlock *__restrict__ blocks) {
+    const SvtHipTfBlock &b = blocks[blockIdx.x];
+    for (int pl = 0; pl < (b.chroma ? 3 : 1); pl++) {
+        const uint32_t bw = pl ? 32u >> b.ss_x : 32u, bh = pl ? 32u >> b.ss_y : 32u;
+        for (uint32_t i = threadIdx.x; i < bw * bh; i += 256) {
+            const uint32_t r = i / bw, c = i - r * bw;
+            const size_t   k = (size_t)r * b.pred_stride[pl] + c;
+            b.accum[pl][k]   = 1000u * ldpx(b.src[pl], (size_t)r * b.src_stride[pl] + c, b.is_16bit);  // TF_PLANEWISE_FILTER_WEIGHT_SCALE
+            b.count[pl][k]   = 1000;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tf_normalise_kernel(const SvtHipTfBlock *__restrict__ blocks, const SvtHipTfOut *__restrict__ outs) {
+    const SvtHipTfBlock &b = blocks[blockIdx.x];
+    const SvtHipTfOut   &o = outs[blockIdx.x];
+    for (int pl = 0; pl < (b.chroma ? 3 : 1); pl++) {
+        const uint32_t bw = pl ? 32u >> b.ss_x : 32u, bh = pl ? 32u >> b.ss_y : 32u;
+        for (uint32_t i = threadIdx.x; i < bw * bh; i += 256) {
+            const uint32_t r = i / bw, c = i - r * bw;
+            const size_t   k = (size_t)r * b.pred_stride[pl] + c;
+            const uint32_t cnt = b.count[pl][k], v = cnt ? (b.accum[pl][k] + (cnt >> 1)) / cnt : 0;
+            if (b.is_16bit)
+                ((uint16_t *)o.dst[pl])[(size_t)r * o.dst_stride[pl] + c] = (uint16_t)v;
+            else
+                ((uint8_t *)o.dst[pl])[(size_t)r * o.dst_stride[pl] + c] = (uint8_t)v;
+        }
+    }
+}
+
+std::once_flag g_once;
+int32_t        g_rc = SVT_HIP_OK;
+void           upload() {
+    uint32_t tab[113];
+    for (int k = 0; k < 113; k++) tab[k] = (uint32_t)(65536.0 * exp(-k / 16.0));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_exp_fp16), tab, sizeof(tab)) != hipSuccess) {
+        set_error("uploading the temporal filter's weight table failed");
+        g_rc = SVT_HIP_ERR_RUNTIME;
+    }
+}
+int32_t ready(const void *p, uint32_t n, const char *who) {
+    if (!p || n == 0) {
+        set_error("%s: bad argument", who);
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    std::call_once(g_once, upload);
+    return g_rc;
+}
+
+}  // namespace
+
+extern "C" int32_t svt_hip_tf_accumulate_batch(const SvtHipTfBlock *d_blocks, uint32_t n_blocks, void *stream) {
+    const int32_t rc = ready(d_blocks, n_blocks, "svt_hip_tf_accumulate_batch");
+    if (rc != SVT_HIP_OK)
+        return rc;
+    hipLaunchKernelGGL(tf_accumulate_kernel, dim3(n_blocks), dim3(256), 0, resolve_stream(stream), d_blocks);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_tf_central_batch(const SvtHipTfBlock *d_blocks, uint32_t n_blocks, void *stream) {
+    const int32_t rc = ready(d_blocks, n_blocks, "svt_hip_tf_central_batch");
+    if (rc != SVT_HIP_OK)
+        return rc;
+    hipLaunchKernelGGL(tf_central_kernel, dim3(n_blocks), dim3(256), 0, resolve_stream(stream), d_blocks);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_tf_normalise_batch(const SvtHipTfBlock *d_blocks, const SvtHipTfOut *d_out, uint32_t n_blocks, void *stream) {
+    const int32_t rc = ready(d_blocks, n_blocks, "svt_hip_tf_normalise_batch");
+    if (rc != SVT_HIP_OK)
+        return rc;
+    if (!d_out) {
+        set_error("svt_hip_tf_normalise_batch: bad argument");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    hipLaunchKernelGGL(tf_normalise_kernel, dim3(n_blocks), dim3(256), 0, resolve_stream(stream), d_blocks, d_out);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}

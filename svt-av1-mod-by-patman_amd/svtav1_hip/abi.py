@@ -246,3 +246,15 @@ class ConvolveDesc(C.Structure):         # SvtHipConvolveDesc (include/svt_hip_i
                 ("round_0", C.c_uint8), ("round_1", C.c_uint8), ("bit_depth", C.c_uint8), ("is_16bit", C.c_uint8), ("compound", C.c_uint8),
                 ("fwd_offset", C.c_uint8), ("bck_offset", C.c_uint8), ("pad_", C.c_uint8 * 3), ("cbuf", C.c_void_p),
                 ("cbuf_stride", C.c_uint32), ("pad2_", C.c_uint32)]
+
+
+class TfBlock(C.Structure):              # SvtHipTfBlock (include/svt_hip_tf.h)
+    _fields_ = [("src", C.c_void_p * 3), ("pred", C.c_void_p * 3), ("accum", C.c_void_p * 3), ("count", C.c_void_p * 3),
+                ("src_stride", C.c_uint32 * 3), ("pred_stride", C.c_uint32 * 3), ("decay_factor_fp16", C.c_uint32 * 3),
+                ("block_error", C.c_uint64 * 4), ("mv_x", C.c_int16 * 4), ("mv_y", C.c_int16 * 4), ("mv_dist_th", C.c_uint16),
+                ("split", C.c_uint8), ("chroma", C.c_uint8), ("ss_x", C.c_uint8), ("ss_y", C.c_uint8), ("is_16bit", C.c_uint8),
+                ("bit_depth", C.c_uint8)]
+
+
+class TfOut(C.Structure):                # SvtHipTfOut
+    _fields_ = [("dst", C.c_void_p * 3), ("dst_stride", C.c_uint32 * 3), ("pad_", C.c_uint32)]

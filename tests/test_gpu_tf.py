@@ -1,0 +1,131 @@
+"""GPU parity: the temporal filter's accumulate / central / normalise stage (through the C-ABI) against the oracle and the
+golden vectors, bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import tf_cases as F
+from svtav1_hip import abi, device
+
+pytestmark = pytest.mark.gpu
+V = C.c_void_p
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf.npz")
+
+
+class DevBlocks:
+    """Device copies of a list of host block cases + the descriptor array pointing at them."""
+
+    def __init__(self, hip, cases):
+        self.hip, self.cases, self.bufs, descs = hip, cases, [], []
+        for b, a in cases:
+            d = abi.TfBlock.from_buffer_copy(b)
+            for pl in range(3):
+                row = []
+                for arr in a[pl]:
+                    db = device.DeviceBuffer(hip, arr.nbytes)
+                    db.upload(arr)
+                    row.append(db)
+                self.bufs.append(row)
+                d.src[pl], d.pred[pl], d.accum[pl], d.count[pl] = (x.ptr for x in row)
+            descs.append(d)
+        arr = (abi.TfBlock * len(descs))(*descs)
+        self.ddesc = device.DeviceBuffer(hip, C.sizeof(arr))
+        self.ddesc.upload(np.frombuffer(arr, np.uint8))
+        self.n = len(descs)
+
+    def planes(self, i, pl):
+        acc, cnt = self.bufs[3 * i + pl][2], self.bufs[3 * i + pl][3]
+        ref = self.cases[i][1][pl]
+        return acc.download(np.uint32, ref[2].shape), cnt.download(np.uint16, ref[3].shape)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_accumulate_batch(hip, orc, bd):
+    cases = [F.block_case(t, bd) for t in range(40)]
+    dev = DevBlocks(hip, cases)
+    device.check(hip, hip.svt_hip_tf_accumulate_batch(V(dev.ddesc.ptr), dev.n, None), "svt_hip_tf_accumulate_batch")
+    device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+    for i, (b, a) in enumerate(cases):
+        orc.orc_tf_accumulate(C.byref(b))
+        for pl in range(3):
+            acc, cnt = dev.planes(i, pl)
+            assert np.array_equal(acc, a[pl][2]) and np.array_equal(cnt, a[pl][3]), (i, pl)
+    assert hip.svt_hip_tf_accumulate_batch(None, 0, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+
+
+def test_golden(hip):
+    g = np.load(GOLD)
+    k = 0
+    for bd in (8, 10):
+        cases = [F.block_case(t, bd, seed=3) for t in range(8)]
+        dev = DevBlocks(hip, cases)
+        device.check(hip, hip.svt_hip_tf_accumulate_batch(V(dev.ddesc.ptr), dev.n, None), "svt_hip_tf_accumulate_batch")
+        device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+        for i in range(len(cases)):
+            for pl in range(3):
+                acc, cnt = dev.planes(i, pl)
+                n = cases[i][1][pl][0].shape[0]
+                assert np.array_equal(acc[:, :n], g[f"acc{k}_{pl}"]) and np.array_equal(cnt[:, :n], g[f"cnt{k}_{pl}"]), (k, pl)
+            k += 1
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_central_accumulate_normalise_chain(hip, orc, bd):
+    """The per-block pipeline of produce_temporally_filtered_pic: the centre picture's own weight, three reference
+    pictures accumulated one launch each, then the normalisation — against the same chain through the oracle."""
+    n_blk, n_ref = 24, 3
+    base = [F.block_case(t, bd, seed=11) for t in range(n_blk)]
+    dev = DevBlocks(hip, base)
+    device.check(hip, hip.svt_hip_tf_central_batch(V(dev.ddesc.ptr), dev.n, None), "svt_hip_tf_central_batch")
+    for b, _ in base:
+        orc.orc_tf_central(C.byref(b))
+    for r in range(n_ref):
+        preds = [F.block_case(t, bd, seed=20 + r) for t in range(n_blk)]     # another reference: new predictions / MVs / errors
+        keep = []
+        for i, ((b, a), (pb, pa)) in enumerate(zip(base, preds)):
+            for pl in range(3):
+                a[pl][1][:] = pa[pl][1]                                       # host prediction for the oracle
+                dev.bufs[3 * i + pl][1].upload(pa[pl][1])
+            for f in ("split", "mv_dist_th"):
+                setattr(b, f, getattr(pb, f))
+            for k in range(4):
+                b.mv_x[k], b.mv_y[k], b.block_error[k] = pb.mv_x[k], pb.mv_y[k], pb.block_error[k]
+            keep.append(pa)
+        descs = []
+        for i, (b, a) in enumerate(base):
+            d = abi.TfBlock.from_buffer_copy(b)
+            for pl in range(3):
+                d.src[pl], d.pred[pl], d.accum[pl], d.count[pl] = (x.ptr for x in dev.bufs[3 * i + pl])
+            descs.append(d)
+        arr = (abi.TfBlock * n_blk)(*descs)
+        dev.ddesc.upload(np.frombuffer(arr, np.uint8))
+        device.check(hip, hip.svt_hip_tf_accumulate_batch(V(dev.ddesc.ptr), n_blk, None), "svt_hip_tf_accumulate_batch")
+        device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+        for b, _ in base:
+            orc.orc_tf_accumulate(C.byref(b))
+    dt = np.uint16 if bd > 8 else np.uint8
+    outs_h, outs_d, odesc, odesc_h = [], [], [], []
+    for i in range(n_blk):
+        oh, od = abi.TfOut(), abi.TfOut()
+        for pl in range(3):
+            n = 32 if pl == 0 else 16
+            hbuf = np.zeros((n, n + 6), dt)
+            dbuf = device.DeviceBuffer(hip, hbuf.nbytes)
+            dbuf.fill(0)
+            outs_h.append(hbuf), outs_d.append(dbuf)
+            oh.dst[pl], od.dst[pl], oh.dst_stride[pl], od.dst_stride[pl] = hbuf.ctypes.data, dbuf.ptr, n + 6, n + 6
+        odesc.append(od), odesc_h.append(oh)
+    oarr = (abi.TfOut * n_blk)(*odesc)
+    dout = device.DeviceBuffer(hip, C.sizeof(oarr))
+    dout.upload(np.frombuffer(oarr, np.uint8))
+    device.check(hip, hip.svt_hip_tf_normalise_batch(V(dev.ddesc.ptr), V(dout.ptr), n_blk, None), "svt_hip_tf_normalise_batch")
+    device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+    for i, (b, a) in enumerate(base):
+        orc.orc_tf_normalise(C.byref(b), C.byref(odesc_h[i]))
+        for pl in range(3 if b.chroma else 1):
+            acc, cnt = dev.planes(i, pl)
+            assert np.array_equal(acc, a[pl][2]) and np.array_equal(cnt, a[pl][3]), ("accum", i, pl)
+            got = outs_d[3 * i + pl].download(dt, outs_h[3 * i + pl].shape)
+            assert np.array_equal(got, outs_h[3 * i + pl]), ("pixels", i, pl)
