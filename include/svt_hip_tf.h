@@ -2,9 +2,9 @@
  * svt_hip_tf.h — C-ABI for the temporal filter's accumulate / normalise stage.
  *
  * Reference interfaces replaced (paths relative to /root/reference):
- *   Source/Lib/Codec/aom_dsp_rtcd.h:810-835        svt_av1_apply_temporal_filter_planewise_medium(_hbd),
+ *   Source/Lib/Codec/aom_dsp_rtcd.h:795-835        svt_av1_apply_[zz_based_]temporal_filter_planewise_medium(_hbd),
  *                                                  apply_filtering_central(_highbd), get_final_filtered_pixels
- *   Source/Lib/Codec/temporal_filtering.c:349-420, 999-1330, 2578-2650   their C implementations
+ *   Source/Lib/Codec/temporal_filtering.c:349-420, 789-997, 999-1330, 2578-2650   their C implementations
  *   caller: tf_16x16 / tf_32x32 loop of produce_temporally_filtered_pic (temporal_filtering.c:3075-3460)
  *
  * The reference's leaves take `struct MeContext *` and read ten of its fields; the control structure does not cross
@@ -39,6 +39,9 @@ typedef struct SvtHipTfBlock {
     uint8_t     chroma;                        /* me_ctx->tf_chroma */
     uint8_t     ss_x, ss_y;
     uint8_t     is_16bit, bit_depth;           /* 8 / 10 / 12: svt_av1_apply_temporal_filter_planewise_medium_hbd's encoder_bit_depth */
+    uint8_t     zz_based;                      /* 1: svt_av1_apply_zz_based_temporal_filter_planewise_medium[_hbd] (the weight comes from
+                                                * the block error alone; src, mv_*, mv_dist_th are not read) */
+    uint8_t     pad_[7];
 } SvtHipTfBlock;
 
 /* accum += w * pred, count += w with the per-quadrant weights of the planewise "medium" filter

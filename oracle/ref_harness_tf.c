@@ -42,7 +42,15 @@ REF_API int ref_tf_block_accumulate(const SvtHipTfBlock *b) {
     MeContext *me = ctx_of(b);
     if (!me)
         return -2;
-    if (b->is_16bit)
+    if (b->zz_based && b->is_16bit)
+        svt_av1_apply_zz_based_temporal_filter_planewise_medium_hbd(me, b->pred[0], (int)b->pred_stride[0], b->pred[1], b->pred[2],
+                                                                    (int)b->pred_stride[1], 32, 32, b->ss_x, b->ss_y, b->accum[0], b->count[0],
+                                                                    b->accum[1], b->count[1], b->accum[2], b->count[2], b->bit_depth);
+    else if (b->zz_based)
+        svt_av1_apply_zz_based_temporal_filter_planewise_medium(me, b->pred[0], (int)b->pred_stride[0], b->pred[1], b->pred[2],
+                                                                (int)b->pred_stride[1], 32, 32, b->ss_x, b->ss_y, b->accum[0], b->count[0],
+                                                                b->accum[1], b->count[1], b->accum[2], b->count[2]);
+    else if (b->is_16bit)
         svt_av1_apply_temporal_filter_planewise_medium_hbd(me, b->src[0], (int)b->src_stride[0], b->pred[0], (int)b->pred_stride[0], b->src[1],
                                                            b->src[2], (int)b->src_stride[1], b->pred[1], b->pred[2], (int)b->pred_stride[1], 32,
                                                            32, b->ss_x, b->ss_y, b->accum[0], b->count[0], b->accum[1], b->count[1],

@@ -92,8 +92,35 @@ static void plane(const SvtHipTfBlock *b, int pl, uint32_t bw, uint32_t bh, uint
     }
 }
 
+/* svt_av1_apply_zz_based_temporal_filter_planewise_medium_partial_c / _hbd (temporal_filtering.c:789-835, 890-940) */
+static void plane_zz(const SvtHipTfBlock *b, int pl, uint32_t bw, uint32_t bh) {
+    const int      is16 = b->is_16bit;
+    const uint32_t decay = b->decay_factor_fp16[pl];
+    for (int q = 0; q < 4; q++) {
+        const uint32_t blk_err = b->split ? (uint32_t)(is16 ? b->block_error[q] >> 4 : b->block_error[q])
+                                          : (uint32_t)(b->block_error[0] >> (is16 ? 6 : 2));
+        const uint32_t avg_err = blk_err << 2, den = (decay >> 10) > 1 ? (decay >> 10) : 1;
+        uint32_t       sd = avg_err / den;
+        sd                = sd < 7 * 16 ? sd : 7 * 16;
+        const uint32_t w  = (exp_fp16(sd) * TF_WEIGHT_SCALE) >> 17;
+        const uint32_t x0 = (q & 1) * bw / 2, y0 = (q >> 1) * bh / 2;
+        for (uint32_t i = 0; i < bh / 2; i++)
+            for (uint32_t j = 0; j < bw / 2; j++) {
+                const size_t k = (size_t)(i + y0) * b->pred_stride[pl] + j + x0;
+                b->count[pl][k] = (uint16_t)(b->count[pl][k] + w);
+                b->accum[pl][k] += w * px(b->pred[pl], k, is16);
+            }
+    }
+}
+
 ORC_API void orc_tf_accumulate(const SvtHipTfBlock *b) {
     uint32_t luma_err[4];
+    if (b->zz_based) {
+        plane_zz(b, 0, 32, 32);
+        if (b->chroma)
+            plane_zz(b, 1, 32u >> b->ss_x, 32u >> b->ss_y), plane_zz(b, 2, 32u >> b->ss_x, 32u >> b->ss_y);
+        return;
+    }
     plane(b, 0, 32, 32, luma_err);
     if (b->chroma) {
         plane(b, 1, 32u >> b->ss_x, 32u >> b->ss_y, luma_err);

@@ -40,9 +40,10 @@ __global__ __launch_bounds__(256) void tf_accumulate_kernel(const SvtHipTfBlock 
         if (threadIdx.x < 4)
             qsum[threadIdx.x] = 0;
         __syncthreads();
-        // squared-error sums of the four quadrants (calculate_squared_errors_sum[_highbd])
+        // squared-error sums of the four quadrants (calculate_squared_errors_sum[_highbd]); the zero-motion variant does
+        // not look at the picture
         uint32_t part[4] = {0, 0, 0, 0};
-        for (uint32_t i = threadIdx.x; i < bw * bh; i += 256) {
+        for (uint32_t i = threadIdx.x; i < (b.zz_based ? 0u : bw * bh); i += 256) {
             const uint32_t r = i / bw, c = i - r * bw;
             const int32_t  d = (int32_t)ldpx(b.src[pl], (size_t)r * b.src_stride[pl] + c, is16) -
                 (int32_t)ldpx(b.pred[pl], (size_t)r * b.pred_stride[pl] + c, is16);
@@ -68,6 +69,12 @@ __global__ __launch_bounds__(256) void tf_accumulate_kernel(const SvtHipTfBlock 
             d_factor                = d_factor > (1u << 8) ? d_factor : (1u << 8);
             const uint32_t blk_err = b.split ? (uint32_t)(is16 ? b.block_error[q] >> 4 : b.block_error[q])
                                              : (uint32_t)(b.block_error[0] >> (is16 ? 6 : 2));
+            if (b.zz_based) {  // svt_av1_apply_zz_based_temporal_filter_planewise_medium_partial_c (:789-835, 890-940)
+                const uint32_t den = (b.decay_factor_fp16[pl] >> 10) > 1 ? (b.decay_factor_fp16[pl] >> 10) : 1;
+                uint32_t       sd  = (blk_err << 2) / den;
+                sd                 = sd < 7 * 16 ? sd : 7 * 16;
+                weight[q]          = (d_exp_fp16[sd] * 1000u) >> 17;
+            } else {
             const uint32_t decay = b.split ? b.decay_factor_fp16[pl] : b.decay_factor_fp16[pl] << 1;
             uint32_t       win = ((((qsum[q] >> shift) << 4) / hw) << 4) / hh;
             if (pl)
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(256) void tf_accumulate_kernel(const SvtHipTfBlock 
             uint32_t       sd  = (uint32_t)(avg_err / den);
             sd                 = sd < 7 * 16 ? sd : 7 * 16;
             weight[q]          = (d_exp_fp16[sd] * 1000u) >> 16;  // TF_WEIGHT_SCALE
+            }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < bw * bh; i += 256) {

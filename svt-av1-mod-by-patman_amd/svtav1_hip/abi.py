@@ -253,7 +253,7 @@ class TfBlock(C.Structure):              # SvtHipTfBlock (include/svt_hip_tf.h)
                 ("src_stride", C.c_uint32 * 3), ("pred_stride", C.c_uint32 * 3), ("decay_factor_fp16", C.c_uint32 * 3),
                 ("block_error", C.c_uint64 * 4), ("mv_x", C.c_int16 * 4), ("mv_y", C.c_int16 * 4), ("mv_dist_th", C.c_uint16),
                 ("split", C.c_uint8), ("chroma", C.c_uint8), ("ss_x", C.c_uint8), ("ss_y", C.c_uint8), ("is_16bit", C.c_uint8),
-                ("bit_depth", C.c_uint8)]
+                ("bit_depth", C.c_uint8), ("zz_based", C.c_uint8), ("pad_", C.c_uint8 * 7)]
 
 
 class TfOut(C.Structure):                # SvtHipTfOut

@@ -41,4 +41,5 @@ def block_case(trial, bd, seed=0):
         b.mv_x[0] = b.mv_y[0] = 0
     b.mv_dist_th = int(rng.choice([1, 16, 64, 300]))
     b.chroma, b.ss_x, b.ss_y, b.is_16bit, b.bit_depth = int(trial % 3 != 2), ss, ss, int(is16), bd
+    b.zz_based = int(trial % 4 == 3)
     return b, arrs
