@@ -30,6 +30,14 @@ __device__ const int16_t DIRS_D[12][2] = {{1 * BS + 0, 2 * BS + 0},  {1 * BS + 0
                                           {1 * BS + 1, 2 * BS + 2},  {1 * BS + 0, 2 * BS + 1}, {1 * BS + 0, 2 * BS + 0},
                                           {1 * BS + 0, 2 * BS - 1},  {-1 * BS + 1, -2 * BS + 2}, {0 * BS + 1, -1 * BS + 2}};
 
+// the batched kernels keep their tile at a tighter pitch than the reference's CDEF_BSTRIDE (two copies of the tile have to fit
+// LDS several times over): same direction table, other row pitch
+constexpr int TS = 64 + 2 * HB + 8;  // 88 samples per tile row
+__device__ const int16_t DIRS_T[12][2] = {{1 * TS + 0, 2 * TS + 0},  {1 * TS + 0, 2 * TS - 1}, {-1 * TS + 1, -2 * TS + 2},
+                                          {0 * TS + 1, -1 * TS + 2}, {0 * TS + 1, 0 * TS + 2}, {0 * TS + 1, 1 * TS + 2},
+                                          {1 * TS + 1, 2 * TS + 2},  {1 * TS + 0, 2 * TS + 1}, {1 * TS + 0, 2 * TS + 0},
+                                          {1 * TS + 0, 2 * TS - 1},  {-1 * TS + 1, -2 * TS + 2}, {0 * TS + 1, -1 * TS + 2}};
+
 __device__ __forceinline__ int32_t constrain(int32_t diff, int32_t threshold, int32_t damping) {
     if (!threshold)
         return 0;
@@ -74,6 +82,54 @@ __device__ __forceinline__ int32_t cdef_pixel(const uint16_t *p, int pri_strengt
     }
     int32_t y = (int32_t)x + ((8 + sum - (sum < 0)) >> 4);
     return y < mn ? mn : (y > mx ? mx : y);
+}
+
+// ---- two horizontally adjacent samples at once, in packed 16-bit arithmetic (v_pk_*_i16).  Every quantity of
+// svt_cdef_filter_block_c is an int16 by construction (samples, CDEF_VERY_LARGE = 30000, differences, the int16 `sum`), so
+// the packed evaluation is the reference's arithmetic lane by lane.  `p0` points at the even-indexed first sample of the
+// pair in the tile, `p1` at the same position of the tile shifted left by one sample: a tap at an odd offset is read from
+// the shifted copy, so that every tap pair is one aligned 32-bit LDS read.
+typedef short          s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 splat2(int v) { return (s16x2)((short)v); }
+__device__ __forceinline__ s16x2 ldpair(const uint16_t *p0, const uint16_t *p1, int o) {
+    return __builtin_bit_cast(s16x2, *(const uint32_t *)((o & 1) ? p1 + (o - 1) : p0 + o));
+}
+// constrain() for a pair; threshold 0 gives 0 without a branch (min(|d|, max(0, 0 - (|d| >> shift))) = 0)
+__device__ __forceinline__ s16x2 constrain2(s16x2 d, int threshold, int shift) {
+    const s16x2 ad = __builtin_elementwise_max(d, -d);
+    s16x2       t  = splat2(threshold) - (s16x2)((u16x2)ad >> (u16x2)((unsigned short)shift));
+    t              = __builtin_elementwise_max(t, splat2(0));
+    const s16x2 m  = __builtin_elementwise_min(ad, t);
+    const s16x2 sg = d >> (s16x2)((short)15);
+    return (m ^ sg) - sg;
+}
+__device__ __forceinline__ int constrain_shift(int threshold, int damping) { return threshold ? imax(0, damping - msb((unsigned)threshold)) : 0; }
+__device__ __forceinline__ s16x2 cdef_pair(const uint16_t *p0, const uint16_t *p1, int pri_strength, int sec_strength, int dir, int pri_damping,
+                                           int sec_damping, int coeff_shift) {
+    const int   tsel = (pri_strength >> coeff_shift) & 1;
+    const int   shp = constrain_shift(pri_strength, pri_damping), shs = constrain_shift(sec_strength, sec_damping);
+    const s16x2 x = __builtin_bit_cast(s16x2, *(const uint32_t *)p0);
+    s16x2       sum = splat2(0), mx = x, mn = x;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int pt = k ? (tsel ? 3 : 2) : (tsel ? 3 : 4), st = k ? 1 : 2;
+        const int o0 = DIRS_T[dir + 2][k], o1 = DIRS_T[dir + 4][k], o2 = DIRS_T[dir][k];
+        const s16x2 t[6] = {ldpair(p0, p1, o0), ldpair(p0, p1, -o0), ldpair(p0, p1, o1), ldpair(p0, p1, -o1), ldpair(p0, p1, o2), ldpair(p0, p1, -o2)};
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const s16x2 c = q < 2 ? constrain2(t[q] - x, pri_strength, shp) : constrain2(t[q] - x, sec_strength, shs);
+            sum += splat2(q < 2 ? pt : st) * c;
+            // CDEF_VERY_LARGE (bit 14 set, no sample has it) does not take part in the maximum: clear those lanes
+            const s16x2 vl = -(s16x2)((u16x2)t[q] >> (u16x2)((unsigned short)14));
+            mx = __builtin_elementwise_max(mx, t[q] & ~vl);
+            mn = __builtin_elementwise_min(mn, t[q]);
+        }
+    }
+    const s16x2 neg = (s16x2)((u16x2)sum >> (u16x2)((unsigned short)15));  // sum < 0
+    s16x2       y   = x + ((splat2(8) + sum - neg) >> (s16x2)((short)4));
+    y               = __builtin_elementwise_max(y, mn);
+    return __builtin_elementwise_min(y, mx);
 }
 
 // svt_aom_cdef_find_dir_c (cdef.c:150-210) for one 8x8 block, one thread.
@@ -137,12 +193,14 @@ __device__ __forceinline__ uint32_t load_px(const void *p, size_t idx, int is16)
 }
 
 struct FbLds {
-    uint16_t       tile[TILE_ROWS * BS];
+    __attribute__((aligned(4))) uint16_t tile[TILE_ROWS * TS];
+    __attribute__((aligned(4))) uint16_t tile1[TILE_ROWS * TS];  // tile shifted left by one sample (cdef_pair)
     SvtHipCdefList dl[64];
     uint8_t        dir[64];
     int32_t        var[64];
     unsigned long long total;
     int            n;
+    uint32_t       bsum[64][5];  // search: per-block sums of the luma distortion
 };
 
 // stage tile + dlist; returns cdef_count (uniform).  Contains barriers.
@@ -164,7 +222,9 @@ __device__ int stage_fb(FbLds &S, const SvtHipCdefPlane &pl, const uint8_t *filt
         uint16_t  v  = VL;
         if (py >= 0 && px >= 0 && py < (int)pl.height && px < (int)pl.width)
             v = (uint16_t)load_px(pl.recon, (size_t)py * pl.recon_stride + px, pl.is_16bit);
-        S.tile[ry * BS + rx] = v;
+        S.tile[ry * TS + rx] = v;
+        if (ry * TS + rx)
+            S.tile1[ry * TS + rx - 1] = v;
     }
     __syncthreads();
     return S.n;
@@ -178,7 +238,7 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
     const int n  = stage_fb(S, pl, filt, fbx, fby);
     if (n == 0)
         return;
-    const uint16_t *in = S.tile + VB * BS + HB;
+    const uint16_t *in = S.tile + VB * TS + HB;
     const int       bwl = 3 - pl.xdec, bhl = 3 - pl.ydec, bw = 1 << bwl, bh = 1 << bhl;
     const int       bsize = pl.ydec ? (pl.xdec ? 0 : 2) : (pl.xdec ? 1 : 3);
     int             sub   = prm.subsampling_factor;
@@ -188,7 +248,7 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
         const int by = S.dl[threadIdx.x].by, bx = S.dl[threadIdx.x].bx;
         if (pl.pli == 0) {
             int32_t   v;
-            const int d = find_dir_block(in + 8 * by * BS + 8 * bx, BS, &v, prm.coeff_shift);
+            const int d = find_dir_block(in + 8 * by * TS + 8 * bx, TS, &v, prm.coeff_shift);
             S.dir[by * 8 + bx] = (uint8_t)d, S.var[by * 8 + bx] = v;
             gdir[(size_t)fb * 64 + by * 8 + bx] = (uint8_t)d, gvar[(size_t)fb * 64 + by * 8 + bx] = v;
         } else {
@@ -204,7 +264,7 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
     // this thread's items and their source samples stay in registers across all strengths
     int      it_by[KMAX], it_bx[KMAX], it_i[KMAX], it_bi[KMAX];
     bool     it_on[KMAX];
-    uint16_t srcpx[KMAX][8];
+    uint32_t srcpx[KMAX][4];  // pairs of source samples
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
         const int item = threadIdx.x + k * 256;
@@ -212,11 +272,13 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
         const int bi = it_on[k] ? item / rows : 0, r = item - (item / rows) * rows;
         it_bi[k] = bi, it_by[k] = S.dl[bi].by, it_bx[k] = S.dl[bi].bx, it_i[k] = r * sub;
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            srcpx[k][j] = (it_on[k] && j < bw)
-                ? (uint16_t)load_px(pl.source, soff + (size_t)((it_by[k] << bhl) + it_i[k]) * pl.source_stride + (it_bx[k] << bwl) + j, pl.is_16bit)
-                : (uint16_t)0;
+        for (int j = 0; j < 8; j += 2) {
+            const size_t at = soff + (size_t)((it_by[k] << bhl) + it_i[k]) * pl.source_stride + (it_bx[k] << bwl) + j;
+            srcpx[k][j >> 1] = (it_on[k] && j < bw) ? (load_px(pl.source, at, pl.is_16bit) | (load_px(pl.source, at + 1, pl.is_16bit) << 16)) : 0u;
+        }
     }
+    const uint16_t *in1 = S.tile1 + VB * TS + HB;
+    const u16x2     ones = {1, 1};
     const bool luma8 = bsize == 3 && pl.pli == 0;
     for (int gi = 0; gi < prm.n_strengths; gi++) {
         if (prm.strengths[gi] < 0)
@@ -236,26 +298,28 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
             uint32_t s_y = 0, s_o = 0, s_yy = 0, s_oo = 0, s_yo = 0;  // luma: the five sums; otherwise s_yy = sum of e^2
             if (it_on[k]) {
                 const int       by = it_by[k], bx = it_bx[k];
-                const uint16_t *p  = in + ((by << bhl) + it_i[k]) * BS + (bx << bwl);
+                const int       at = ((by << bhl) + it_i[k]) * TS + (bx << bwl);
                 const int       t  = pl.pli ? pri_s : adjust_strength(pri_s, S.var[by * 8 + bx]);
                 const int       dd = pri_s ? S.dir[by * 8 + bx] : 0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < 8; j += 2) {  // two samples per step
                     if (j >= bw)
                         break;
-                    int32_t y;
-                    if (pri_s == 0 && sec_s == 0) {
-                        y = pl.is_16bit ? p[j] : (uint8_t)p[j];
-                    } else {
-                        y = cdef_pixel(p + j, t, sec_s, dd, pd, sd, prm.coeff_shift);
-                        y = pl.is_16bit ? (uint16_t)(int16_t)y : (uint8_t)(int16_t)y;
-                    }
-                    const int32_t o = srcpx[k][j];
+                    uint32_t yb;
+                    if (pri_s == 0 && sec_s == 0)
+                        yb = *(const uint32_t *)(in + at + j);
+                    else
+                        yb = __builtin_bit_cast(uint32_t, cdef_pair(in + at + j, in1 + at + j, t, sec_s, dd, pd, sd, prm.coeff_shift));
+                    if (!pl.is_16bit)
+                        yb &= 0x00ff00ffu;  // (uint8_t)(int16_t)y
+                    const u16x2 y = __builtin_bit_cast(u16x2, yb), o = __builtin_bit_cast(u16x2, srcpx[k][j >> 1]);
                     if (luma8) {
-                        s_y += (uint32_t)y, s_o += (uint32_t)o, s_yy += (uint32_t)(y * y), s_oo += (uint32_t)(o * o), s_yo += (uint32_t)(y * o);
+                        s_y = __builtin_amdgcn_udot2(y, ones, s_y, false), s_o = __builtin_amdgcn_udot2(o, ones, s_o, false);
+                        s_yy = __builtin_amdgcn_udot2(y, y, s_yy, false), s_oo = __builtin_amdgcn_udot2(o, o, s_oo, false);
+                        s_yo = __builtin_amdgcn_udot2(y, o, s_yo, false);
                     } else {
-                        const int32_t e = o - y;
-                        s_yy += (uint32_t)(e * e);
+                        const s16x2 e = __builtin_bit_cast(s16x2, o) - __builtin_bit_cast(s16x2, y);
+                        s_yy          = (uint32_t)__builtin_amdgcn_sdot2(e, e, (int)s_yy, false);
                     }
                 }
             }
@@ -267,8 +331,21 @@ __global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, co
                     s_oo += __shfl_down(s_oo, off, 64), s_yo += __shfl_down(s_yo, off, 64);
                 }
             }
-            if (it_on[k] && it_i[k] == 0)
-                acc += luma8 ? dist_8xn(s_y, s_o, s_yy, s_oo, s_yo, prm.coeff_shift) : (unsigned long long)s_yy;
+            if (it_on[k] && it_i[k] == 0) {
+                if (luma8) {  // the five sums of this block; the double-precision distortion is evaluated block-parallel below
+                    uint32_t *bs = S.bsum[it_bi[k]];
+                    bs[0] = s_y, bs[1] = s_o, bs[2] = s_yy, bs[3] = s_oo, bs[4] = s_yo;
+                } else {
+                    acc += (unsigned long long)s_yy;
+                }
+            }
+        }
+        if (luma8) {  // one lane per 8x8 block instead of one in eight lanes of every wave
+            __syncthreads();
+            if ((int)threadIdx.x < n) {
+                const uint32_t *bs = S.bsum[threadIdx.x];
+                acc                = dist_8xn(bs[0], bs[1], bs[2], bs[3], bs[4], prm.coeff_shift);
+            }
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if ((threadIdx.x & 63) == 0)
@@ -295,25 +372,35 @@ __global__ __launch_bounds__(256) void cdef_apply_kernel(SvtHipCdefPlane pl, con
     if (active && (int)threadIdx.x < n)
         on[S.dl[threadIdx.x].by * 8 + S.dl[threadIdx.x].bx] = 1;
     __syncthreads();
-    const uint16_t *in = S.tile + VB * BS + HB;
+    const uint16_t *in = S.tile + VB * TS + HB;
     const int       bwl = 3 - pl.xdec, bhl = 3 - pl.ydec;
     const int       fw = 64 >> pl.xdec, fh = 64 >> pl.ydec;
     const int       pri_s = pri << coeff_shift, sec_s = sec << coeff_shift, dmp = damping + coeff_shift - (pl.pli != 0);
-    for (int idx = threadIdx.x; idx < fw * fh; idx += blockDim.x) {
-        const int y = idx / fw, x = idx - y * fw;
+    const uint16_t *in1 = S.tile1 + VB * TS + HB;
+    for (int idx = threadIdx.x; idx < (fw >> 1) * fh; idx += blockDim.x) {  // two samples per step
+        const int y = idx / (fw >> 1), x = 2 * (idx - y * (fw >> 1));
         const int py = fby * fh + y, px = fbx * fw + x;
         if (py >= (int)pl.height || px >= (int)pl.width)
             continue;
         const int by = y >> bhl, bx = x >> bwl;
-        int32_t   v  = in[y * BS + x];
+        uint32_t  v  = *(const uint32_t *)(in + y * TS + x);
         if (on[by * 8 + bx]) {
             const int t = pl.pli ? pri_s : adjust_strength(pri_s, gvar[(size_t)fb * 64 + by * 8 + bx]);
-            v           = cdef_pixel(in + y * BS + x, t, sec_s, pri_s ? gdir[(size_t)fb * 64 + by * 8 + bx] : 0, dmp, dmp, coeff_shift);
+            v = __builtin_bit_cast(uint32_t, cdef_pair(in + y * TS + x, in1 + y * TS + x, t, sec_s, pri_s ? gdir[(size_t)fb * 64 + by * 8 + bx] : 0,
+                                                       dmp, dmp, coeff_shift));
         }
-        if (pl.is_16bit)
-            ((uint16_t *)pl.source)[(size_t)py * pl.source_stride + px] = (uint16_t)(int16_t)v;
-        else
-            ((uint8_t *)pl.source)[(size_t)py * pl.source_stride + px] = (uint8_t)(int16_t)v;
+        const bool two = px + 1 < (int)pl.width;
+        if (pl.is_16bit) {
+            uint16_t *o = (uint16_t *)pl.source + (size_t)py * pl.source_stride + px;
+            o[0]        = (uint16_t)v;
+            if (two)
+                o[1] = (uint16_t)(v >> 16);
+        } else {
+            uint8_t *o = (uint8_t *)pl.source + (size_t)py * pl.source_stride + px;
+            o[0]       = (uint8_t)v;
+            if (two)
+                o[1] = (uint8_t)(v >> 16);
+        }
     }
 }
 
