@@ -34,7 +34,7 @@ namespace {
 // LDS window buffers.  The pre-HME / HME level 0 / level 1 stages search down-scaled pictures and do not need the full
 // resolution source block, so their window buffer also covers it (and the full-pel bookkeeping); the block is staged again
 // before the first full resolution stage.  Bigger windows than the buffer: several passes.
-constexpr uint32_t ME_HME_WIN_DW = 6080;                          // 23.75 KiB: pre-HME, HME level 0 / 1
+constexpr uint32_t ME_HME_WIN_DW = 4720;                          // 18.4 KiB: pre-HME, HME level 0 / 1 (6 workgroups per CU)
 constexpr uint32_t ME_WIN_DW     = ME_HME_WIN_DW - 64 * 16 - 256;  // HME level 2 and full-pel
 constexpr uint32_t FP_TILE_W   = 64;    // widest full-pel tile staged at once (positions)
 
@@ -1243,7 +1243,7 @@ __device__ void finalize_b64(LDS &L, const Ctx &c) {
 // ------------------------------------------------------------------------------------------------
 // One launch, one workgroup per b64: all stages back to back.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS, 5) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
+__global__ __launch_bounds__(WG_THREADS, 6) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
     __shared__ MeLds L;
 #ifdef SVT_HIP_ME_PROFILE
     unsigned long long prof_last = wall_clock64();
