@@ -34,9 +34,13 @@ namespace {
 // LDS window buffers.  The pre-HME / HME level 0 / level 1 stages search down-scaled pictures and do not need the full
 // resolution source block, so their window buffer also covers it (and the full-pel bookkeeping); the block is staged again
 // before the first full resolution stage.  Bigger windows than the buffer: several passes.
-constexpr uint32_t ME_HME_WIN_DW = 4720;                          // 18.4 KiB: pre-HME, HME level 0 / 1 (6 workgroups per CU)
+constexpr uint32_t ME_HME_WIN_DW = 3200;                          // 12.5 KiB: pre-HME, HME level 0 / 1 (8 workgroups per CU)
 constexpr uint32_t ME_WIN_DW     = ME_HME_WIN_DW - 64 * 16 - 256;  // HME level 2 and full-pel
-constexpr uint32_t FP_TILE_W   = 64;    // widest full-pel tile staged at once (positions)
+constexpr uint32_t fp_pitch_c(uint32_t tw) { return (((tw + 3) >> 2) + 17) | 1u; }  // = fp_pitch()
+// widest full-pel tile staged at once (positions): the tile's window — (rows of positions + 63) x fp_pitch(width) dwords —
+// must hold at least a few rows of positions
+constexpr uint32_t FP_TILE_W = ME_WIN_DW / fp_pitch_c(64) >= 63 + 8 ? 64 : 32;
+static_assert(ME_WIN_DW / fp_pitch_c(FP_TILE_W) >= 63 + 8, "full-pel window buffer too small for one tile");
 
 struct PreHme {
     uint64_t sad;
@@ -1243,7 +1247,7 @@ __device__ void finalize_b64(LDS &L, const Ctx &c) {
 // ------------------------------------------------------------------------------------------------
 // One launch, one workgroup per b64: all stages back to back.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS, 6) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
+__global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
     __shared__ MeLds L;
 #ifdef SVT_HIP_ME_PROFILE
     unsigned long long prof_last = wall_clock64();
