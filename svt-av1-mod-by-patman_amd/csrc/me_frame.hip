@@ -498,7 +498,6 @@ struct Ctx {
     uint32_t  b64, org_x, org_y, b64_w, b64_h, aw, ah;
     bool      hme_sub, me_sub;
     int       tl, nlists, R0, R1, nref;
-    uint32_t *gs, *gm;  // p_sb_best_sad / p_sb_best_mv of this b64 (in the output arrays)
 };
 #define ME_CTX_LOCALS(c)                                                                                                      \
     const SvtHipMeFrameJob &job = *(c).job;                                                                                   \
@@ -508,7 +507,8 @@ struct Ctx {
     const uint32_t aw = (c).aw, ah = (c).ah;                                                                                  \
     const bool     hme_sub = (c).hme_sub, me_sub = (c).me_sub;                                                                \
     const int      tl = (c).tl, nlists = (c).nlists, R0 = (c).R0, R1 = (c).R1, nref = (c).nref;                               \
-    uint32_t *const gs = (c).gs, *const gm = (c).gm;                                                                          \
+    /* p_sb_best_sad / p_sb_best_mv of this b64, recomputed where needed: two pointers held across every stage were spilled */ \
+    uint32_t *const gs = job.out.best_sad + (size_t)(c).b64 * NL * NR * 85, *const gm = job.out.best_mv + (size_t)(c).b64 * NL * NR * 85; \
     (void)job, (void)p, (void)S, (void)tid, (void)org_x, (void)org_y, (void)b64_w, (void)b64_h, (void)aw, (void)ah;           \
     (void)hme_sub, (void)me_sub, (void)tl, (void)nlists, (void)R0, (void)R1, (void)nref, (void)gs, (void)gm
 
@@ -529,7 +529,6 @@ __device__ bool make_ctx(Ctx &c, const SvtHipMeFrameJob &job, uint32_t bx) {
     c.hme_sub = p.hme_search_method == 0, c.me_sub = p.me_search_method == 0;
     c.tl = p.temporal_layer_index, c.nlists = p.num_of_list_to_search;
     c.R0 = p.num_of_ref_pic_to_search[0], c.R1 = c.nlists > 1 ? p.num_of_ref_pic_to_search[1] : 0, c.nref = c.R0 + c.R1;
-    c.gs = job.out.best_sad + (size_t)c.b64 * NL * NR * 85, c.gm = job.out.best_mv + (size_t)c.b64 * NL * NR * 85;
     return true;
 }
 
@@ -641,20 +640,30 @@ __device__ void zz_prune_lane0(LDS &L, const Ctx &c) {
     }
 }
 
+// The four searching stages (pre-HME, HME level 0 / 1 / 2) are written as a set-up part and a finish part around ONE shared
+// call of wg_multi_search in the kernel's step loop: a single inlined copy of the search (four copies do not fit the register
+// budget of 8 workgroups per CU, and an out-of-line copy saves and restores 16 registers per call through scratch memory —
+// measured 0.5 GB of extra traffic per launch).  `part` 0 = set-up (fills the descriptors and `a`), 1 = finish.
+struct SearchArgs {
+    bool            search;
+    uint32_t        nd;
+    const uint32_t *src;
+    uint32_t        row_dw, bw, bh, cap;
+};
+
 // prehme_b64 (motion_estimation.c:1792-1866) for references [f0, f1): one lane per (reference, region) sets its
 // descriptor up, ONE wg_multi_search call searches them all, the same lane decodes.  Ends with a barrier.
 template <class LDS>
-__device__ void prehme_round(LDS &L, const Ctx &c, int f0, int f1, bool searching) {
+__device__ void prehme_round(LDS &L, const Ctx &c, int f0, int f1, bool searching, int part, SearchArgs &a) {
     ME_CTX_LOCALS(c);
     const int      f  = f0 + (int)(tid >> 1), si = (int)(tid & 1);
     const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
     const uint32_t nd = 2u * (uint32_t)(f1 - f0);
     const bool     mine = tid < nd;
-    int16_t        q_ox = 0, q_oy = 0;
-    bool           go = false;
-    if (mine) {
+    if (part == 0 && mine) {
         PreHme     &d  = S.ph[li][ri][si];
         SearchDesc &sd = L.sh.desc[tid];
+        sd.aux_go      = 0;
         const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
         sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
         if (tl > 0 || li == 0) {
@@ -689,9 +698,8 @@ __device__ void prehme_round(LDS &L, const Ctx &c, int f0, int f1, bool searchin
                 const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
                 const uint32_t bw = b64_w >> 2, bh = hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2);
                 set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, p.prehme_skip_search_line && bw == 16 && bh <= 16);
-                q_ox = ox, q_oy = oy;
+                sd.aux_x = ox, sd.aux_y = oy, sd.aux_go = 1;
                 S.performed_phme[li][ri][si] = 1;
-                go = true;
             }
         } else {
             d.col = (int16_t)-S.ph[0][ri][si].col;
@@ -699,11 +707,14 @@ __device__ void prehme_round(LDS &L, const Ctx &c, int f0, int f1, bool searchin
             d.sad = S.ph[0][ri][si].sad;
         }
     }
+    if (part == 0) {
+        a = SearchArgs{searching, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), LDS::HME_WIN_DW};
+        return;
+    }
     if (searching) {
-        wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
-                        LDS::HME_WIN_DW);
-        if (go) {
-            PreHme &d = S.ph[li][ri][si];
+        if (mine && L.sh.desc[tid].aux_go) {
+            PreHme       &d    = S.ph[li][ri][si];
+            const int16_t q_ox = L.sh.desc[tid].aux_x, q_oy = L.sh.desc[tid].aux_y;
             decode_result(L.sh, tid, hme_sub, &d.sad, &d.col, &d.row);
             d.col = (int16_t)(d.col + q_ox);
             d.col = (int16_t)(d.col * 4);
@@ -743,17 +754,16 @@ __device__ void phme_prune_lane0(LDS &L, const Ctx &c) {
 
 // HME level 0 (motion_estimation.c:1976-2106) for references [f0, f1); one lane per (reference, quadrant).  Ends with a barrier.
 template <class LDS>
-__device__ void hme_l0_round(LDS &L, const Ctx &c, int f0, int f1) {
+__device__ void hme_l0_round(LDS &L, const Ctx &c, int f0, int f1, int part, SearchArgs &a) {
     ME_CTX_LOCALS(c);
     const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
     const bool     mine = tid < nd;
     const int      f    = f0 + (int)(tid >> 2);
     const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
     const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
-    int16_t        q_ox = 0, q_oy = 0;
-    bool           go = false;
-    if (mine) {
+    if (part == 0 && mine) {
         SearchDesc         &sd = L.sh.desc[tid];
+        sd.aux_go              = 0;
         const SvtHipPlane8 &rp = job.ref[li][ri].sixteenth;
         sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
         const int psi = S.ph[li][ri][0].sad <= S.ph[li][ri][1].sad ? 0 : 1;
@@ -801,12 +811,15 @@ __device__ void hme_l0_round(LDS &L, const Ctx &c, int f0, int f1) {
             const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox16) + ox);
             const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy16) + oy);
             set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-            q_ox = ox, q_oy = oy;
-            go   = true;
+            sd.aux_x = ox, sd.aux_y = oy, sd.aux_go = 1;
         }
     }
-    wg_multi_search(L.sh, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), L.win,
-                    LDS::HME_WIN_DW);
+    if (part == 0) {
+        a = SearchArgs{true, nd, L.src_s, hme_sub ? 8u : 4u, b64_w >> 2, hme_sub ? (b64_h >> 2) >> 1 : (b64_h >> 2), LDS::HME_WIN_DW};
+        return;
+    }
+    const bool go = mine && L.sh.desc[tid].aux_go;
+    const int16_t q_ox = L.sh.desc[tid & 31].aux_x, q_oy = L.sh.desc[tid & 31].aux_y;
     if (go) {
         int16_t mx = S.l0x[li][ri][sw_][sh_], my = S.l0y[li][ri][sw_][sh_];
         decode_result(L.sh, tid, hme_sub, &S.l0s[li][ri][sw_][sh_], &mx, &my);
@@ -835,17 +848,16 @@ __device__ void hme_l0_round(LDS &L, const Ctx &c, int f0, int f1) {
 
 // HME level 1 (motion_estimation.c:2111-2192) for references [f0, f1).  Ends with a barrier.
 template <class LDS>
-__device__ void hme_l1_round(LDS &L, const Ctx &c, int f0, int f1) {
+__device__ void hme_l1_round(LDS &L, const Ctx &c, int f0, int f1, int part, SearchArgs &a) {
     ME_CTX_LOCALS(c);
     const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
     const bool     mine = tid < nd;
     const int      f    = f0 + (int)(tid >> 2);
     const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
     const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
-    int16_t        q_ox = 0, q_oy = 0;
-    bool           go = false;
-    if (mine) {
+    if (part == 0 && mine) {
         SearchDesc         &sd = L.sh.desc[tid];
+        sd.aux_go              = 0;
         const SvtHipPlane8 &rp = job.ref[li][ri].quarter;
         sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
         if (tl > 0 || li == 0) {
@@ -868,13 +880,16 @@ __device__ void hme_l1_round(LDS &L, const Ctx &c, int f0, int f1) {
                 const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + ox4) + ox);
                 const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + oy4) + oy);
                 set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-                q_ox = ox, q_oy = oy;
-                go   = true;
+                sd.aux_x = ox, sd.aux_y = oy, sd.aux_go = 1;
             }
         }
     }
-    wg_multi_search(L.sh, nd, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1), L.win,
-                    LDS::HME_WIN_DW);
+    if (part == 0) {
+        a = SearchArgs{true, nd, L.src_q, hme_sub ? 16u : 8u, b64_w >> 1, hme_sub ? (b64_h >> 1) >> 1 : (b64_h >> 1), LDS::HME_WIN_DW};
+        return;
+    }
+    const bool go = mine && L.sh.desc[tid].aux_go;
+    const int16_t q_ox = L.sh.desc[tid & 31].aux_x, q_oy = L.sh.desc[tid & 31].aux_y;
     if (go) {
         int16_t mx = S.l1x[li][ri][sw_][sh_], my = S.l1y[li][ri][sw_][sh_];
         decode_result(L.sh, tid, hme_sub, &S.l1s[li][ri][sw_][sh_], &mx, &my);
@@ -887,17 +902,16 @@ __device__ void hme_l1_round(LDS &L, const Ctx &c, int f0, int f1) {
 
 // HME level 2 (motion_estimation.c:2197-2247) for references [f0, f1).  Ends with a barrier.
 template <class LDS>
-__device__ void hme_l2_round(LDS &L, const Ctx &c, int f0, int f1) {
+__device__ void hme_l2_round(LDS &L, const Ctx &c, int f0, int f1, int part, SearchArgs &a) {
     ME_CTX_LOCALS(c);
     const uint32_t nd   = (uint32_t)(f1 - f0) * 4u;
     const bool     mine = tid < nd;
     const int      f    = f0 + (int)(tid >> 2);
     const uint32_t qi = tid & 3, sw_ = qi & 1, sh_ = qi >> 1;
     const int      li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
-    int16_t        q_ox = 0, q_oy = 0;
-    bool           go = false;
-    if (mine) {
+    if (part == 0 && mine) {
         SearchDesc         &sd = L.sh.desc[tid];
+        sd.aux_go              = 0;
         const SvtHipPlane8 &rp = job.ref[li][ri].full;
         sd.sa_w = sd.sa_h = 0, sd.skip = 0, sd.ref = rp.buf, sd.ref_stride = sd.raw_stride = rp.stride;
         if (tl > 0 || li == 0) {
@@ -914,12 +928,16 @@ __device__ void hme_l2_round(LDS &L, const Ctx &c, int f0, int f1) {
                 const int16_t x_tl = (int16_t)(((int16_t)rp.org_x + (int16_t)org_x) + ox);
                 const int16_t y_tl = (int16_t)(((int16_t)rp.org_y + (int16_t)org_y) + oy);
                 set_desc(sd, p, rp, x_tl, y_tl, sa_w, sa_h, 0);
-                q_ox = ox, q_oy = oy;
-                go   = true;
+                sd.aux_x = ox, sd.aux_y = oy, sd.aux_go = 1;
             }
         }
     }
-    wg_multi_search(L.sh, nd, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, L.win, LDS::WIN_DW);
+    if (part == 0) {
+        a = SearchArgs{true, nd, L.src_full, hme_sub ? 32u : 16u, b64_w, hme_sub ? b64_h >> 1 : b64_h, LDS::WIN_DW};
+        return;
+    }
+    const bool go = mine && L.sh.desc[tid].aux_go;
+    const int16_t q_ox = L.sh.desc[tid & 31].aux_x, q_oy = L.sh.desc[tid & 31].aux_y;
     if (go) {
         int16_t mx = S.l2x[li][ri][sw_][sh_], my = S.l2y[li][ri][sw_][sh_];
         decode_result(L.sh, tid, hme_sub, &S.l2s[li][ri][sw_][sh_], &mx, &my);
@@ -1273,48 +1291,56 @@ __global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFra
         __syncthreads();
     }
     ME_PHASE(1);
-    ME_SITE(0);
-    if (p.prehme_enable) {
-        // List 1 reads list 0's results for the l1 early exit (:1771-1781) and for the tl == 0 mirror (:1853-1860); only
-        // then does it need a round of its own — otherwise all references are searched by one call.
-        const bool split = nlists == 2 && (p.prehme_l1_early_exit || tl == 0);
-        if (split) {
-            prehme_round(L, c, 0, R0, true);
-            prehme_round(L, c, R0, nref, tl > 0);
-        } else {
-            prehme_round(L, c, 0, nref, true);
-        }
-        phme_prune_lane0(L, c);
-        __syncthreads();
-    }
-    ME_PHASE(2);
-    ME_SITE(1);
-    if (p.enable_hme_flag && p.enable_hme_level0_flag) {
-        // With distance-based resizing, references other than the first read the first one's quadrant-(0,0) vector
-        // (get_hme_l0_search_area, :1881-1890): the first reference then gets a round of its own.
+    {
+        // List 1 reads list 0's pre-HME results for the l1 early exit (:1771-1781) and for the tl == 0 mirror (:1853-1860):
+        // only then does it need a round of its own.  With distance-based resizing, references other than the first read
+        // the first one's quadrant-(0,0) level-0 vector (get_hme_l0_search_area, :1881-1890): the first reference then
+        // gets a round of its own.
+        const bool pre = p.prehme_enable, split = nlists == 2 && (p.prehme_l1_early_exit || tl == 0);
+        const bool l0 = p.enable_hme_flag && p.enable_hme_level0_flag, l1 = p.enable_hme_flag && p.enable_hme_level1_flag;
+        const bool l2 = p.enable_hme_flag && p.enable_hme_level2_flag;
         const bool dep = p.enable_me_sr_adjustment && p.distance_based_hme_resizing && p.reduce_hme_l0_sr_th_min &&
             p.reduce_hme_l0_sr_th_max && nref > 1;
-        if (dep) {
-            hme_l0_round(L, c, 0, 1);
-            hme_l0_round(L, c, 1, nref);
-        } else {
-            hme_l0_round(L, c, 0, nref);
+        for (int step = 0; step < 6; step++) {
+            if (step == 2) {  // after pre-HME
+                if (pre) {
+                    phme_prune_lane0(L, c);
+                    __syncthreads();
+                }
+                ME_PHASE(2);
+            } else if (step == 4) {
+                ME_PHASE(3);
+            } else if (step == 5) {
+                ME_PHASE(4);
+                // the down-scaled stages' windows may have overwritten the full resolution source block: stage it again
+                // (the barrier that ends the last search orders the window reads before these writes)
+                if (pre || l0 || l1) {
+                    stage_sources(L, c, 1);
+                    __syncthreads();
+                }
+            }
+            const bool active = step == 0 ? pre : step == 1 ? (pre && split) : step == 2 ? l0 : step == 3 ? (l0 && dep) : step == 4 ? l1 : l2;
+            if (!active)
+                continue;
+            const int f0 = step == 1 ? R0 : (step == 3 ? 1 : 0);
+            const int f1 = step == 0 ? (split ? R0 : nref) : (step == 2 ? (dep ? 1 : nref) : nref);
+            SearchArgs a;
+            for (int part = 0; part < 2; part++) {
+                if (step < 2)
+                    prehme_round(L, c, f0, f1, step == 0 || tl > 0, part, a);
+                else if (step < 4)
+                    hme_l0_round(L, c, f0, f1, part, a);
+                else if (step == 4)
+                    hme_l1_round(L, c, f0, f1, part, a);
+                else
+                    hme_l2_round(L, c, f0, f1, part, a);
+                if (part == 0 && a.search) {
+                    ME_SITE(step < 2 ? 0 : (step < 4 ? 1 : step - 2));
+                    wg_multi_search(L.sh, a.nd, a.src, a.row_dw, a.bw, a.bh, L.win, a.cap);
+                }
+            }
         }
     }
-    ME_PHASE(3);
-    ME_SITE(2);
-    if (p.enable_hme_flag && p.enable_hme_level1_flag)
-        hme_l1_round(L, c, 0, nref);
-    ME_PHASE(4);
-    ME_SITE(3);
-    // the down-scaled stages' windows may have overwritten the full resolution source block: stage it again (the barrier
-    // that ends the last search orders the window reads before these writes)
-    if (p.prehme_enable || (p.enable_hme_flag && (p.enable_hme_level0_flag || p.enable_hme_level1_flag))) {
-        stage_sources(L, c, 1);
-        __syncthreads();
-    }
-    if (p.enable_hme_flag && p.enable_hme_level2_flag)
-        hme_l2_round(L, c, 0, nref);
     ME_PHASE(5);
     centre_prune_lane0(L, c);
     __syncthreads();

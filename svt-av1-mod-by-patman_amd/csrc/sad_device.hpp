@@ -37,6 +37,10 @@ struct SearchDesc {
     uint32_t pitch_dw;  // LDS row pitch of the staged window (dwords)
     uint32_t rows_per_pos;  // raw rows spanned by one search position: (bh-1)*k + 1
     uint32_t inv_pitch, inv_nq;  // ceil(2^32 / x): exact quotients for the small dividends used here
+    // --- caller's per-descriptor state that has to survive the search (kept here rather than in registers: live values
+    // across the inlined search are what the register allocator spills) ---
+    int16_t  aux_x, aux_y;
+    uint32_t aux_go;
 };
 
 struct SearchSeg {
@@ -203,7 +207,7 @@ template <bool ITEMS, class SH> __device__ __forceinline__ uint32_t find_seg(con
 // Must be called by all WG_THREADS threads of the workgroup; contains barriers.  Descriptor i must have been
 // written by thread i (or be visible through an earlier barrier).
 template <class SH>
-__device__ inline void wg_multi_search(SH &sh, uint32_t n, const uint32_t *__restrict__ src,
+__device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32_t *__restrict__ src,
                                        uint32_t src_row_dw, uint32_t bw, uint32_t bh, uint32_t *__restrict__ win,
                                        uint32_t win_cap_dw) {
     const uint32_t tid = threadIdx.x;
