@@ -499,11 +499,23 @@ struct Ctx {
     bool      hme_sub, me_sub;
     int       tl, nlists, R0, R1, nref;
 };
+// Values every stage derives its indices from are made opaque at the top of each stage: otherwise the optimiser hoists the
+// index arithmetic of ALL stages out of the kernel's step loop and keeps dozens of results alive across the searches — which
+// under the 64-register budget means spilling values as cheap as tid >> 2.
+__device__ __forceinline__ uint32_t opaque_v(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t opaque_s(uint32_t v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
 #define ME_CTX_LOCALS(c)                                                                                                      \
     const SvtHipMeFrameJob &job = *(c).job;                                                                                   \
     const SvtHipMeParams   &p   = job.prm;                                                                                    \
     B64State               &S   = L.st;                                                                                       \
-    const uint32_t tid = threadIdx.x, org_x = (c).org_x, org_y = (c).org_y, b64_w = (c).b64_w, b64_h = (c).b64_h;             \
+    const uint32_t tid = opaque_v(threadIdx.x), org_x = opaque_s((c).org_x), org_y = opaque_s((c).org_y);                       \
+    const uint32_t b64_w = opaque_s((c).b64_w), b64_h = opaque_s((c).b64_h);                                                    \
     const uint32_t aw = (c).aw, ah = (c).ah;                                                                                  \
     const bool     hme_sub = (c).hme_sub, me_sub = (c).me_sub;                                                                \
     const int      tl = (c).tl, nlists = (c).nlists, R0 = (c).R0, R1 = (c).R1, nref = (c).nref;                               \
