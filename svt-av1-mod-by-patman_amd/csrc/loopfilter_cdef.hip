@@ -230,7 +230,7 @@ __device__ int stage_fb(FbLds &S, const SvtHipCdefPlane &pl, const uint8_t *filt
     return S.n;
 }
 
-__global__ __launch_bounds__(256) void cdef_search_kernel(SvtHipCdefPlane pl, const uint8_t *__restrict__ filt,
+__global__ __launch_bounds__(256, 5) void cdef_search_kernel(SvtHipCdefPlane pl, const uint8_t *__restrict__ filt,
                                                           SvtHipCdefSearchParams prm, uint64_t *__restrict__ mse,
                                                           uint8_t *__restrict__ gdir, int32_t *__restrict__ gvar, int nhfb) {
     __shared__ FbLds S;

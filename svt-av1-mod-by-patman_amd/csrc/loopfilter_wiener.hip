@@ -38,7 +38,7 @@ struct StatsAux {  // raw first moments of one unit
 constexpr int CHUNKS = 4;  // row chunks of one tile column that a workgroup accumulates before it touches global memory
 
 template <int WIN>
-__global__ __launch_bounds__(256) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int is16, int th,
+__global__ __launch_bounds__(256, 4) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int is16, int th,
                                                            long long *__restrict__ M, long long *__restrict__ H, StatsAux *__restrict__ aux) {
     constexpr int HALF = WIN / 2, W2 = WIN * WIN;
     constexpr int NPAIR = WIN * (WIN + 1) / 2, NJOB = NPAIR + WIN + 1;  // column pairs, column x source, source sum
