@@ -84,7 +84,12 @@ __device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) { return ((
 // One dword from any byte address: amdhsa runs the memory pipeline in unaligned-access mode, so this is a single
 // global_load_dword (window origins are arbitrary byte offsets into the padded planes).
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *g) { return *(const u32_unaligned *)g; }
+// Picture pointers reach the kernels through descriptors kept in LDS, so the compiler sees generic pointers and would emit
+// flat loads (which also count against the LDS counter: every wait on one then waits for outstanding LDS traffic too).
+// They are always global memory: say so.
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *g) {
+    return *(const __attribute__((address_space(1))) u32_unaligned *)g;
+}
 // n / d for n * d < 2^32 with inv = ceil(2^32 / d) (d >= 2; d == 1 is handled by the caller passing inv = 0)
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
 __device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? (uint32_t)((0x100000000ull + d - 1) / d) : 0u; }
