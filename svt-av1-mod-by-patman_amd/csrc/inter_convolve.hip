@@ -17,16 +17,16 @@ namespace {
 constexpr int FILTER_BITS = 7, TILE = 64, IP = TILE + 8;
 
 __device__ __forceinline__ int32_t ldpx(const void *p, ptrdiff_t idx, int is16) {
-    return is16 ? ((const uint16_t *)p)[idx] : ((const uint8_t *)p)[idx];
+    return is16 ? ((const __attribute__((address_space(1))) uint16_t *)p)[idx] : ((const __attribute__((address_space(1))) uint8_t *)p)[idx];  // pictures are global memory: no flat loads
 }
 __device__ __forceinline__ int32_t rnd(int32_t v, int n) { return (v + ((1 << n) >> 1)) >> n; }
 __device__ __forceinline__ void stpx(void *p, size_t idx, int is16, int32_t v, int bd) {
     const int32_t hi = (1 << bd) - 1;
     v                = v < 0 ? 0 : (v > hi ? hi : v);
     if (is16)
-        ((uint16_t *)p)[idx] = (uint16_t)v;
+        ((__attribute__((address_space(1))) uint16_t *)p)[idx] = (uint16_t)v;
     else
-        ((uint8_t *)p)[idx] = (uint8_t)v;
+        ((__attribute__((address_space(1))) uint8_t *)p)[idx] = (uint8_t)v;
 }
 
 // compound epilogue (inter_prediction.c:531-543 and its siblings): store the offset intermediate, or average with the stored

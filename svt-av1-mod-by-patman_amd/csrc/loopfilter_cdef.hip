@@ -189,7 +189,7 @@ __device__ __forceinline__ uint64_t dist_8xn(uint64_t ss, uint64_t sd, uint64_t 
 }
 
 __device__ __forceinline__ uint32_t load_px(const void *p, size_t idx, int is16) {
-    return is16 ? ((const uint16_t *)p)[idx] : ((const uint8_t *)p)[idx];
+    return is16 ? ((const __attribute__((address_space(1))) uint16_t *)p)[idx] : ((const __attribute__((address_space(1))) uint8_t *)p)[idx];  // pictures are global memory: no flat loads
 }
 
 struct FbLds {

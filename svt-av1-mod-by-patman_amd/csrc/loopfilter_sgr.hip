@@ -39,7 +39,7 @@ static const int32_t SGR_PRM_H[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1},
 
 __device__ __forceinline__ int32_t rnd(int32_t v, int n) { return (v + ((1 << n) >> 1)) >> n; }
 __device__ __forceinline__ int32_t ldpx(const void *p, size_t idx, int is16) {
-    return is16 ? ((const uint16_t *)p)[idx] : ((const uint8_t *)p)[idx];
+    return is16 ? ((const __attribute__((address_space(1))) uint16_t *)p)[idx] : ((const __attribute__((address_space(1))) uint8_t *)p)[idx];  // pictures are global memory: no flat loads
 }
 
 struct SgrGeom {

@@ -25,7 +25,7 @@ constexpr int TW = 64, TH = 32;  // samples per tile (TH shrinks to 8 for 12-bit
 constexpr int W2MAX = 49;  // WIENER_WIN2
 
 __device__ __forceinline__ int32_t ldpx(const void *p, size_t idx, int is16) {
-    return is16 ? ((const uint16_t *)p)[idx] : ((const uint8_t *)p)[idx];
+    return is16 ? ((const __attribute__((address_space(1))) uint16_t *)p)[idx] : ((const __attribute__((address_space(1))) uint8_t *)p)[idx];  // pictures are global memory: no flat loads
 }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));

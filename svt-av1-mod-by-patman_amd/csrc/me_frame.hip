@@ -90,6 +90,7 @@ struct MeLds {
 };
 static_assert(sizeof(MeLds::win) >= (ME_WIN_DW + 64 * 16) * 4 + 85 * 12, "full-pel view must fit the HME window buffer");
 
+typedef __attribute__((address_space(1))) uint32_t g_u32;  // the result arrays are global memory (the pointers come out of LDS)
 #define MINV(a, b) ((a) < (b) ? (a) : (b))
 #define MAXV(a, b) ((a) > (b) ? (a) : (b))
 #define ABSV(a) ((a) < 0 ? -(a) : (a))
@@ -345,7 +346,7 @@ __device__ __forceinline__ int use_me_pu(const SvtHipMeParams &p, uint32_t n) {
 #define GM(li, ri, n) gm[((li) * NR + (ri)) * 85 + (n)]
 
 template <class LDS>
-__device__ void cand_single_ref(LDS &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+__device__ void cand_single_ref(LDS &L, const SvtHipMeParams &p, const g_u32 *gs, const g_u32 *gm, uint32_t n,
                                 uint32_t *mv, uint8_t *cand) {
     const uint8_t pu = z_to_raster_d[n];
     L.me_dist[pu]    = GS(0, 0, n);
@@ -358,7 +359,7 @@ __device__ void cand_single_ref(LDS &L, const SvtHipMeParams &p, const uint32_t 
 }
 
 template <class LDS>
-__device__ void cand_mrp_off(LDS &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+__device__ void cand_mrp_off(LDS &L, const SvtHipMeParams &p, const g_u32 *gs, const g_u32 *gm, uint32_t n,
                              uint32_t nlist, uint32_t *mv, uint8_t *cand, uint8_t *total) {
     const uint8_t org0 = L.st.sr[0][0].do_ref, org1 = (uint8_t)((nlist == 1) ? 0 : L.st.sr[1][0].do_ref);
     if (nlist < 2 || !L.st.sr[1][0].do_ref)
@@ -404,7 +405,7 @@ __device__ void cand_mrp_off(LDS &L, const SvtHipMeParams &p, const uint32_t *gs
 }
 
 template <class LDS>
-__device__ void cand_general(LDS &L, const SvtHipMeParams &p, const uint32_t *gs, const uint32_t *gm, uint32_t n,
+__device__ void cand_general(LDS &L, const SvtHipMeParams &p, const g_u32 *gs, const g_u32 *gm, uint32_t n,
                              uint32_t nlist, uint32_t *mv, uint8_t *cand, uint8_t *total) {
     const uint8_t pu  = (n > 4) ? z_to_raster_d[n] : (uint8_t)n;
     uint8_t       off = 0;
@@ -520,7 +521,7 @@ __device__ __forceinline__ uint32_t opaque_s(uint32_t v) {
     const bool     hme_sub = (c).hme_sub, me_sub = (c).me_sub;                                                                \
     const int      tl = (c).tl, nlists = (c).nlists, R0 = (c).R0, R1 = (c).R1, nref = (c).nref;                               \
     /* p_sb_best_sad / p_sb_best_mv of this b64, recomputed where needed: two pointers held across every stage were spilled */ \
-    uint32_t *const gs = job.out.best_sad + (size_t)(c).b64 * NL * NR * 85, *const gm = job.out.best_mv + (size_t)(c).b64 * NL * NR * 85; \
+    g_u32 *const gs = (g_u32 *)(job.out.best_sad + (size_t)(c).b64 * NL * NR * 85), *const gm = (g_u32 *)(job.out.best_mv + (size_t)(c).b64 * NL * NR * 85); \
     (void)job, (void)p, (void)S, (void)tid, (void)org_x, (void)org_y, (void)b64_w, (void)b64_h, (void)aw, (void)ah;           \
     (void)hme_sub, (void)me_sub, (void)tl, (void)nlists, (void)R0, (void)R1, (void)nref, (void)gs, (void)gm
 
@@ -1269,8 +1270,6 @@ __device__ void finalize_b64(LDS &L, const Ctx &c) {
     }
     if (tid < NL * NR)
         out.search_results[(size_t)b64 * NL * NR + tid] = (&S.sr[0][0])[tid];
-    if (tid < NL * NR)
-        job.out.search_results[(size_t)b64 * NL * NR + tid] = (&S.sr[0][0])[tid];
 }
 
 

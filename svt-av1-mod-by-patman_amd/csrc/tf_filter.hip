@@ -19,7 +19,7 @@ __device__ const uint32_t SQRT_FP16[16] = {0,      65536,  92681,  113511, 13107
                                            185363, 196608, 207243, 217358, 227023, 236293, 245213, 253819};  // (uint32)(sqrt(i) * 65536)
 
 __device__ __forceinline__ uint32_t ldpx(const void *p, size_t i, int is16) {
-    return is16 ? ((const uint16_t *)p)[i] : ((const uint8_t *)p)[i];
+    return is16 ? ((const __attribute__((address_space(1))) uint16_t *)p)[i] : ((const __attribute__((address_space(1))) uint8_t *)p)[i];  // pictures are global memory: no flat loads
 }
 __device__ __forceinline__ uint32_t sqrt_fast(uint32_t x) {  // temporal_filtering.c:705-714
     if (x > 15) {
