@@ -19,9 +19,8 @@ namespace {
 // STEP = 2: mean of in(2i..2i+1, 2j..2j+1).  STEP = 4: mean of in(4i+1..4i+2, 4j+1..4j+2).
 template <int STEP>
 __device__ __forceinline__ void downsample_pad_body(const uint8_t *__restrict__ in, uint32_t in_stride, uint8_t *__restrict__ out,
-                                                    uint32_t out_stride, uint32_t out_w, uint32_t out_h, uint32_t pad) {
+                                                    uint32_t out_stride, uint32_t out_w, uint32_t out_h, uint32_t pad, uint32_t Y) {
     const uint32_t X4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;  // first padded column of this dword
-    const uint32_t Y  = blockIdx.y;
     if (X4 >= out_stride || Y >= out_h + 2 * pad)
         return;
     int yi = (int)Y - (int)pad;
@@ -65,19 +64,23 @@ template <int STEP>
 __global__ __launch_bounds__(256) void downsample_pad_kernel(const uint8_t *__restrict__ in, uint32_t in_stride,
                                                              uint8_t *__restrict__ out, uint32_t out_stride,
                                                              uint32_t out_w, uint32_t out_h, uint32_t pad) {
-    downsample_pad_body<STEP>(in, in_stride, out, out_stride, out_w, out_h, pad);
+    downsample_pad_body<STEP>(in, in_stride, out, out_stride, out_w, out_h, pad, blockIdx.y);
 }
 
+constexpr uint32_t BATCH_ROWS = 4;
 // Batched form: blockIdx.z = picture.  level 0: full -> quarter (STEP 2), 1: quarter -> sixteenth (STEP 2),
 // 2: full -> sixteenth (STEP 4, HME level 1 off).
 __global__ __launch_bounds__(256) void downsample_pad_batch_kernel(const SvtHipAnalysisJob *__restrict__ jobs, int level) {
     const SvtHipPyramid8 &y = jobs[blockIdx.z].pyr;
     const SvtHipPlane8   &i = level == 1 ? y.quarter : y.full, &o = level == 0 ? y.quarter : y.sixteenth;
     const uint8_t        *in = i.buf + i.org_x + (size_t)i.org_y * i.stride;
-    if (level == 2)
-        downsample_pad_body<4>(in, i.stride, o.buf, o.stride, o.width, o.height, o.org_x);
-    else
-        downsample_pad_body<2>(in, i.stride, o.buf, o.stride, o.width, o.height, o.org_x);
+    // BATCH_ROWS output rows per workgroup: a row of one dword per thread is too little work per launch slot
+    for (uint32_t r = 0; r < BATCH_ROWS; r++) {
+        if (level == 2)
+            downsample_pad_body<4>(in, i.stride, o.buf, o.stride, o.width, o.height, o.org_x, blockIdx.y * BATCH_ROWS + r);
+        else
+            downsample_pad_body<2>(in, i.stride, o.buf, o.stride, o.width, o.height, o.org_x, blockIdx.y * BATCH_ROWS + r);
+    }
 }
 
 // Edge replication of a plane in place (svt_aom_generate_padding); interior untouched.
@@ -268,10 +271,10 @@ extern "C" int32_t svt_hip_analysis_frames(const SvtHipAnalysisJob *jobs, uint32
     if (!d_jobs)
         return SVT_HIP_ERR_RUNTIME;
     if (hme_level1_enabled) {
-        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_q_stride / 4 + 1 + 255) / 256, max_q_rows, n_jobs), dim3(256), 0, st, d_jobs, 0);
-        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_s_stride / 4 + 1 + 255) / 256, max_s_rows, n_jobs), dim3(256), 0, st, d_jobs, 1);
+        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_q_stride / 4 + 1 + 255) / 256, (max_q_rows + BATCH_ROWS - 1) / BATCH_ROWS, n_jobs), dim3(256), 0, st, d_jobs, 0);
+        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_s_stride / 4 + 1 + 255) / 256, (max_s_rows + BATCH_ROWS - 1) / BATCH_ROWS, n_jobs), dim3(256), 0, st, d_jobs, 1);
     } else {
-        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_s_stride / 4 + 1 + 255) / 256, max_s_rows, n_jobs), dim3(256), 0, st, d_jobs, 2);
+        hipLaunchKernelGGL(downsample_pad_batch_kernel, dim3((max_s_stride / 4 + 1 + 255) / 256, (max_s_rows + BATCH_ROWS - 1) / BATCH_ROWS, n_jobs), dim3(256), 0, st, d_jobs, 2);
     }
     hipLaunchKernelGGL(variance_batch_kernel, dim3((max_nb + 3) / 4, n_jobs), dim3(256), 0, st, d_jobs, (int)full_precision);
     stage_commit(st);
