@@ -143,11 +143,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SVTAV1_BENCH_REHEARSAL=1: rehearse the multi-rank control flow on a ONE-GPU box (all ranks share device 0, process
+    # group over gloo).  Never set by the driver; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("SVTAV1_BENCH_REHEARSAL") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl")   # RCCL on ROCm; used for the barrier / max-time reduction only
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl")   # RCCL on ROCm; used for the barrier / max-time reduction only
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -234,7 +239,7 @@ def main():
         step(k)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dev)       # slowest rank defines the step time
+    elapsed = shard.max_over_ranks(elapsed, "cpu" if rehearsal else dev)       # slowest rank defines the step time
 
     me_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_me]))
     n_refs = len(L0_OFFS) + len(L1_OFFS)
