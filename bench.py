@@ -347,6 +347,22 @@ def bench_txfm(lib, dev, args, world, rank):
         alg = 14.0 * w * h * nblk
         per_size[f"{w}x{h}"] = {"blocks": nblk, "launch_ms": round(ms, 4), "GBps": round(alg / (ms * 1e-3) / 1e9, 1)}
         total_ms += ms
+        if max(w, h) <= 16:
+            # the same blocks with the descriptors grouped by transform type (what INTEGRATION.md asks the producer to do):
+            # every wave then runs ONE 1-D kernel kind per pass.  Reported beside the mixed order, not part of `value`.
+            descs["tx_type"] = (i >= nblk // 2).astype(np.uint8)
+            d_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
+            for _ in range(args.warmup):
+                launch()
+            torch.cuda.synchronize()
+            ge = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            for a, b in ge:
+                a.record(stream)
+                launch()
+                b.record(stream)
+            torch.cuda.synchronize()
+            gms = float(np.mean([a.elapsed_time(b) for a, b in ge]))
+            per_size[f"{w}x{h}"]["grouped_by_type_GBps"] = round(alg / (gms * 1e-3) / 1e9, 1)
     # the TPL dispenser's block cost on the same kernel (src_ops_process.c:734-748): 8-bit source and prediction in,
     # residual formed in the kernel, forward DCT_DCT 16x16, SATD out — 2N + 16 algorithmic bytes per block; reported beside
     # the headline sizes, not part of `value`
