@@ -12,7 +12,7 @@ python3 bench.py --workload lf > $OUT/${TAG}_bench_4k10_lf.json 2> $OUT/bench_lf
 cd /tmp && export TMPDIR=/tmp
 for wl in me txfm lf; do
   rm -rf /tmp/kt_$wl
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$wl -- python3 $REPO/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $OUT/kt_$wl.log 2>&1 || echo "kernel-trace $wl failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$wl -- python3 $REPO/bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > $OUT/kt_$wl.log 2>&1 || echo "kernel-trace $wl failed"
   f=$(find /tmp/kt_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_rocprof_kernel_stats_$wl.csv
 done
