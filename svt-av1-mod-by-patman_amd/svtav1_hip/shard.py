@@ -3,8 +3,12 @@
 The open-loop analysis of one picture (pyramid, variance, ME against its reference pictures) reads only that
 picture and its references' source pictures, so a clip splits into contiguous segments, one per
 rank (= one per GPU), each carrying `lookback` / `lookahead` context pictures so that every reference is resident
-locally.  There is no exchange step in the data path; the process group is used for the start/stop barrier, the
+locally.  There is no exchange step in the open-loop data path; the process group is used for the start/stop barrier, the
 max-over-ranks timing and (optionally) collecting the small per-picture results on rank 0.
+
+The one real exchange step of the encoder sits behind the in-loop filters of this path: the GPU that
+reconstructed and filtered a REFERENCE picture publishes it to the GPUs that will predict from it (inter-prediction
+interpolation, temporal filter).  `publish_reference()` is that step: one broadcast of the whole padded picture.
 """
 import torch
 import torch.distributed as dist
@@ -55,3 +59,22 @@ def gather_on_root(local_results):
     for p in parts:
         merged.update(p)
     return merged
+
+
+def publish_reference(picture, owner, stream=None, async_op=True):
+    """Broadcast one reconstructed reference picture from its owner rank to every other rank (the reference publishes it at
+    rest_process.c:659-660, 732-744 once restoration has finished).
+
+    `picture` is ONE contiguous tensor holding the padded Y/U/V planes back to back (the planes the kernels use are views of
+    it): a single large collective per picture instead of three small ones — xGMI rings are per-link bound (≈27 MB for a
+    padded 4K 10-bit 4:2:0 picture ≈ 0.2 ms per link).  Only `is_ref` pictures travel.  With `async_op` the work handle is
+    returned so that the broadcast overlaps the owner's next picture; pass the side `stream` it should be enqueued on
+    (NCCL / RCCL use the current stream of the tensor's device).  Returns None on a single rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    assert picture.is_contiguous()
+    raw = picture.view(-1).view(torch.uint8)      # bytes: every backend moves them, whatever the sample type
+    if stream is not None:
+        with torch.cuda.stream(stream):
+            return dist.broadcast(raw, src=owner, async_op=async_op)
+    return dist.broadcast(raw, src=owner, async_op=async_op)

@@ -45,6 +45,16 @@ def worker(rank, world, port, q):
         shard.barrier()
         slowest = shard.max_over_ranks(1.0 + rank)
         merged = shard.gather_on_root(local)
+        # the exchange step: rank 1 owns a reconstructed reference picture (one flat buffer, planes are views of it)
+        import torch
+        rng = np.random.default_rng(5)
+        ref_pic = rng.integers(0, 1024, size=3 * 96 * 64 // 2, dtype=np.int64).astype(np.int16)
+        pic = torch.from_numpy(ref_pic.copy() if rank == 1 else np.zeros_like(ref_pic))
+        work = shard.publish_reference(pic, owner=1)
+        work.wait()
+        assert np.array_equal(pic.numpy(), ref_pic)
+        luma = pic[:96 * 64].view(64, 96)       # a plane view of the published picture
+        assert int(luma[3, 5]) == int(ref_pic[3 * 96 + 5])
         if rank == 0:
             q.put((slowest, {i: {k: v.copy() for k, v in r.items()} for i, r in merged.items()}))
     finally:
