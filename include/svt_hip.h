@@ -63,8 +63,9 @@ SVT_HIP_API int32_t svt_hip_stream_sync(void *stream);
 /* ---- installing the Tier A functions into the reference's RTCD dispatch -------------------------------
  * Every Tier A export is named <reference pointer name>_hip and has that pointer's exact signature
  * (aom_dsp_rtcd.h / common_dsp_rtcd.h).  svt_hip_rtcd_lookup("svt_sad_loop_kernel") returns
- * &svt_sad_loop_kernel_hip, or NULL when this library has no replacement for that pointer.  (One alias: the
- * reference's `downsample_2d` pointer, aom_dsp_rtcd.h:838, resolves to svt_aom_downsample_2d_hip.)
+ * &svt_sad_loop_kernel_hip, or NULL when this library has no replacement for that pointer.  (Two aliases, for the
+ * pointers without an svt_ prefix: `downsample_2d`, aom_dsp_rtcd.h:838, resolves to svt_aom_downsample_2d_hip and
+ * `sad_16b_kernel`, :861, to svt_aom_sad_16b_kernel_hip.)
  * svt_hip_install_rtcd assigns all bindings it can resolve and reports how many; it installs nothing and
  * returns SVT_HIP_ERR_NO_DEVICE when no gfx950 device can be initialised, so the caller keeps the CPU
  * functions selected by svt_aom_setup_rtcd_internal (aom_dsp_rtcd.c:187).  See INTEGRATION.md. */

@@ -46,6 +46,11 @@ SVT_HIP_API uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t
                                                     const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize,
                                                     int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
 
+/* svt_search_one_dual (aom_dsp_rtcd.h:239; enc_cdef.c:627-686): one greedy step of the joint luma / chroma strength
+ * search over the per-filter-block tables mse[0][i][strength], mse[1][i][strength]. */
+SVT_HIP_API uint64_t svt_search_one_dual_hip(int *lev0, int *lev1, int nb_strengths, uint64_t **mse[2], int sb_count,
+                                             int start_gi, int end_gi);
+
 /* ---------------------------------------------------------------------------------------------
  * Tier B — one picture plane per call, device pointers.
  *   recon / source : top-left sample of the picture area (no padding needed; samples outside the

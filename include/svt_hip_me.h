@@ -9,6 +9,8 @@
  *   Source/Lib/Codec/aom_dsp_rtcd.h:850,851  svt_ext_all_sad_calculation_8x8_16x16 /
  *                                            svt_ext_eight_sad_calculation_32x32_64x64
  *   Source/Lib/Codec/aom_dsp_rtcd.h:852,854  svt_initialize_buffer_32bits / svt_nxm_sad_kernel
+ *   Source/Lib/Codec/aom_dsp_rtcd.h:853,861,866  svt_nxm_sad_kernel_sub_sampled / sad_16b_kernel /
+ *                                            svt_pme_sad_loop_kernel
  *   Source/Lib/Codec/aom_dsp_rtcd.h:856-860  svt_compute_mean_8x8, _mean_square_values_8x8,
  *                                            _sub_mean_8x8, svt_compute_interm_var_four8x8
  *   Source/Lib/Codec/motion_estimation.c:3146   svt_aom_motion_estimation_b64   (Tier B: whole frame)
@@ -39,6 +41,47 @@ SVT_HIP_API void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint
 SVT_HIP_API uint32_t svt_nxm_sad_kernel_hip(const uint8_t *src, uint32_t src_stride,
                                             const uint8_t *ref, uint32_t ref_stride,
                                             uint32_t height, uint32_t width);
+
+/* svt_nxm_sad_kernel_sub_sampled (aom_dsp_rtcd.h:853): the generic-C row of the reference's table binds this pointer to
+ * the plain N x M SAD (aom_dsp_rtcd.c:1213), which is what this computes. */
+SVT_HIP_API uint32_t svt_nxm_sad_kernel_sub_sampled_hip(const uint8_t *src, uint32_t src_stride,
+                                                        const uint8_t *ref, uint32_t ref_stride,
+                                                        uint32_t height, uint32_t width);
+/* sad_16b_kernel (aom_dsp_rtcd.h:861; the C function is svt_aom_sad_16b_kernel_c, compute_sad_c.c:39).
+ * svt_hip_rtcd_lookup("sad_16b_kernel") resolves to this export. */
+SVT_HIP_API uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_stride, uint16_t *ref,
+                                                uint32_t ref_stride, uint32_t height, uint32_t width);
+/* svt_initialize_buffer_32bits (aom_dsp_rtcd.h:852): count128 * 4 + count32 words set to `value`. */
+SVT_HIP_API void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32,
+                                                  uint32_t value);
+
+/* Mirrors of MV (block_structures.h:26-29) and of struct svt_mv_cost_param (mcomp.h:37-49): same field order, types
+ * and padding, so that a `const struct svt_mv_cost_param *` can be passed as is.  mv_cost_type holds MV_COST_TYPE
+ * (mcomp.h:29-36: ENTROPY 0, L1_LOWRES 1, L1_MIDRES 2, L1_HDRES 3, OPT 4, NONE 5); mvcost[0] / mvcost[1] point at the
+ * centre of the row / column cost tables (valid index range -(1 << 14) .. (1 << 14)). */
+typedef struct SvtHipMv {
+    int16_t row, col;
+} SvtHipMv;
+typedef struct SvtHipMvCostParam {
+    const SvtHipMv *ref_mv;
+    SvtHipMv        full_ref_mv;
+    uint8_t         mv_cost_type;
+    const int      *mvjcost;
+    const int      *mvcost[2];
+    int             error_per_bit;
+    int             early_exit_th;
+    int             sad_per_bit;
+} SvtHipMvCostParam;
+/* svt_pme_sad_loop_kernel (aom_dsp_rtcd.h:866; product_coding_loop.c:1781-1828): SAD + motion-vector cost over the
+ * sparse search grid (eight consecutive columns, then a jump of search_step; rows search_step apart); best_cost /
+ * best_mvx / best_mvy are updated only by a strictly smaller cost, the first position in scan order winning a tie. */
+SVT_HIP_API void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParam *mv_cost_params, uint8_t *src,
+                                             uint32_t src_stride, uint8_t *ref, uint32_t ref_stride,
+                                             uint32_t block_height, uint32_t block_width, uint32_t *best_cost,
+                                             int16_t *best_mvx, int16_t *best_mvy,
+                                             int16_t search_position_start_x, int16_t search_position_start_y,
+                                             int16_t search_area_width, int16_t search_area_height,
+                                             int16_t search_step, int16_t mvx, int16_t mvy);
 
 SVT_HIP_API void svt_ext_all_sad_calculation_8x8_16x16_hip(
     uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t mv,

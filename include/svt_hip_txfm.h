@@ -88,6 +88,34 @@ SVT_HIP_API void svt_av1_highbd_quantize_fp_qm_hip(SVT_HIP_QARGS, const uint8_t 
 /* Residual producer and transform-domain cost of the TPL dispenser / mode decision: svt_aom_subtract_block,
  * svt_aom_highbd_subtract_block (common_dsp_rtcd.h:234-237; src8 / pred8 of the highbd form are uint16 planes) and
  * svt_aom_satd (aom_dsp_rtcd.h:206-207). */
+/* Mirror of TxfmParam (definitions.h:1051-1063): TxType, TxSize and TxSetType are one-byte (packed) enums there. */
+typedef struct SvtHipTxfmParam {
+    uint8_t tx_type;
+    uint8_t tx_size;
+    int32_t lossless;
+    int32_t bd;
+    int32_t is_hbd;
+    uint8_t tx_set_type;
+    int32_t eob;
+} SvtHipTxfmParam;
+/* svt_av1_inv_txfm_add (common_dsp_rtcd.h:150; inv_transforms.c:3177-3193): 8-bit prediction + inverse transform ->
+ * 8-bit reconstruction, size and type taken from txfm_param.  bd must be 8 and lossless 0 (all the reference passes). */
+SVT_HIP_API void svt_av1_inv_txfm_add_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w,
+                                          int32_t stride_w, const SvtHipTxfmParam *txfm_param);
+/* svt_residual_kernel8bit / 16bit (common_dsp_rtcd.h:163,174), svt_spatial_full_distortion_kernel (:171),
+ * svt_full_distortion_kernel16_bits (:173: byte pointers that hold 16-bit samples; offsets and strides in samples) */
+SVT_HIP_API void svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride,
+                                             int16_t *residual, uint32_t residual_stride, uint32_t area_width,
+                                             uint32_t area_height);
+SVT_HIP_API void svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride,
+                                              int16_t *residual, uint32_t residual_stride, uint32_t area_width,
+                                              uint32_t area_height);
+SVT_HIP_API uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride,
+                                                            uint8_t *recon, int32_t recon_offset, uint32_t recon_stride,
+                                                            uint32_t area_width, uint32_t area_height);
+SVT_HIP_API uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride,
+                                                           uint8_t *pred, int32_t pred_offset, uint32_t pred_stride,
+                                                           uint32_t area_width, uint32_t area_height);
 SVT_HIP_API void svt_aom_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr,
                                             ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride);
 SVT_HIP_API void svt_aom_highbd_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride,

@@ -468,6 +468,47 @@ __global__ __launch_bounds__(256) void dist_kernel(const void *dst, int dstride,
 bool plane_ok(const SvtHipCdefPlane *p) {
     return p && p->recon && p->source && p->width && p->height && p->xdec <= 1 && p->ydec == p->xdec && (p->pli == 0 ? p->xdec == 0 : p->pli <= 2);
 }
+// svt_search_one_dual (enc_cdef.c:627-686).  mse: [2][sb_count][n] dense (luma, chroma), n = end_gi.  Each thread owns
+// (luma strength j, chroma strength k) pairs and walks the filter blocks in order, so every total is the same 64-bit sum as
+// the reference's; the winner is the smallest (total, pair number) — the first strict minimum of the reference's raster scan.
+__global__ __launch_bounds__(256) void search_one_dual_kernel(const uint64_t *__restrict__ mse, const int32_t *__restrict__ lev, int nb,
+                                                              int sb_count, int n, int start_gi, uint64_t *__restrict__ out) {
+    __shared__ uint64_t s_tot[256];
+    __shared__ uint32_t s_id[256];
+    const uint64_t     *m0 = mse, *m1 = mse + (size_t)sb_count * n;
+    const int           span = n - start_gi;
+    uint64_t            best = 1ull << 63;
+    uint32_t            best_id = 0xffffffffu;
+    for (int pair = threadIdx.x; pair < span * span; pair += 256) {
+        const int j = start_gi + pair / span, k = start_gi + pair % span;
+        uint64_t  tot = 0;
+        for (int i = 0; i < sb_count; i++) {
+            uint64_t cur = 1ull << 63;
+            for (int gi = 0; gi < nb; gi++) {
+                const uint64_t c = m0[(size_t)i * n + lev[gi]] + m1[(size_t)i * n + lev[8 + gi]];
+                cur              = c < cur ? c : cur;
+            }
+            const uint64_t c = m0[(size_t)i * n + j] + m1[(size_t)i * n + k];
+            tot += c < cur ? c : cur;
+        }
+        if (tot < best)  // pairs of one thread are visited in increasing order
+            best = tot, best_id = (uint32_t)pair;
+    }
+    s_tot[threadIdx.x] = best, s_id[threadIdx.x] = best_id;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const uint64_t t = s_tot[threadIdx.x + off];
+            const uint32_t d = s_id[threadIdx.x + off];
+            if (t < s_tot[threadIdx.x] || (t == s_tot[threadIdx.x] && d < s_id[threadIdx.x]))
+                s_tot[threadIdx.x] = t, s_id[threadIdx.x] = d;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[0] = s_tot[0], out[1] = s_id[0];
+}
+
 void fatal(const char *what) {
     fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
     abort();
@@ -604,4 +645,46 @@ extern "C" uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t
 extern "C" uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const SvtHipCdefList *dlist,
                                                    int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) {
     return dist_tier_a(dst8, dstride, src8, dlist, cdef_count, bsize, coeff_shift, pli, sub, 0);
+}
+
+// svt_search_one_dual (aom_dsp_rtcd.h:239): mse[0][i] / mse[1][i] are the luma / chroma tables of filter block i (TOTAL_STRENGTHS
+// entries each in the reference; entries below end_gi are read).  lev0 / lev1 hold nb_strengths chosen pairs and receive one more.
+extern "C" uint64_t svt_search_one_dual_hip(int *lev0, int *lev1, int nb_strengths, uint64_t **mse[2], int sb_count, int start_gi,
+                                            int end_gi) {
+    if (nb_strengths < 0 || nb_strengths >= 8 || start_gi < 0 || end_gi > 64 || sb_count < 0) {
+        set_error("svt_search_one_dual: nb_strengths %d / strength range %d..%d outside CDEF's limits", nb_strengths, start_gi, end_gi);
+        fatal("svt_search_one_dual");
+    }
+    if (end_gi <= start_gi) {  // nothing to search: the reference leaves (0, 0) and 1 << 63
+        lev0[nb_strengths] = lev1[nb_strengths] = 0;
+        return 1ull << 63;
+    }
+    if (!ensure_init())
+        fatal("svt_search_one_dual");
+    const size_t n = (size_t)end_gi, tab = up256((size_t)2 * sb_count * n * 8 + 8), o_lev = tab, o_res = o_lev + 256;
+    Scratch     &sc = tls_scratch();
+    uint8_t     *h = sc.host(o_res + 256), *d = sc.device(o_res + 256);
+    uint64_t    *m = (uint64_t *)h;
+    for (int p = 0; p < 2; p++)
+        for (int i = 0; i < sb_count; i++) memcpy(m + ((size_t)p * sb_count + i) * n, mse[p][i], n * 8);
+    int32_t *lv = (int32_t *)(h + o_lev);
+    for (int g = 0; g < 8; g++) lv[g] = g < nb_strengths ? lev0[g] : 0, lv[8 + g] = g < nb_strengths ? lev1[g] : 0;
+    for (int g = 0; g < nb_strengths; g++)
+        if (lev0[g] < 0 || lev0[g] >= end_gi || lev1[g] < 0 || lev1[g] >= end_gi) {
+            set_error("svt_search_one_dual: chosen strength outside the searched range");
+            fatal("svt_search_one_dual");
+        }
+    hipStream_t st = resolve_stream(nullptr);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, h, o_res, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(search_one_dual_kernel, dim3(1), dim3(256), 0, st, (const uint64_t *)d, (const int32_t *)(d + o_lev), nb_strengths,
+                       sb_count, end_gi, start_gi, (uint64_t *)(d + o_res));
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + o_res, d + o_res, 16, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    const uint64_t *res = (const uint64_t *)(h + o_res);
+    const int       span = end_gi - start_gi;
+    const uint32_t  id   = (uint32_t)res[1];
+    lev0[nb_strengths] = id == 0xffffffffu ? 0 : start_gi + (int)id / span;
+    lev1[nb_strengths] = id == 0xffffffffu ? 0 : start_gi + (int)id % span;
+    return res[0];
 }

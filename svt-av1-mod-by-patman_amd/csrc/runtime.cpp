@@ -247,9 +247,11 @@ int32_t svt_hip_stream_sync(void *stream) {
 #include <dlfcn.h>
 
 extern "C" void *svt_hip_rtcd_lookup(const char *name) {
-    // the one RTCD pointer of the path whose variable has no svt_ prefix (aom_dsp_rtcd.h:838)
+    // the two RTCD pointers of the path whose variables have no svt_ prefix (aom_dsp_rtcd.h:838, :861)
     if (name && strcmp(name, "downsample_2d") == 0)
         name = "svt_aom_downsample_2d";
+    if (name && strcmp(name, "sad_16b_kernel") == 0)  // aom_dsp_rtcd.h:861
+        name = "svt_aom_sad_16b_kernel";
     if (!name || strncmp(name, "svt_", 4) != 0 || strncmp(name, "svt_hip_", 8) == 0 || strlen(name) > 200)
         return nullptr;
     static void *self = [] {

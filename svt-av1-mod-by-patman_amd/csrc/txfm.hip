@@ -684,13 +684,14 @@ void fwd_tier_a(int w, int h, int shape, int16_t *input, int32_t *output, uint32
     memcpy(output, a.h + dsc->coeff_off, out_bytes);
 }
 
-void inv_tier_a(int w, int h, const int32_t *input, uint16_t *out_r, int32_t stride_r, uint16_t *out_w, int32_t stride_w,
-                int32_t tx_type, int32_t bd) {
+template <class PIX>
+void inv_tier_a(int w, int h, const int32_t *input, const PIX *out_r, int32_t stride_r, PIX *out_w, int32_t stride_w, int32_t tx_type,
+                int32_t bd) {
     if (txfm_ready() != SVT_HIP_OK)
         fatal("inverse transform");
     const int    iw = w < 32 ? w : 32, ih = h < 32 ? h : 32;
-    const size_t co_bytes = (size_t)iw * ih * 4, pr_bytes = ((size_t)(h - 1) * stride_r + w) * 2,
-                 rc_bytes = ((size_t)(h - 1) * stride_w + w) * 2;
+    const size_t co_bytes = (size_t)iw * ih * 4, pr_bytes = ((size_t)(h - 1) * stride_r + w) * sizeof(PIX),
+                 rc_bytes = ((size_t)(h - 1) * stride_w + w) * sizeof(PIX);
     Arena           a(1024 + up256(co_bytes + 16) + up256(pr_bytes + 16) + up256(rc_bytes + 16));
     SvtHipTxfmDesc *dsc = (SvtHipTxfmDesc *)a.h;
     memset(dsc, 0, sizeof(*dsc));
@@ -700,13 +701,13 @@ void inv_tier_a(int w, int h, const int32_t *input, uint16_t *out_r, int32_t str
     dsc->residual_off = dsc->coeff_off = dsc->qcoeff_off = dsc->qm_off = dsc->iqm_off = dsc->iscan_off = SVT_HIP_NO_OFFSET;
     dsc->pred_stride = (uint32_t)stride_r, dsc->recon_stride = (uint32_t)stride_w;
     dsc->tx_type = (uint8_t)tx_type, dsc->bit_depth = (uint8_t)bd;
-    dsc->quant_mode = SVT_HIP_QUANT_NONE, dsc->flags = SVT_HIP_TX_INV | SVT_HIP_TX_PIXEL16;
+    dsc->quant_mode = SVT_HIP_QUANT_NONE, dsc->flags = SVT_HIP_TX_INV | (sizeof(PIX) == 2 ? SVT_HIP_TX_PIXEL16 : 0);
     hipStream_t st = resolve_stream(nullptr);
     run_one(w, h, a, dsc->recon_off, st);
     SVT_HIP_CHECK_FATAL(hipMemcpyAsync(a.h + dsc->recon_off, a.d + dsc->recon_off, rc_bytes, hipMemcpyDeviceToHost, st));
     SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
-    const uint16_t *rc = (const uint16_t *)(a.h + dsc->recon_off);
-    for (int r = 0; r < h; r++) memcpy(out_w + (size_t)r * stride_w, rc + (size_t)r * stride_w, (size_t)w * 2);
+    const PIX *rc = (const PIX *)(a.h + dsc->recon_off);
+    for (int r = 0; r < h; r++) memcpy(out_w + (size_t)r * stride_w, rc + (size_t)r * stride_w, (size_t)w * sizeof(PIX));
 }
 
 void quant_tier_a(int mode, const int32_t *coeff_ptr, intptr_t n, const int16_t *zbin, const int16_t *round, const int16_t *quant,
@@ -794,6 +795,24 @@ HANDLE_DEF(16, 64) HANDLE_DEF(32, 64) HANDLE_DEF(64, 16) HANDLE_DEF(64, 32) HAND
 
 #define QA SVT_HIP_QARGS
 #define QP_ coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan
+// svt_av1_inv_txfm_add (common_dsp_rtcd.h:150; inv_transforms.c:3177-3193): the 8-bit destination form, dispatched on
+// txfm_param->tx_size like highbd_inv_txfm_add (:3112-3146).  The reference widens the prediction to 16 bits, transforms at
+// txfm_param->bd and narrows; with bd == 8 (the only value its callers pass, :3101,3163) that equals the 8-bit pixel path of
+// the kernel.  Lossless (the 4x4 Walsh-Hadamard form) is never requested by this reference version (full_loop.c:1703,1715
+// and src_ops_process.c:1157 pass 0) and is refused loudly.
+extern "C" void svt_av1_inv_txfm_add_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w,
+                                         const SvtHipTxfmParam *txfm_param) {
+    static const uint8_t wide[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
+    static const uint8_t high[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
+    if (!txfm_param || txfm_param->tx_size >= 19 || txfm_param->lossless || txfm_param->bd != 8) {
+        set_error("svt_av1_inv_txfm_add: unsupported parameters (tx_size %d, lossless %d, bd %d)", txfm_param ? txfm_param->tx_size : -1,
+                  txfm_param ? txfm_param->lossless : -1, txfm_param ? txfm_param->bd : -1);
+        fatal("inverse transform");
+    }
+    inv_tier_a<uint8_t>(wide[txfm_param->tx_size], high[txfm_param->tx_size], dqcoeff, dst_r, stride_r, dst_w, stride_w,
+                        txfm_param->tx_type, 8);
+}
+
 extern "C" void svt_aom_quantize_b_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B, QP_, qm, iqm, ls); }
 extern "C" void svt_av1_quantize_b_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B, QP_, qm, iqm, ls); }
 extern "C" void svt_aom_highbd_quantize_b_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B_HBD, QP_, qm, iqm, ls); }

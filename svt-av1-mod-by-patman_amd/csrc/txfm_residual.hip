@@ -93,7 +93,48 @@ void fatal(const char *what) {
     fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
     abort();
 }
+// sum (a - b)^2 over a w x h area of pixels (svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits)
+template <class PIX>
+__global__ __launch_bounds__(256) void spatial_sse_kernel(const PIX *__restrict__ a, int as, const PIX *__restrict__ b, int bs, int w, int h,
+                                                          unsigned long long *__restrict__ out) {
+    uint64_t acc = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        const int     r = i / w, c = i - r * w;
+        const int64_t d = (int64_t)a[(size_t)r * as + c] - (int64_t)b[(size_t)r * bs + c];
+        acc += (uint64_t)(d * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(out, (unsigned long long)acc);
+}
+
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+template <class PIX>
+uint64_t spatial_sse_tier_a(const PIX *a, uint32_t as, const PIX *b, uint32_t bs, uint32_t w, uint32_t h, const char *what) {
+    if (!w || !h)
+        return 0;
+    if (!ensure_init())
+        fatal(what);
+    const size_t pix = (size_t)w * h, pb = up256(pix * sizeof(PIX));
+    Scratch     &sc = tls_scratch();
+    uint8_t     *hh = sc.host(2 * pb + 256), *d = sc.device(2 * pb + 256);
+    for (uint32_t r = 0; r < h; r++) {
+        memcpy(hh + (size_t)r * w * sizeof(PIX), a + (size_t)r * as, (size_t)w * sizeof(PIX));
+        memcpy(hh + pb + (size_t)r * w * sizeof(PIX), b + (size_t)r * bs, (size_t)w * sizeof(PIX));
+    }
+    memset(hh + 2 * pb, 0, 8);
+    hipStream_t st = resolve_stream(nullptr);
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, hh, 2 * pb + 8, hipMemcpyHostToDevice, st));
+    const int blocks = (int)((pix + 255) / 256);
+    hipLaunchKernelGGL((spatial_sse_kernel<PIX>), dim3(blocks < 256 ? blocks : 256), dim3(256), 0, st, (const PIX *)d, (int)w,
+                       (const PIX *)(d + pb), (int)w, (int)w, (int)h, (unsigned long long *)(d + 2 * pb));
+    SVT_HIP_CHECK_FATAL(hipGetLastError());
+    SVT_HIP_CHECK_FATAL(hipMemcpyAsync(hh + 2 * pb, d + 2 * pb, 8, hipMemcpyDeviceToHost, st));
+    SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
+    return *(const uint64_t *)(hh + 2 * pb);
+}
 
 template <class PIX>
 void subtract_tier_a(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const PIX *src, ptrdiff_t src_stride, const PIX *pred,
@@ -132,6 +173,30 @@ extern "C" void svt_aom_highbd_subtract_block_hip(int rows, int cols, int16_t *d
     (void)bd;
     subtract_tier_a<uint16_t>(rows, cols, diff_ptr, diff_stride, (const uint16_t *)src_ptr, src_stride, (const uint16_t *)pred_ptr,
                               pred_stride);
+}
+// svt_residual_kernel8bit / 16bit (common_dsp_rtcd.h:163,174; pic_operators.c:101-143): the same difference with the
+// operands in another order
+extern "C" void svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual,
+                                            uint32_t residual_stride, uint32_t area_width, uint32_t area_height) {
+    subtract_tier_a<uint8_t>((int)area_height, (int)area_width, residual, residual_stride, input, input_stride, pred, pred_stride);
+}
+extern "C" void svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual,
+                                             uint32_t residual_stride, uint32_t area_width, uint32_t area_height) {
+    subtract_tier_a<uint16_t>((int)area_height, (int)area_width, residual, residual_stride, input, input_stride, pred, pred_stride);
+}
+// svt_spatial_full_distortion_kernel (common_dsp_rtcd.h:171; picture_operators_c.c:62-78) and svt_full_distortion_kernel16_bits
+// (common_dsp_rtcd.h:173; pic_operators.c:174-196: byte pointers reinterpreted as 16-bit samples, offsets in samples)
+extern "C" uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon,
+                                                           int32_t recon_offset, uint32_t recon_stride, uint32_t area_width,
+                                                           uint32_t area_height) {
+    return spatial_sse_tier_a<uint8_t>(input + input_offset, input_stride, recon + recon_offset, recon_stride, area_width, area_height,
+                                       "svt_spatial_full_distortion_kernel");
+}
+extern "C" uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *pred,
+                                                          int32_t pred_offset, uint32_t pred_stride, uint32_t area_width,
+                                                          uint32_t area_height) {
+    return spatial_sse_tier_a<uint16_t>((const uint16_t *)input + input_offset, input_stride, (const uint16_t *)pred + pred_offset,
+                                        pred_stride, area_width, area_height, "svt_full_distortion_kernel16_bits");
 }
 extern "C" int svt_aom_satd_hip(const int32_t *coeff, int length) {
     if (length <= 0)

@@ -258,3 +258,17 @@ class TfBlock(C.Structure):              # SvtHipTfBlock (include/svt_hip_tf.h)
 
 class TfOut(C.Structure):                # SvtHipTfOut
     _fields_ = [("dst", C.c_void_p * 3), ("dst_stride", C.c_uint32 * 3), ("pad_", C.c_uint32)]
+
+
+class Mv(C.Structure):                   # SvtHipMv == MV (block_structures.h:26-29)
+    _fields_ = [("row", C.c_int16), ("col", C.c_int16)]
+
+
+class MvCostParam(C.Structure):          # SvtHipMvCostParam == struct svt_mv_cost_param (mcomp.h:37-49)
+    _fields_ = [("ref_mv", C.POINTER(Mv)), ("full_ref_mv", Mv), ("mv_cost_type", C.c_uint8), ("mvjcost", C.c_void_p),
+                ("mvcost", C.c_void_p * 2), ("error_per_bit", C.c_int), ("early_exit_th", C.c_int), ("sad_per_bit", C.c_int)]
+
+
+class TxfmParam(C.Structure):            # SvtHipTxfmParam == TxfmParam (definitions.h:1051-1063)
+    _fields_ = [("tx_type", C.c_uint8), ("tx_size", C.c_uint8), ("lossless", C.c_int32), ("bd", C.c_int32), ("is_hbd", C.c_int32),
+                ("tx_set_type", C.c_uint8), ("eob", C.c_int32)]

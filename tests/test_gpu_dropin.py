@@ -22,7 +22,7 @@ class Binding(C.Structure):
     _fields_ = [("name", C.c_char_p), ("slot", C.c_void_p)]
 
 
-ALIAS = {"svt_aom_downsample_2d": "downsample_2d"}     # export stem -> the reference's pointer variable (aom_dsp_rtcd.h:838)
+ALIAS = {"svt_aom_downsample_2d": "downsample_2d", "svt_aom_sad_16b_kernel": "sad_16b_kernel"}     # export stem -> the reference's pointer variable (aom_dsp_rtcd.h:838, :861)
 
 
 def tier_a_pointer_names():
