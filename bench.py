@@ -463,6 +463,7 @@ def bench_lf(lib, dev, args, world, rank):
     timed("sgr_apply_luma", lambda: LB.run_sgr_apply(lib, inp, sp), 2 * P * d)
     timed("wiener_stats_luma_win7", lambda: LB.run_wiener_stats(lib, inp, sp), 2 * P * d + inp["n_wiener"] * (49 + 49 * 49) * 8)
     timed("wiener_convolve_luma", lambda: LB.run_wiener_convolve(lib, inp, sp), 2 * P * d)
+    timed("tf_noise_estimate_luma", lambda: LB.run_tf_noise(lib, inp, sp), P * d)
     shard.barrier()
     if rank == 0:
         worst = min(stages.items(), key=lambda kv: kv[1]["GBps"])

@@ -62,6 +62,24 @@ typedef struct SvtHipTfOut {
 } SvtHipTfOut;
 SVT_HIP_API int32_t svt_hip_tf_normalise_batch(const SvtHipTfBlock *d_blocks, const SvtHipTfOut *d_out, uint32_t n_blocks, void *stream);
 
+/* ---- noise estimate (svt_estimate_noise_fp16 / svt_estimate_noise_highbd_fp16, aom_dsp_rtcd.h:874-877;
+ * temporal_filtering.c:3668-3736): over the interior of one plane, the mean absolute Laplacian of the samples whose
+ * Sobel gradient magnitude is below EDGE_THRESHOLD, scaled by sqrt(pi/2)/6, in 16.16 fixed point; -65536 when fewer
+ * than SMOOTH_THRESHOLD samples qualify.  Callers: pd_process.c:2990-3041 (per plane, before the temporal filter),
+ * md_config_process.c:499. */
+typedef struct SvtHipTfNoise {
+    uint64_t sum;        /* sum of |Laplacian| (rounded down to 8-bit scale for deeper samples) over the smooth samples */
+    uint64_t num;        /* number of smooth samples */
+    int32_t  noise_fp16; /* the reference's return value */
+    int32_t  pad_;
+} SvtHipTfNoise;
+/* Tier B: device plane in, device record out (zeroed by the call); stride in samples. */
+SVT_HIP_API int32_t svt_hip_tf_estimate_noise(const void *d_src, uint32_t width, uint32_t height, uint32_t stride,
+                                              int32_t is_16bit, int32_t bit_depth, SvtHipTfNoise *d_out, void *stream);
+/* Tier A: the RTCD signatures (host pointers). */
+SVT_HIP_API int32_t svt_estimate_noise_fp16_hip(const uint8_t *src, uint16_t width, uint16_t height, uint16_t stride_y);
+SVT_HIP_API int32_t svt_estimate_noise_highbd_fp16_hip(const uint16_t *src, int width, int height, int stride, int bd);
+
 #ifdef __cplusplus
 }
 #endif

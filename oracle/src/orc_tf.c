@@ -9,6 +9,7 @@
  * tests/golden/tf.npz. */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/svt_hip_tf.h"
 
@@ -153,4 +154,28 @@ ORC_API void orc_tf_normalise(const SvtHipTfBlock *b, const SvtHipTfOut *o) {
                     ((uint8_t *)o->dst[pl])[(size_t)i * o->dst_stride[pl] + j] = (uint8_t)v;
             }
     }
+}
+
+/* svt_estimate_noise_fp16_c / svt_estimate_noise_highbd_fp16_c (temporal_filtering.c:3668-3736); stride in samples,
+ * bd is 8 for 8-bit planes (no rounding shift). */
+ORC_API int32_t orc_estimate_noise(const void *src, int width, int height, int stride, int is16, int bd) {
+    int64_t   sum = 0, num = 0;
+    const int sh = is16 ? bd - 8 : 0, rnd = sh ? 1 << (sh - 1) : 0;
+#define PX(r, c) (is16 ? (int)((const uint16_t *)src)[(size_t)(r) * stride + (c)] : (int)((const uint8_t *)src)[(size_t)(r) * stride + (c)])
+    for (int i = 1; i < height - 1; i++)
+        for (int j = 1; j < width - 1; j++) {
+            const int gx = (PX(i - 1, j - 1) - PX(i - 1, j + 1)) + (PX(i + 1, j - 1) - PX(i + 1, j + 1)) + 2 * (PX(i, j - 1) - PX(i, j + 1));
+            const int gy = (PX(i - 1, j - 1) - PX(i + 1, j - 1)) + (PX(i - 1, j + 1) - PX(i + 1, j + 1)) + 2 * (PX(i - 1, j) - PX(i + 1, j));
+            const int ga = (abs(gx) + abs(gy) + rnd) >> sh;
+            if (ga < 50) {
+                const int v = 4 * PX(i, j) - 2 * (PX(i, j - 1) + PX(i, j + 1) + PX(i - 1, j) + PX(i + 1, j)) +
+                    (PX(i - 1, j - 1) + PX(i - 1, j + 1) + PX(i + 1, j - 1) + PX(i + 1, j + 1));
+                sum += (abs(v) + rnd) >> sh;
+                num++;
+            }
+        }
+#undef PX
+    if (num < 16)
+        return -65536;
+    return (int32_t)((sum * 82137) / (6 * num));
 }

@@ -150,3 +150,13 @@ def run_wiener_convolve(lib, inp, sp):
     off = (PAD * (W + 2 * PAD) + PAD) * 2
     _chk(lib, lib.svt_hip_wiener_convolve(C.c_void_p(inp["ptr"](inp["planes"][0], W)), W + 2 * PAD, C.c_void_p(out.data_ptr() + off),
                                           W + 2 * PAD, W, H, inp["wfx"], inp["wfy"], 1, inp["bd"], sp))
+
+
+def run_tf_noise(lib, inp, sp):
+    """The temporal filter's noise estimate over the luma plane (svt_hip_tf_estimate_noise)."""
+    W, H = inp["W"], inp["H"]
+    if "d_noise" not in inp:
+        import torch
+        inp["d_noise"] = torch.zeros(24, dtype=torch.uint8, device=inp["planes"][0].device)
+    _chk(lib, lib.svt_hip_tf_estimate_noise(C.c_void_p(inp["ptr"](inp["planes"][0], W)), C.c_uint32(W), C.c_uint32(H), C.c_uint32(W + 2 * PAD), 1,
+                                            inp["bd"], C.c_void_p(inp["d_noise"].data_ptr()), sp))

@@ -27,3 +27,12 @@ for bd in (8, 10):
         k += 1
 np.savez_compressed(os.path.join(HERE, "tf.npz"), **store)
 print("tf.npz:", k, "cases", os.path.getsize(os.path.join(HERE, "tf.npz")), "bytes")
+
+# noise estimate: the reference's dispatch pointers on the seeded planes of tf_cases.noise_cases(); only the results are stored
+from test_txfm_oracle import rtcd  # noqa: E402
+V = C.c_void_p
+lo = rtcd(ref, "svt_estimate_noise_fp16", C.c_int32, V, C.c_uint16, C.c_uint16, C.c_uint16)
+hi = rtcd(ref, "svt_estimate_noise_highbd_fp16", C.c_int32, V, C.c_int, C.c_int, C.c_int, C.c_int)
+noise = [lo(img.ctypes.data, w, h, stride) if bd == 8 else hi(img.ctypes.data, w, h, stride, bd) for img, w, h, stride, bd in F.noise_cases()]
+np.savez_compressed(os.path.join(HERE, "tf_noise.npz"), noise=np.array(noise, np.int64))
+print("tf_noise.npz:", len(noise), "values", noise[:8])

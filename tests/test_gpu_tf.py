@@ -129,3 +129,27 @@ def test_central_accumulate_normalise_chain(hip, orc, bd):
             assert np.array_equal(acc, a[pl][2]) and np.array_equal(cnt, a[pl][3]), ("accum", i, pl)
             got = outs_d[3 * i + pl].download(dt, outs_h[3 * i + pl].shape)
             assert np.array_equal(got, outs_h[3 * i + pl]), ("pixels", i, pl)
+
+
+def test_noise_estimate(hip, orc):
+    """svt_estimate_noise_fp16_hip / svt_estimate_noise_highbd_fp16_hip (Tier A) and svt_hip_tf_estimate_noise (Tier B, device
+    plane) against the oracle and the values the real reference produced (golden/tf_noise.npz) — bit-exact."""
+    from test_tf_oracle import GOLD_NOISE, orc_noise
+    gold = np.load(GOLD_NOISE)["noise"]
+    hip.svt_estimate_noise_fp16_hip.restype = C.c_int32
+    hip.svt_estimate_noise_highbd_fp16_hip.restype = C.c_int32
+    rec = np.dtype([("sum", "<u8"), ("num", "<u8"), ("noise", "<i4"), ("pad", "<i4")])
+    for i, (img, w, h, stride, bd) in enumerate(F.noise_cases()):
+        exp = orc_noise(orc, img, w, h, stride, bd)
+        assert exp == int(gold[i])
+        if bd == 8:
+            got = hip.svt_estimate_noise_fp16_hip(C.c_void_p(img.ctypes.data), C.c_uint16(w), C.c_uint16(h), C.c_uint16(stride))
+        else:
+            got = hip.svt_estimate_noise_highbd_fp16_hip(C.c_void_p(img.ctypes.data), w, h, stride, bd)
+        assert got == exp, (w, h, bd)
+        dsrc, dout = device.DeviceBuffer(hip, img.nbytes), device.DeviceBuffer(hip, rec.itemsize)
+        dsrc.upload(img.view(np.uint8).reshape(-1))
+        device.check(hip, hip.svt_hip_tf_estimate_noise(C.c_void_p(dsrc.ptr), C.c_uint32(w), C.c_uint32(h), C.c_uint32(stride), int(bd > 8), bd,
+                                                        C.c_void_p(dout.ptr), None), "svt_hip_tf_estimate_noise")
+        out = dout.download(np.uint8, rec.itemsize).view(rec)[0]
+        assert int(out["noise"]) == exp and (int(out["num"]) >= 16) == (exp != -65536), (w, h, bd)

@@ -43,3 +43,31 @@ def block_case(trial, bd, seed=0):
     b.chroma, b.ss_x, b.ss_y, b.is_16bit, b.bit_depth = int(trial % 3 != 2), ss, ss, int(is16), bd
     b.zz_based = int(trial % 4 == 3)
     return b, arrs
+
+
+def noise_cases():
+    """(plane, width, height, stride, bit depth) for the noise estimate: textures with every mix of smooth and edge samples,
+    degenerate sizes (no interior / fewer than SMOOTH_THRESHOLD smooth samples) and a frame-sized plane."""
+    rng = np.random.default_rng(77)
+    k = 0
+    for w, h in ((64, 48), (131, 77), (3, 3), (2, 9), (9, 2), (6, 5), (257, 33), (640, 360), (1920, 1080)):
+        for bd in (8, 10, 12):
+            if w * h > 100000 and bd == 12:
+                continue
+            stride = w + int(rng.integers(0, 17))
+            hi = (1 << bd) - 1
+            kind = k % 5
+            if kind == 0:       # smooth ramp + mild noise: most samples qualify
+                base = np.add.outer(np.arange(h), np.arange(stride)) * (hi / 512.0) % (hi * 0.8)
+                img = base + rng.normal(0, 2.0 * (1 << (bd - 8)), size=(h, stride))
+            elif kind == 1:     # white noise: almost everything is an edge
+                img = rng.integers(0, hi + 1, size=(h, stride))
+            elif kind == 2:     # flat: all smooth, Laplacian zero
+                img = np.full((h, stride), hi // 3)
+            elif kind == 3:     # blocks with hard edges + noise
+                img = (np.add.outer(np.arange(h) // 8, np.arange(stride) // 8) % 2) * (hi * 0.6) + rng.normal(0, 3.0 * (1 << (bd - 8)), size=(h, stride))
+            else:               # extremes
+                img = rng.integers(0, 2, size=(h, stride)) * hi
+            img = np.clip(np.rint(img), 0, hi).astype(np.uint8 if bd == 8 else np.uint16)
+            k += 1
+            yield img, w, h, stride, bd
