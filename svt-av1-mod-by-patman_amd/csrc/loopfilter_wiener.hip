@@ -6,10 +6,12 @@
 // y[k] = dgd(sample + tap k) - avg.  Here the RAW second moments are accumulated instead and the mean is folded in at the
 // end (exact integer algebra: sum (a - m)(b - m) = sum ab - m sum a - m sum b + N m^2), so no pre-pass over the unit is
 // needed for `avg`.  One workgroup owns a 64 x 32 tile of the unit, staged in LDS with its border; a thread owns one
-// pair of tap COLUMNS (c1 <= c2): per PAIR of horizontally adjacent samples it reads the 7 + 7 vertical taps of its two
-// columns (one aligned 32-bit LDS read per tap: the tile is kept twice, the second copy shifted by one sample) and does
-// the 49 multiply-accumulates of that 7 x 7 block of H as 49 v_dot2_u32_u16 in registers (uint32 partials, flushed per
-// tile to int64).  28 column pairs + 7 column-by-source blocks x 7 sample slices fill the 256 lanes.
+// pair of tap COLUMNS (c1 <= c2) — or a tap column and the source, which is the same sliding block — and walks DOWN a
+// column of horizontally adjacent sample PAIRS: per step it reads one new row of each of its two columns (one aligned
+// 32-bit LDS read each: the tile is kept twice, the second copy shifted by one sample; the other six vertical taps are
+// the previous step's) and does the 49 multiply-accumulates of that 7 x 7 block of H as 49 v_dot2_u32_u16 in registers
+// (uint32 partials, flushed per tile to int64).  28 column pairs + 7 column-by-source blocks x 7 column slices fill the
+// 256 lanes; the first moments come from column sums of the tile.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,15 +43,17 @@ template <int WIN>
 __global__ __launch_bounds__(256, 4) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int is16, int th,
                                                            long long *__restrict__ M, long long *__restrict__ H, StatsAux *__restrict__ aux) {
     constexpr int HALF = WIN / 2, W2 = WIN * WIN;
-    constexpr int NPAIR = WIN * (WIN + 1) / 2, NJOB = NPAIR + WIN + 1;  // column pairs, column x source, source sum
-    constexpr int NSL = 256 / NJOB;                                      // sample slices
+    constexpr int NPAIR = WIN * (WIN + 1) / 2, NJOB = NPAIR + WIN;  // column pairs (blocks of H), column x source (rows of M)
+    constexpr int NSL = 256 / NJOB;                                  // column slices per job
     constexpr int DP = TW + 2 * 3 + 2;
     // d1 is d shifted left by one sample: a thread whose column offset is odd reads its sample PAIRS from d1, so that every
-    // pair is one aligned 32-bit LDS read
+    // pair is one aligned 32-bit LDS read.  s holds the source rows HALF rows down (rows above / below: zero), which makes a
+    // column-by-source job the same sliding 7 x 7 block as a column pair: its middle column is the row of M.
     __shared__ __attribute__((aligned(4))) uint16_t d[(TH + 2 * 3) * DP];
     __shared__ __attribute__((aligned(4))) uint16_t d1[(TH + 2 * 3) * DP];
-    __shared__ __attribute__((aligned(4))) uint16_t s[TH * TW];
-    __shared__ long long Hl[W2 * W2], Ml[W2], Sl[W2], misc[2];  // this workgroup's totals (int64), flushed once at the end
+    __shared__ __attribute__((aligned(4))) uint16_t s[(TH + 2 * 3) * TW];
+    __shared__ uint32_t  cs[WIN][TW + 2 * 3];                     // column sums of d over the tile rows, per vertical tap
+    __shared__ long long Hl[W2 * W2], Ml[W2], Sl[W2], misc[2];    // this workgroup's totals (int64), flushed once at the end
     const SvtHipWienerUnit u = units[blockIdx.z];
     const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
     const int x0 = blockIdx.x * TW;
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(256, 4) void wiener_stats_kernel(const SvtHipWiener
         Ml[threadIdx.x] = 0, Sl[threadIdx.x] = 0;
     if (threadIdx.x < 2)
         misc[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < (TH + 2 * 3) * TW; i += 256) s[i] = 0;
     const int job = threadIdx.x / NSL, sl = threadIdx.x - job * NSL;
     int       c1 = 0, c2 = 0;
     if (job < NPAIR) {  // column pair (c1 <= c2) from the triangular index
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(256, 4) void wiener_stats_kernel(const SvtHipWiener
     } else {
         c1 = job - NPAIR;
     }
+    const bool is_m = job >= NPAIR;
     for (int chunk = 0; chunk < CHUNKS; chunk++) {
         const int y0 = (blockIdx.y * CHUNKS + chunk) * th;
         if (y0 >= uh)
@@ -83,72 +89,95 @@ __global__ __launch_bounds__(256, 4) void wiener_stats_kernel(const SvtHipWiener
             if (c)
                 d1[r * DP + c - 1] = v;
         }
-        for (int idx = threadIdx.x; idx < npx; idx += 256) {
-            const int r = idx / tw, c = idx - r * tw;
-            s[r * TW + c] = (uint16_t)ldpx(u.src, (size_t)((ptrdiff_t)(u.v_start + y0 + r) * u.src_stride + (u.h_start + x0 + c)), is16);
+        for (int idx = threadIdx.x; idx < (tv + HALF) * TW; idx += 256) {   // rows below a short last chunk read as zero again
+            const int r = idx / TW, c = idx - r * TW;
+            s[(r + HALF) * TW + c] = r < tv && c < tw
+                ? (uint16_t)ldpx(u.src, (size_t)((ptrdiff_t)(u.v_start + y0 + r) * u.src_stride + (u.h_start + x0 + c)), is16) : (uint16_t)0;
         }
         __syncthreads();
         // Two horizontally adjacent samples per step: each multiply-accumulate of the block is one v_dot2_u32_u16 over the
-        // pair.  hw = pairs per row; the partner of the last sample of an odd-width tile is masked to zero.
-        const int hw = (tw + 1) >> 1, npair = tv * hw;
-        if (job < NPAIR) {
+        // pair (the partner of the last sample of an odd-width tile is masked to zero).  A thread walks DOWN its sample
+        // columns: the WIN vertical taps of one row are WIN - 1 of the previous row's, so a step costs two LDS reads for the
+        // WIN x WIN multiply-accumulates; the row loop is unrolled WIN times, which makes the rotation of the tap registers
+        // a renaming.
+        const int hw = (tw + 1) >> 1;
+        if (job < NJOB) {
             uint32_t acc[WIN][WIN];
 #pragma unroll
             for (int a = 0; a < WIN; a++)
 #pragma unroll
                 for (int b = 0; b < WIN; b++) acc[a][b] = 0;
-            const uint16_t *ta = (c1 & 1) ? d1 - 1 : d, *tb = (c2 & 1) ? d1 - 1 : d;
-            for (int pj = sl; pj < npair; pj += NSL) {
-                const int      r = pj / hw, c = 2 * (pj - r * hw);
+            const uint16_t *ta = ((c1 & 1) ? d1 - 1 : d) + c1;
+            const uint16_t *tb = is_m ? s : ((c2 & 1) ? d1 - 1 : d) + c2;
+            const int       pb = is_m ? TW : DP;
+            for (int cp = sl; cp < hw; cp += NSL) {
+                const int      c    = 2 * cp;
                 const uint32_t mask = c + 1 < tw ? 0xffffffffu : 0x0000ffffu;
-                u16x2          va[WIN], vb[WIN];
+                const uint16_t *qa = ta + c, *qb = tb + c;
+                u16x2           va[WIN], vb[WIN];
 #pragma unroll
-                for (int k = 0; k < WIN; k++) {
-                    va[k] = __builtin_bit_cast(u16x2, *(const uint32_t *)&ta[(r + k) * DP + c + c1] & mask);
-                    vb[k] = __builtin_bit_cast(u16x2, *(const uint32_t *)&tb[(r + k) * DP + c + c2]);
+                for (int k = 0; k < WIN - 1; k++) {
+                    va[k] = __builtin_bit_cast(u16x2, *(const uint32_t *)&qa[k * DP] & mask);
+                    vb[k] = __builtin_bit_cast(u16x2, *(const uint32_t *)&qb[k * pb]);
                 }
+                for (int r = 0; r < tv; r += WIN) {
+#pragma unroll
+                    for (int j = 0; j < WIN; j++) {
+                        if (r + j < tv) {
+                            constexpr int NEWEST = WIN - 1;
+                            va[(j + NEWEST) % WIN] = __builtin_bit_cast(u16x2, *(const uint32_t *)&qa[(r + j + NEWEST) * DP] & mask);
+                            vb[(j + NEWEST) % WIN] = __builtin_bit_cast(u16x2, *(const uint32_t *)&qb[(r + j + NEWEST) * pb]);
+#pragma unroll
+                            for (int a = 0; a < WIN; a++)
+#pragma unroll
+                                for (int b = 0; b < WIN; b++)
+                                    acc[a][b] = __builtin_amdgcn_udot2(va[(j + a) % WIN], vb[(j + b) % WIN], acc[a][b], false);
+                        }
+                    }
+                }
+            }
+            if (!is_m) {
+                // tap index = column * WIN + row (restoration_pick.c:686-691); only the upper triangle k <= l is kept
 #pragma unroll
                 for (int a = 0; a < WIN; a++)
 #pragma unroll
-                    for (int b = 0; b < WIN; b++) acc[a][b] = __builtin_amdgcn_udot2(va[a], vb[b], acc[a][b], false);
+                    for (int b = 0; b < WIN; b++) {
+                        const int k = c1 * WIN + a, l = c2 * WIN + b;
+                        if (k <= l && acc[a][b])
+                            atomicAdd((unsigned long long *)&Hl[k * W2 + l], (unsigned long long)acc[a][b]);
+                    }
+            } else {
+#pragma unroll
+                for (int a = 0; a < WIN; a++) atomicAdd((unsigned long long *)&Ml[c1 * WIN + a], (unsigned long long)acc[a][HALF]);
             }
-            // tap index = column * WIN + row (restoration_pick.c:686-691); only the upper triangle k <= l is kept
-#pragma unroll
-            for (int a = 0; a < WIN; a++)
-#pragma unroll
-                for (int b = 0; b < WIN; b++) {
-                    const int k = c1 * WIN + a, l = c2 * WIN + b;
-                    if (k <= l && acc[a][b])
-                        atomicAdd((unsigned long long *)&Hl[k * W2 + l], (unsigned long long)acc[a][b]);
-                }
-        } else if (job < NPAIR + WIN) {
-            uint32_t t[WIN], f[WIN];
-#pragma unroll
-            for (int a = 0; a < WIN; a++) t[a] = 0, f[a] = 0;
-            const uint16_t *ta = (c1 & 1) ? d1 - 1 : d;
-            for (int pj = sl; pj < npair; pj += NSL) {
-                const int      r = pj / hw, c = 2 * (pj - r * hw);
-                const uint32_t mask = c + 1 < tw ? 0xffffffffu : 0x0000ffffu;
-                const u16x2    x = __builtin_bit_cast(u16x2, *(const uint32_t *)&s[r * TW + c] & mask);
-                const u16x2    one = __builtin_bit_cast(u16x2, 0x00010001u & mask);
-#pragma unroll
-                for (int k = 0; k < WIN; k++) {
-                    const u16x2 v = __builtin_bit_cast(u16x2, *(const uint32_t *)&ta[(r + k) * DP + c + c1]);
-                    t[k] = __builtin_amdgcn_udot2(v, x, t[k], false), f[k] = __builtin_amdgcn_udot2(v, one, f[k], false);
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < WIN; a++) {
-                atomicAdd((unsigned long long *)&Ml[c1 * WIN + a], (unsigned long long)t[a]);
-                atomicAdd((unsigned long long *)&Sl[c1 * WIN + a], (unsigned long long)f[a]);
-            }
-        } else if (job == NPAIR + WIN) {
-            long long ss = 0;
-            for (int pi = sl; pi < npx; pi += NSL) ss += s[(pi / tw) * TW + (pi % tw)];
-            atomicAdd((unsigned long long *)&misc[0], (unsigned long long)ss);
-            if (sl == 0)
-                atomicAdd((unsigned long long *)&misc[1], (unsigned long long)npx);
         }
+        // first moments: sum of dgd under every tap = column sums of the tile slid down the WIN vertical taps, then summed
+        // over the tw columns behind each horizontal tap; the source sum likewise
+        if ((int)threadIdx.x < tw + 2 * HALF) {
+            const int x = threadIdx.x;
+            uint32_t  w = 0;
+            for (int r = 0; r < tv; r++) w += d[r * DP + x];
+            cs[0][x] = w;
+#pragma unroll
+            for (int a = 1; a < WIN; a++) {
+                w += (uint32_t)d[(tv + a - 1) * DP + x] - (uint32_t)d[(a - 1) * DP + x];
+                cs[a][x] = w;
+            }
+        } else if (threadIdx.x >= 128 && (int)threadIdx.x < 128 + tw) {
+            const int x = threadIdx.x - 128;
+            long long ss = 0;
+            for (int r = 0; r < tv; r++) ss += s[(r + HALF) * TW + x];
+            atomicAdd((unsigned long long *)&misc[0], (unsigned long long)ss);
+        }
+        __syncthreads();
+        if (threadIdx.x < W2) {  // k = column * WIN + row
+            const int cc = threadIdx.x / WIN, a = threadIdx.x - cc * WIN;
+            long long t = 0;
+            for (int c = 0; c < tw; c++) t += cs[a][c + cc];
+            Sl[threadIdx.x] += t;
+        }
+        if (threadIdx.x == 0)
+            misc[1] += npx;
     }
     __syncthreads();
     long long *Hu = H + (size_t)blockIdx.z * W2MAX * W2MAX, *Mu = M + (size_t)blockIdx.z * W2MAX;
