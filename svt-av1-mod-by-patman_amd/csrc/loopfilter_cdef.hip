@@ -132,6 +132,57 @@ __device__ __forceinline__ s16x2 cdef_pair(const uint16_t *p0, const uint16_t *p
     return __builtin_elementwise_min(y, mx);
 }
 
+// ---- several strengths over one set of taps (the search) -------------------------------------------------------------
+// Everything about a sample pair that does not depend on the strength is formed once: the twelve tap pairs, |tap - x|, the
+// sign folded into the tap weight (unit weights for the primary taps, whose two weights depend on the strength), and the
+// clamp range.  A strength then costs five packed instructions per tap: shift, subtract, max 0, min, multiply-add.
+struct PairTaps {
+    s16x2 x, mn, mx;
+    s16x2 ad[12];  // |tap - x|;                index = 6 * distance + q, q < 2 primary, q >= 2 secondary
+    s16x2 w[12];   // primary: +-1; secondary: +-{2, 1} by distance
+};
+__device__ __forceinline__ void pair_taps(PairTaps &T, const uint16_t *p0, const uint16_t *p1, int dir) {
+    T.x  = __builtin_bit_cast(s16x2, *(const uint32_t *)p0);
+    T.mx = T.x, T.mn = T.x;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int   o0 = DIRS_T[dir + 2][k], o1 = DIRS_T[dir + 4][k], o2 = DIRS_T[dir][k];
+        const s16x2 t[6] = {ldpair(p0, p1, o0), ldpair(p0, p1, -o0), ldpair(p0, p1, o1), ldpair(p0, p1, -o1), ldpair(p0, p1, o2), ldpair(p0, p1, -o2)};
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const s16x2 d  = t[q] - T.x;
+            const s16x2 sg = d >> (s16x2)((short)15);
+            T.ad[6 * k + q] = __builtin_elementwise_max(d, -d);
+            T.w[6 * k + q]  = q < 2 ? (sg | splat2(1)) : ((splat2(k ? 1 : 2) ^ sg) - sg);
+            const s16x2 vl = -(s16x2)((u16x2)t[q] >> (u16x2)((unsigned short)14));  // CDEF_VERY_LARGE takes no part in the maximum
+            T.mx = __builtin_elementwise_max(T.mx, t[q] & ~vl);
+            T.mn = __builtin_elementwise_min(T.mn, t[q]);
+        }
+    }
+}
+// thr_p / shp / pt0 / pt1: primary threshold, its shift and the two primary tap weights (splat); thr_s / shs: secondary
+__device__ __forceinline__ s16x2 pair_eval(const PairTaps &T, s16x2 thr_p, s16x2 shp, s16x2 pt0, s16x2 pt1, int thr_s, int shs) {
+    s16x2 prim[2] = {splat2(0), splat2(0)}, sum = splat2(0);
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const s16x2 a = T.ad[6 * k + q];
+            s16x2       t = q < 2 ? thr_p - (s16x2)((u16x2)a >> __builtin_bit_cast(u16x2, shp))
+                                  : splat2(thr_s) - (s16x2)((u16x2)a >> (u16x2)((unsigned short)shs));
+            t             = __builtin_elementwise_min(a, __builtin_elementwise_max(t, splat2(0)));
+            if (q < 2)
+                prim[k] += T.w[6 * k + q] * t;
+            else
+                sum += T.w[6 * k + q] * t;
+        }
+    sum += pt0 * prim[0] + pt1 * prim[1];
+    const s16x2 neg = (s16x2)((u16x2)sum >> (u16x2)((unsigned short)15));  // sum < 0
+    s16x2       y   = T.x + ((splat2(8) + sum - neg) >> (s16x2)((short)4));
+    y               = __builtin_elementwise_max(y, T.mn);
+    return __builtin_elementwise_min(y, T.mx);
+}
+
 // svt_aom_cdef_find_dir_c (cdef.c:150-210) for one 8x8 block, one thread.
 __device__ int find_dir_block(const uint16_t *img, int stride, int32_t *var, int coeff_shift) {
     const int32_t div_table[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
@@ -198,9 +249,12 @@ struct FbLds {
     SvtHipCdefList dl[64];
     uint8_t        dir[64];
     int32_t        var[64];
-    unsigned long long total;
     int            n;
-    uint32_t       bsum[64][5];  // search: per-block sums of the luma distortion
+};
+struct SearchLds {  // search only: kept apart so that the apply kernel's LDS footprint stays small
+    __attribute__((aligned(4))) uint16_t src[64 * 64];  // source samples of the filter block
+    uint32_t           bsum[4][64][5];                  // per-(strength of the group, block) sums of the luma distortion
+    unsigned long long total[4];                        // one per strength of the current group
 };
 
 // stage tile + dlist; returns cdef_count (uniform).  Contains barriers.
@@ -230,10 +284,11 @@ __device__ int stage_fb(FbLds &S, const SvtHipCdefPlane &pl, const uint8_t *filt
     return S.n;
 }
 
-__global__ __launch_bounds__(256, 5) void cdef_search_kernel(SvtHipCdefPlane pl, const uint8_t *__restrict__ filt,
+__global__ __launch_bounds__(256, 4) void cdef_search_kernel(SvtHipCdefPlane pl, const uint8_t *__restrict__ filt,
                                                           SvtHipCdefSearchParams prm, uint64_t *__restrict__ mse,
                                                           uint8_t *__restrict__ gdir, int32_t *__restrict__ gvar, int nhfb) {
     __shared__ FbLds S;
+    __shared__ SearchLds Q;
     const int fb = blockIdx.x, fbx = fb % nhfb, fby = fb / nhfb;
     const int n  = stage_fb(S, pl, filt, fbx, fby);
     if (n == 0)
@@ -260,99 +315,152 @@ __global__ __launch_bounds__(256, 5) void cdef_search_kernel(SvtHipCdefPlane pl,
     const size_t soff  = (size_t)(fby * (64 >> pl.ydec)) * pl.source_stride + fbx * (64 >> pl.xdec);
     const int    rows  = bh / sub;  // filtered rows per block (power of two)
     const int    nitem = n * rows;  // work item = one filtered row of one block; the rows of a block sit in adjacent lanes
-    constexpr int KMAX = 2;         // 64 blocks x 8 rows / 256 threads
-    // this thread's items and their source samples stay in registers across all strengths
-    int      it_by[KMAX], it_bx[KMAX], it_i[KMAX], it_bi[KMAX];
-    bool     it_on[KMAX];
-    uint32_t srcpx[KMAX][4];  // pairs of source samples
-#pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        const int item = threadIdx.x + k * 256;
-        it_on[k]       = item < nitem;
-        const int bi = it_on[k] ? item / rows : 0, r = item - (item / rows) * rows;
-        it_bi[k] = bi, it_by[k] = S.dl[bi].by, it_bx[k] = S.dl[bi].bx, it_i[k] = r * sub;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            const size_t at = soff + (size_t)((it_by[k] << bhl) + it_i[k]) * pl.source_stride + (it_bx[k] << bwl) + j;
-            srcpx[k][j >> 1] = (it_on[k] && j < bw) ? (load_px(pl.source, at, pl.is_16bit) | (load_px(pl.source, at + 1, pl.is_16bit) << 16)) : 0u;
-        }
+    const int    rl    = msb((unsigned)rows);
+    // the source samples of the listed blocks, staged once for all strengths
+    for (int idx = threadIdx.x; idx < (n << (bhl + bwl)); idx += 256) {
+        const int bi = idx >> (bhl + bwl), r = (idx >> bwl) & (bh - 1), c = idx & (bw - 1);
+        const int y = (S.dl[bi].by << bhl) + r, x = (S.dl[bi].bx << bwl) + c;
+        Q.src[y * 64 + x] = (uint16_t)load_px(pl.source, soff + (size_t)y * pl.source_stride + x, pl.is_16bit);
     }
+    __syncthreads();
     const uint16_t *in1 = S.tile1 + VB * TS + HB;
     const u16x2     ones = {1, 1};
     const bool luma8 = bsize == 3 && pl.pli == 0;
-    for (int gi = 0; gi < prm.n_strengths; gi++) {
-        if (prm.strengths[gi] < 0)
-            continue;
-        int pri = prm.strengths[gi] / 4, sec = prm.strengths[gi] % 4;
-        sec += sec == 3;
-        const int pri_s = pri << prm.coeff_shift, sec_s = sec << prm.coeff_shift;
-        const int pd = prm.pri_damping + prm.coeff_shift - (pl.pli != 0), sd = prm.sec_damping + prm.coeff_shift - (pl.pli != 0);
-        if (threadIdx.x == 0)
-            S.total = 0;
-        __syncthreads();
-        unsigned long long acc = 0;
+    const int  pd = prm.pri_damping + prm.coeff_shift - (pl.pli != 0), sd = prm.sec_damping + prm.coeff_shift - (pl.pli != 0);
+    // Strengths are evaluated in groups of up to NG that share their taps: a zero primary strength filters along direction
+    // 0 (cdef.c:380-388), every other one along the block's direction, so there are two classes.
+    constexpr int NG = 4;
+    for (int cls = 0; cls < 2; cls++) {
+        int gi = 0;
+        while (gi < prm.n_strengths) {
+            int ids[NG], ng = 0;
 #pragma unroll
-        for (int k = 0; k < KMAX; k++) {
-            if (k * 256 >= nitem)  // uniform
+            for (int g = 0; g < NG; g++) {
+                while (gi < prm.n_strengths && (prm.strengths[gi] < 0 || (prm.strengths[gi] / 4 == 0) != (cls == 0))) gi++;
+                ids[g] = gi < prm.n_strengths ? gi++ : -1;
+                ng += ids[g] >= 0;
+            }
+            if (ng == 0)
                 break;
-            uint32_t s_y = 0, s_o = 0, s_yy = 0, s_oo = 0, s_yo = 0;  // luma: the five sums; otherwise s_yy = sum of e^2
-            if (it_on[k]) {
-                const int       by = it_by[k], bx = it_bx[k];
-                const int       at = ((by << bhl) + it_i[k]) * TS + (bx << bwl);
-                const int       t  = pl.pli ? pri_s : adjust_strength(pri_s, S.var[by * 8 + bx]);
-                const int       dd = pri_s ? S.dir[by * 8 + bx] : 0;
+            int pri_s[NG], sec_s[NG], shs[NG];
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) {  // two samples per step
-                    if (j >= bw)
-                        break;
-                    uint32_t yb;
-                    if (pri_s == 0 && sec_s == 0)
-                        yb = *(const uint32_t *)(in + at + j);
-                    else
-                        yb = __builtin_bit_cast(uint32_t, cdef_pair(in + at + j, in1 + at + j, t, sec_s, dd, pd, sd, prm.coeff_shift));
-                    if (!pl.is_16bit)
-                        yb &= 0x00ff00ffu;  // (uint8_t)(int16_t)y
-                    const u16x2 y = __builtin_bit_cast(u16x2, yb), o = __builtin_bit_cast(u16x2, srcpx[k][j >> 1]);
-                    if (luma8) {
-                        s_y = __builtin_amdgcn_udot2(y, ones, s_y, false), s_o = __builtin_amdgcn_udot2(o, ones, s_o, false);
-                        s_yy = __builtin_amdgcn_udot2(y, y, s_yy, false), s_oo = __builtin_amdgcn_udot2(o, o, s_oo, false);
-                        s_yo = __builtin_amdgcn_udot2(y, o, s_yo, false);
-                    } else {
-                        const s16x2 e = __builtin_bit_cast(s16x2, o) - __builtin_bit_cast(s16x2, y);
-                        s_yy          = (uint32_t)__builtin_amdgcn_sdot2(e, e, (int)s_yy, false);
+            for (int g = 0; g < NG; g++) {
+                const int st = ids[g] >= 0 ? prm.strengths[ids[g]] : 0;
+                int       sec = st % 4;
+                sec += sec == 3;
+                pri_s[g] = (st / 4) << prm.coeff_shift, sec_s[g] = sec << prm.coeff_shift;
+                shs[g]   = constrain_shift(sec_s[g], sd);
+            }
+            if (threadIdx.x < NG)
+                Q.total[threadIdx.x] = 0;
+            __syncthreads();
+            unsigned long long acc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; g++) acc[g] = 0;
+#pragma unroll 1
+            for (int k = 0; k * 256 < nitem; k++) {
+                const int  item = threadIdx.x + k * 256;
+                const bool on   = item < nitem;
+                const int  bi = on ? item >> rl : 0, row = ((on ? item : 0) & (rows - 1)) * sub;
+                // luma: s_y, s_yy, s_yo per strength, s_o / s_oo once; otherwise s_yy = sum of e^2
+                uint32_t s_y[NG], s_yy[NG], s_yo[NG], s_o = 0, s_oo = 0;
+#pragma unroll
+                for (int g = 0; g < NG; g++) s_y[g] = 0, s_yy[g] = 0, s_yo[g] = 0;
+                if (on) {
+                    const int by = S.dl[bi].by, bx = S.dl[bi].bx;
+                    const int at = ((by << bhl) + row) * TS + (bx << bwl);
+                    const uint16_t *sp = Q.src + ((by << bhl) + row) * 64 + (bx << bwl);
+                    const int dd = cls ? S.dir[by * 8 + bx] : 0;
+                    s16x2     thr_p[NG], shp[NG], pt0[NG], pt1[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        const int t    = pl.pli ? pri_s[g] : adjust_strength(pri_s[g], S.var[by * 8 + bx]);
+                        const int tsel = (t >> prm.coeff_shift) & 1;
+                        thr_p[g] = splat2(t), shp[g] = splat2(constrain_shift(t, pd));
+                        pt0[g] = splat2(tsel ? 3 : 4), pt1[g] = splat2(tsel ? 3 : 2);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {  // two samples per step
+                        if (j >= bw)
+                            break;
+                        PairTaps T;
+                        pair_taps(T, in + at + j, in1 + at + j, dd);
+                        const u16x2 o = __builtin_bit_cast(u16x2, *(const uint32_t *)(sp + j));
+                        if (luma8)
+                            s_o = __builtin_amdgcn_udot2(o, ones, s_o, false), s_oo = __builtin_amdgcn_udot2(o, o, s_oo, false);
+#pragma unroll
+                        for (int g = 0; g < NG; g++) {
+                            if (g >= ng)  // uniform
+                                break;
+                            uint32_t yb = __builtin_bit_cast(uint32_t, pair_eval(T, thr_p[g], shp[g], pt0[g], pt1[g], sec_s[g], shs[g]));
+                            if (!pl.is_16bit)
+                                yb &= 0x00ff00ffu;  // (uint8_t)(int16_t)y
+                            const u16x2 y = __builtin_bit_cast(u16x2, yb);
+                            if (luma8) {
+                                s_y[g]  = __builtin_amdgcn_udot2(y, ones, s_y[g], false);
+                                s_yy[g] = __builtin_amdgcn_udot2(y, y, s_yy[g], false);
+                                s_yo[g] = __builtin_amdgcn_udot2(y, o, s_yo[g], false);
+                            } else {
+                                const s16x2 e = __builtin_bit_cast(s16x2, o) - __builtin_bit_cast(s16x2, y);
+                                s_yy[g]       = (uint32_t)__builtin_amdgcn_sdot2(e, e, (int)s_yy[g], false);
+                            }
+                        }
+                    }
+                }
+                // sum over the rows of the block: `rows` adjacent lanes (groups are aligned: 256 % rows == 0)
+                for (int off = rows >> 1; off > 0; off >>= 1) {
+                    if (luma8)
+                        s_o += __shfl_down(s_o, off, 64), s_oo += __shfl_down(s_oo, off, 64);
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        if (g >= ng)
+                            break;
+                        s_yy[g] += __shfl_down(s_yy[g], off, 64);
+                        if (luma8)
+                            s_y[g] += __shfl_down(s_y[g], off, 64), s_yo[g] += __shfl_down(s_yo[g], off, 64);
+                    }
+                }
+                if (on && row == 0) {
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        if (g >= ng)
+                            break;
+                        if (luma8) {  // the five sums of this block; the double-precision distortion is evaluated block-parallel below
+                            uint32_t *bs = Q.bsum[g][bi];
+                            bs[0] = s_y[g], bs[1] = s_o, bs[2] = s_yy[g], bs[3] = s_oo, bs[4] = s_yo[g];
+                        } else {
+                            acc[g] += (unsigned long long)s_yy[g];
+                        }
                     }
                 }
             }
-            // sum over the rows of the block: `rows` adjacent lanes (groups are aligned: 256 % rows == 0)
-            for (int off = rows >> 1; off > 0; off >>= 1) {
-                s_yy += __shfl_down(s_yy, off, 64);
-                if (luma8) {
-                    s_y += __shfl_down(s_y, off, 64), s_o += __shfl_down(s_o, off, 64);
-                    s_oo += __shfl_down(s_oo, off, 64), s_yo += __shfl_down(s_yo, off, 64);
+            if (luma8) {  // one lane per (strength, 8x8 block) instead of one in eight lanes of every wave
+                __syncthreads();
+                for (int e = threadIdx.x; e < ng * n; e += 256) {
+                    const int       g = e / n, bi = e - g * n;
+                    const uint32_t *bs = Q.bsum[g][bi];
+                    atomicAdd(&Q.total[g], (unsigned long long)dist_8xn(bs[0], bs[1], bs[2], bs[3], bs[4], prm.coeff_shift));
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g >= ng)
+                        break;
+                    unsigned long long a = acc[g];
+                    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+                    if ((threadIdx.x & 63) == 0)
+                        atomicAdd(&Q.total[g], a);
                 }
             }
-            if (it_on[k] && it_i[k] == 0) {
-                if (luma8) {  // the five sums of this block; the double-precision distortion is evaluated block-parallel below
-                    uint32_t *bs = S.bsum[it_bi[k]];
-                    bs[0] = s_y, bs[1] = s_o, bs[2] = s_yy, bs[3] = s_oo, bs[4] = s_yo;
-                } else {
-                    acc += (unsigned long long)s_yy;
-                }
-            }
-        }
-        if (luma8) {  // one lane per 8x8 block instead of one in eight lanes of every wave
             __syncthreads();
-            if ((int)threadIdx.x < n) {
-                const uint32_t *bs = S.bsum[threadIdx.x];
-                acc                = dist_8xn(bs[0], bs[1], bs[2], bs[3], bs[4], prm.coeff_shift);
+            if ((int)threadIdx.x < ng) {
+                int id = ids[0];
+#pragma unroll
+                for (int g = 1; g < NG; g++) id = (int)threadIdx.x == g ? ids[g] : id;
+                mse[(size_t)fb * prm.n_strengths + id] = ((uint64_t)Q.total[threadIdx.x] >> 2 * prm.coeff_shift) * (uint64_t)sub;
             }
+            __syncthreads();  // totals read before the next group clears them
         }
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if ((threadIdx.x & 63) == 0)
-            atomicAdd(&S.total, acc);
-        __syncthreads();
-        if (threadIdx.x == 0)
-            mse[(size_t)fb * prm.n_strengths + gi] = ((uint64_t)S.total >> 2 * prm.coeff_shift) * (uint64_t)sub;
     }
 }
 
