@@ -12,6 +12,7 @@
 // clamps every addition to the pass's stage range (inv_transforms.c:42-84).
 #pragma once
 
+#include <type_traits>
 #include <stdint.h>
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -333,6 +334,15 @@ TXD_FN void iadst4(typename A::T (&v)[4], int bit) {
     v[3] = A::rs(A::sub(A::add(s0, s1), s3), bit);
 }
 
+// compile-time loop: the body receives the index as an integral constant, so a table entry read inside it is a constant
+// expression (a run-time-indexed read of a static constexpr member array is emitted as a load from a device global)
+template <int I, int N, class F>
+TXD_FN void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 template <int N> struct AdstPerm;
 template <> struct AdstPerm<8> {
     static constexpr int in[8]  = {0, -7, -3, 4, -1, 6, 2, -5};  // a[j] = sign * x[index]   (transforms.c:1515-1522)
@@ -393,11 +403,13 @@ TXD_FN void fadst(typename A::T (&v)[N], const Rot &r) {
         fadst4<A>(v, r.bit);
     } else {
         typename A::T a[N];
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            constexpr auto &P = AdstPerm<N>::in;
-            a[j] = P[j] < 0 ? A::neg(v[-P[j]]) : v[P[j]];
-        }
+        static_for<0, N>([&](auto J) {
+            constexpr int pj = AdstPerm<N>::in[J];
+            if constexpr (pj < 0)
+                a[J] = A::neg(v[-pj]);
+            else
+                a[J] = v[pj];
+        });
         adst_rot<A, N, 1>(a, r);
         adst_bf<A, N, 2, false>(a, r);
         adst_rot<A, N, 2>(a, r);
@@ -407,8 +419,10 @@ TXD_FN void fadst(typename A::T (&v)[N], const Rot &r) {
             adst_bf<A, N, 8, false>(a, r);
         }
         adst_final<A, N>(a, r);
-#pragma unroll
-        for (int k = 0; k < N; k++) v[k] = a[AdstPerm<N>::out[k]];
+        static_for<0, N>([&](auto K) {
+            constexpr int pk = AdstPerm<N>::out[K];
+            v[K] = a[pk];
+        });
     }
 }
 template <class A, int N>
@@ -417,8 +431,10 @@ TXD_FN void iadst(typename A::T (&v)[N], const Rot &r) {
         iadst4<A>(v, r.bit);
     } else {
         typename A::T a[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) a[AdstPerm<N>::out[k]] = v[k];
+        static_for<0, N>([&](auto K) {
+            constexpr int pk = AdstPerm<N>::out[K];
+            a[pk] = v[K];
+        });
         adst_final<A, N>(a, r);
         if constexpr (N == 16) {
             adst_bf<A, N, 8, true>(a, r);
@@ -428,14 +444,13 @@ TXD_FN void iadst(typename A::T (&v)[N], const Rot &r) {
         adst_rot<A, N, 2>(a, r);
         adst_bf<A, N, 2, true>(a, r);
         adst_rot<A, N, 1>(a, r);
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            constexpr auto &P = AdstPerm<N>::in;
-            if (P[j] < 0)
-                v[-P[j]] = A::neg(a[j]);
+        static_for<0, N>([&](auto J) {
+            constexpr int pj = AdstPerm<N>::in[J];
+            if constexpr (pj < 0)
+                v[-pj] = A::neg(a[J]);
             else
-                v[P[j]] = a[j];
-        }
+                v[pj] = a[J];
+        });
     }
 }
 
