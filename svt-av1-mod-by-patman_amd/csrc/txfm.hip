@@ -346,6 +346,14 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) 
     }
     // ---------------------------------------------------------------------- coefficients out / quantise
     uint32_t eob = 0;
+    // this lane's scan positions are requested before the coefficient stores below (same arena: see the prediction loads)
+    uint32_t iscv[(IW + 1) / 2];
+    {
+        const bool      qon = live && t < IH && d.quant_mode != SVT_HIP_QUANT_NONE;
+        const uint16_t *isp = (const uint16_t *)(base + (qon ? d.iscan_off : 0)) + (qon ? t * IW : 0);
+#pragma unroll
+        for (int c = 0; c < IW; c += 2) iscv[c / 2] = qon ? ((uint32_t)isp[c] | ((uint32_t)isp[c + 1] << 16)) : 0u;
+    }
     if (live && do_fwd && d.coeff_off != SVT_HIP_NO_OFFSET && (d.flags & SVT_HIP_TX_FULLCOEFF) && t < H) {
         int32_t *co = (int32_t *)(base + d.coeff_off) + t * W;
 #pragma unroll
@@ -360,7 +368,6 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) 
         if (d.quant_mode != SVT_HIP_QUANT_NONE) {
             QP q;
             load_qp(q, d, base);
-            const int16_t *iscan = (const int16_t *)(base + d.iscan_off);
             if (!do_fwd) {  // quantise coefficients that already live in memory
                 const int32_t *ci = (const int32_t *)(base + d.coeff_off) + t * IW;
 #pragma unroll
@@ -381,7 +388,7 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) 
                     quant_small<false>(q, row[c], ac, qc, dqc);
                 else
                     quant_one(q, row[c], rc, qc, dqc);
-                const uint32_t pos = qc ? (uint32_t)(uint16_t)iscan[rc] + 1u : 0u;
+                const uint32_t pos = qc ? ((iscv[c / 2] >> (16 * (c & 1))) & 0xffffu) + 1u : 0u;
                 eob                = pos > eob ? pos : eob;
                 lds[t * PW + c] = qc;  // staged for the coalesced store below
                 row[c]          = dqc;
@@ -466,18 +473,30 @@ __global__ __launch_bounds__((Geo<W, H>::NT * Geo<W, H>::L), (Geo<W, H>::MINW)) 
         }
         // FLIPADST columns: output row r of the network is picture row H-1-r — flip the addresses, not the register index
         // (a run-time register index costs a 16-way select per element)
-        const ptrdiff_t r0 = ud ? H - 1 : 0, ps = ud ? -(ptrdiff_t)d.pred_stride : (ptrdiff_t)d.pred_stride,
-                        rs = ud ? -(ptrdiff_t)d.recon_stride : (ptrdiff_t)d.recon_stride;
+        const ptrdiff_t r0 = ud ? H - 1 : 0, rs = ud ? -(ptrdiff_t)d.recon_stride : (ptrdiff_t)d.recon_stride;
+        // all prediction samples are requested before the first reconstruction sample is stored: a load behind a store to
+        // the same arena could not be moved ahead of it by the compiler, and waiting for it also waits for that store
+        uint32_t predv[(H + 1) / 2];
+        {
+            const ptrdiff_t ps = ud ? -(ptrdiff_t)d.pred_stride : (ptrdiff_t)d.pred_stride;
+            if (d.flags & SVT_HIP_TX_PIXEL16) {
+                const uint16_t *pr = (const uint16_t *)(base + d.pred_off) + r0 * (ptrdiff_t)d.pred_stride + t;
+#pragma unroll
+                for (int r = 0; r < H; r += 2) predv[r / 2] = (uint32_t)pr[(ptrdiff_t)r * ps] | ((uint32_t)pr[(ptrdiff_t)(r + 1) * ps] << 16);
+            } else {
+                const uint8_t *pr = base + d.pred_off + r0 * (ptrdiff_t)d.pred_stride + t;
+#pragma unroll
+                for (int r = 0; r < H; r += 2) predv[r / 2] = (uint32_t)pr[(ptrdiff_t)r * ps] | ((uint32_t)pr[(ptrdiff_t)(r + 1) * ps] << 16);
+            }
+        }
         if (d.flags & SVT_HIP_TX_PIXEL16) {
-            const uint16_t *pr = (const uint16_t *)(base + d.pred_off) + r0 * (ptrdiff_t)d.pred_stride + t;
-            uint16_t       *rc = (uint16_t *)(base + d.recon_off) + r0 * (ptrdiff_t)d.recon_stride + t;
+            uint16_t *rc = (uint16_t *)(base + d.recon_off) + r0 * (ptrdiff_t)d.recon_stride + t;
 #pragma unroll
-            for (int r = 0; r < H; r++, pr += ps, rc += rs) *rc = clip_pixel_add(*pr, v[r], bd);
+            for (int r = 0; r < H; r++, rc += rs) *rc = clip_pixel_add((uint16_t)(predv[r / 2] >> (16 * (r & 1))), v[r], bd);
         } else {
-            const uint8_t *pr = base + d.pred_off + r0 * (ptrdiff_t)d.pred_stride + t;
-            uint8_t       *rc = base + d.recon_off + r0 * (ptrdiff_t)d.recon_stride + t;
+            uint8_t *rc = base + d.recon_off + r0 * (ptrdiff_t)d.recon_stride + t;
 #pragma unroll
-            for (int r = 0; r < H; r++, pr += ps, rc += rs) *rc = (uint8_t)clip_pixel_add(*pr, v[r], 8);
+            for (int r = 0; r < H; r++, rc += rs) *rc = (uint8_t)clip_pixel_add((uint16_t)(predv[r / 2] >> (16 * (r & 1))), v[r], 8);
         }
     }
 }
