@@ -474,8 +474,11 @@ __global__ __launch_bounds__(256) void cdef_apply_kernel(SvtHipCdefPlane pl, con
     int       pri = fb_strength[fb] / 4, sec = fb_strength[fb] % 4;
     sec += sec == 3;
     const bool active = (pri || sec) && n > 0;
-    if (threadIdx.x < 64)
-        on[threadIdx.x] = 0;
+    if (threadIdx.x < 64) {  // direction / variance of the 64 blocks once, not per sample pair behind the previous pair's stores
+        on[threadIdx.x]    = 0;
+        S.dir[threadIdx.x] = gdir[(size_t)fb * 64 + threadIdx.x];
+        S.var[threadIdx.x] = gvar[(size_t)fb * 64 + threadIdx.x];
+    }
     __syncthreads();
     if (active && (int)threadIdx.x < n)
         on[S.dl[threadIdx.x].by * 8 + S.dl[threadIdx.x].bx] = 1;
@@ -493,21 +496,28 @@ __global__ __launch_bounds__(256) void cdef_apply_kernel(SvtHipCdefPlane pl, con
         const int by = y >> bhl, bx = x >> bwl;
         uint32_t  v  = *(const uint32_t *)(in + y * TS + x);
         if (on[by * 8 + bx]) {
-            const int t = pl.pli ? pri_s : adjust_strength(pri_s, gvar[(size_t)fb * 64 + by * 8 + bx]);
-            v = __builtin_bit_cast(uint32_t, cdef_pair(in + y * TS + x, in1 + y * TS + x, t, sec_s, pri_s ? gdir[(size_t)fb * 64 + by * 8 + bx] : 0,
-                                                       dmp, dmp, coeff_shift));
+            const int t = pl.pli ? pri_s : adjust_strength(pri_s, S.var[by * 8 + bx]);
+            v = __builtin_bit_cast(uint32_t, cdef_pair(in + y * TS + x, in1 + y * TS + x, t, sec_s, pri_s ? S.dir[by * 8 + bx] : 0, dmp, dmp, coeff_shift));
         }
         const bool two = px + 1 < (int)pl.width;
-        if (pl.is_16bit) {
+        if (pl.is_16bit) {  // one store per pair wherever the pair is naturally aligned
             uint16_t *o = (uint16_t *)pl.source + (size_t)py * pl.source_stride + px;
-            o[0]        = (uint16_t)v;
-            if (two)
-                o[1] = (uint16_t)(v >> 16);
+            if (two && ((uintptr_t)o & 3) == 0) {
+                *(uint32_t *)o = v;
+            } else {
+                o[0] = (uint16_t)v;
+                if (two)
+                    o[1] = (uint16_t)(v >> 16);
+            }
         } else {
             uint8_t *o = (uint8_t *)pl.source + (size_t)py * pl.source_stride + px;
-            o[0]       = (uint8_t)v;
-            if (two)
-                o[1] = (uint8_t)(v >> 16);
+            if (two && ((uintptr_t)o & 1) == 0) {
+                *(uint16_t *)o = (uint16_t)((v & 0xffu) | ((v >> 8) & 0xff00u));
+            } else {
+                o[0] = (uint8_t)v;
+                if (two)
+                    o[1] = (uint8_t)(v >> 16);
+            }
         }
     }
 }
