@@ -68,8 +68,11 @@ template <int R> __device__ __forceinline__ void ab_at(const uint16_t *tile, int
 }
 
 // MODE 0: write flt0 / flt1.  MODE 1: fused svt_apply_selfguided_restoration (projection with xq, clip, store samples).
+// SGR_NT threads share one 64x64 unit's 45 KB of LDS: three workgroups fit a CU, so the thread count sets the number of
+// waves that can cover each other's barrier phases
+constexpr int SGR_NT = 512;
 template <int MODE>
-__global__ __launch_bounds__(256) void sgr_filter_kernel(SgrGeom g, int ep, int32_t *__restrict__ flt0, int32_t *__restrict__ flt1,
+__global__ __launch_bounds__(SGR_NT) void sgr_filter_kernel(SgrGeom g, int ep, int32_t *__restrict__ flt0, int32_t *__restrict__ flt1,
                                                          uint32_t flt_stride, void *__restrict__ dst, uint32_t dst_stride, int xq0, int xq1) {
     __shared__ uint16_t tile[70 * TP];
     __shared__ int32_t  Am[66 * AP], Bm[66 * AP];
@@ -78,23 +81,23 @@ __global__ __launch_bounds__(256) void sgr_filter_kernel(SgrGeom g, int ep, int3
     const int w = min((int)g.pu_w, (int)g.width - j0), h = min((int)g.pu_h, (int)g.height - i0);
     const int r0 = SGR_PRM[ep][0], r1 = SGR_PRM[ep][1];
     const int bd = g.bit_depth;
-    for (int idx = tid; idx < (h + 6) * (w + 6); idx += 256) {
+    for (int idx = tid; idx < (h + 6) * (w + 6); idx += SGR_NT) {
         const int r = idx / (w + 6), c = idx - r * (w + 6);
         tile[r * TP + c] = (uint16_t)ldpx(g.dat, (size_t)((ptrdiff_t)(i0 + r - 3) * g.dat_stride + (j0 + c - 3)), g.is16);
     }
     __syncthreads();
-    constexpr int PER = 16;  // samples per thread of a 64x64 unit
+    constexpr int PER = 64 * 64 / SGR_NT;  // samples per thread of a 64x64 unit
     int32_t       f0[PER];
     if (r0 > 0) {  // selfguided_restoration_fast_internal: maps on rows -1, 1, 3, ...
         const int nrows = (h + 2 + 1) / 2, W2 = w + 2;
-        for (int idx = tid; idx < nrows * W2; idx += 256) {
+        for (int idx = tid; idx < nrows * W2; idx += SGR_NT) {
             const int ii = idx / W2, j = idx - ii * W2 - 1, i = 2 * ii - 1;
             ab_at<2>(tile, i, j, (uint32_t)SGR_PRM[ep][2], bd, Am[(i + 1) * AP + j + 1], Bm[(i + 1) * AP + j + 1]);
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            const int idx = tid + k * 256;
+            const int idx = tid + k * SGR_NT;
             f0[k]         = 0;
             if (idx < w * h) {
                 const int  i = idx / w, j = idx - i * w;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void sgr_filter_kernel(SgrGeom g, int ep, int3
     }
     if (r1 > 0) {  // selfguided_restoration_internal (r = 1): maps on every row
         const int W2 = w + 2;
-        for (int idx = tid; idx < (h + 2) * W2; idx += 256) {
+        for (int idx = tid; idx < (h + 2) * W2; idx += SGR_NT) {
             const int ii = idx / W2, j = idx - ii * W2 - 1, i = ii - 1;
             ab_at<1>(tile, i, j, (uint32_t)SGR_PRM[ep][3], bd, Am[(i + 1) * AP + j + 1], Bm[(i + 1) * AP + j + 1]);
         }
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void sgr_filter_kernel(SgrGeom g, int ep, int3
     }
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int idx = tid + k * 256;
+        const int idx = tid + k * SGR_NT;
         if (idx >= w * h)
             continue;
         const int i = idx / w, j = idx - i * w;
@@ -396,7 +399,7 @@ extern "C" int32_t svt_hip_sgr_filter_unit(const SvtHipSgrUnit *unit, int32_t ep
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
     const dim3 grid((unit->width + unit->pu_w - 1) / unit->pu_w, (unit->height + unit->pu_h - 1) / unit->pu_h);
-    hipLaunchKernelGGL(sgr_filter_kernel<0>, grid, dim3(256), 0, resolve_stream(stream), geom_of(unit), ep, d_flt0, d_flt1, flt_stride,
+    hipLaunchKernelGGL(sgr_filter_kernel<0>, grid, dim3(SGR_NT), 0, resolve_stream(stream), geom_of(unit), ep, d_flt0, d_flt1, flt_stride,
                        (void *)nullptr, 0u, 0, 0);
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
@@ -418,7 +421,7 @@ extern "C" int32_t svt_hip_sgr_apply_unit(const SvtHipSgrUnit *unit, int32_t ep,
     else
         xq[0] = xqd[0], xq[1] = (1 << PRJ_BITS) - xq[0] - xqd[1];
     const dim3 grid((unit->width + unit->pu_w - 1) / unit->pu_w, (unit->height + unit->pu_h - 1) / unit->pu_h);
-    hipLaunchKernelGGL(sgr_filter_kernel<1>, grid, dim3(256), 0, resolve_stream(stream), geom_of(unit), ep, (int32_t *)nullptr,
+    hipLaunchKernelGGL(sgr_filter_kernel<1>, grid, dim3(SGR_NT), 0, resolve_stream(stream), geom_of(unit), ep, (int32_t *)nullptr,
                        (int32_t *)nullptr, 0u, d_dst, dst_stride, xq[0], xq[1]);
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
@@ -447,7 +450,7 @@ extern "C" int32_t svt_hip_sgr_search_unit(const SvtHipSgrUnit *unit, int32_t st
     EpResult      *res   = (EpResult *)((uint8_t *)d_work + up256((size_t)n_ep * 2 * plane * sizeof(int32_t)));
     const dim3     grid((unit->width + unit->pu_w - 1) / unit->pu_w, (unit->height + unit->pu_h - 1) / unit->pu_h);
     for (int k = 0; k < n_ep; k++)
-        hipLaunchKernelGGL(sgr_filter_kernel<0>, grid, dim3(256), 0, st, geom_of(unit), start_ep + k * ep_inc, work + (size_t)k * 2 * plane,
+        hipLaunchKernelGGL(sgr_filter_kernel<0>, grid, dim3(SGR_NT), 0, st, geom_of(unit), start_ep + k * ep_inc, work + (size_t)k * 2 * plane,
                            work + (size_t)k * 2 * plane + plane, fs, (void *)nullptr, 0u, 0, 0);
     hipLaunchKernelGGL(sgr_search_ep_kernel, dim3(n_ep), dim3(1024), 0, st, *unit, (const int32_t *)work, fs, start_ep, ep_inc, do_refine,
                        res);
@@ -493,7 +496,7 @@ extern "C" void svt_av1_selfguided_restoration_hip(const uint8_t *dgd8, int32_t 
     SvtHipSgrUnit u{dp, nullptr, (uint32_t)pitch, 0, (uint32_t)width, (uint32_t)height, (uint8_t)(highbd != 0), (uint8_t)bit_depth, 64, 64};
     int32_t      *df0 = (int32_t *)(d + in_bytes), *df1 = (int32_t *)(d + in_bytes + fl_bytes);
     const dim3    grid((width + 63) / 64, (height + 63) / 64);
-    hipLaunchKernelGGL(sgr_filter_kernel<0>, grid, dim3(256), 0, st, geom_of(&u), ep, df0, df1, (uint32_t)width, (void *)nullptr, 0u, 0, 0);
+    hipLaunchKernelGGL(sgr_filter_kernel<0>, grid, dim3(SGR_NT), 0, st, geom_of(&u), ep, df0, df1, (uint32_t)width, (void *)nullptr, 0u, 0, 0);
     SVT_HIP_CHECK_FATAL(hipGetLastError());
     SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + in_bytes, d + in_bytes, 2 * fl_bytes, hipMemcpyDeviceToHost, st));
     SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
