@@ -89,6 +89,13 @@ SVT_HIP_API int32_t svt_hip_cdef_apply_plane(const SvtHipCdefPlane *plane, const
                                              const uint8_t *d_fb_strength, int32_t damping, int32_t coeff_shift,
                                              const uint8_t *d_dir, const int32_t *d_var, void *stream);
 
+/* The same for up to three planes of one picture in ONE launch (svt_av1_cdef_frame, enc_cdef.c:284-610, walks the planes
+ * of a filter block together): planes[p] / d_fb_strength[p] per plane (luma strength index for plane 0, chroma for 1, 2);
+ * all planes must cover the same 64x64 (luma) filter-block grid. */
+SVT_HIP_API int32_t svt_hip_cdef_apply_frame(const SvtHipCdefPlane *planes, uint32_t n_planes, const uint8_t *d_filt8x8,
+                                             const uint8_t *const *d_fb_strength, int32_t damping, int32_t coeff_shift,
+                                             const uint8_t *d_dir, const int32_t *d_var, void *stream);
+
 /* =============================================================================================
  * Deblocking
  *   Source/Lib/Codec/common_dsp_rtcd.h:1043-1074  svt_aom_lpf_{horizontal,vertical}_{4,6,8,14} and the highbd set

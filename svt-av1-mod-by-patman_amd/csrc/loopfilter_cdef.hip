@@ -464,12 +464,12 @@ __global__ __launch_bounds__(256, 4) void cdef_search_kernel(SvtHipCdefPlane pl,
     }
 }
 
-__global__ __launch_bounds__(256) void cdef_apply_kernel(SvtHipCdefPlane pl, const uint8_t *__restrict__ filt,
-                                                         const uint8_t *__restrict__ fb_strength, int damping, int coeff_shift,
-                                                         const uint8_t *__restrict__ gdir, const int32_t *__restrict__ gvar, int nhfb) {
+__device__ __forceinline__ void cdef_apply_fb(const SvtHipCdefPlane &pl, const uint8_t *__restrict__ filt,
+                                              const uint8_t *__restrict__ fb_strength, int damping, int coeff_shift,
+                                              const uint8_t *__restrict__ gdir, const int32_t *__restrict__ gvar, int nhfb, int fb) {
     __shared__ FbLds S;
     __shared__ uint8_t on[64];
-    const int fb = blockIdx.x, fbx = fb % nhfb, fby = fb / nhfb;
+    const int fbx = fb % nhfb, fby = fb / nhfb;
     const int n  = stage_fb(S, pl, filt, fbx, fby);
     int       pri = fb_strength[fb] / 4, sec = fb_strength[fb] % 4;
     sec += sec == 3;
@@ -520,6 +520,24 @@ __global__ __launch_bounds__(256) void cdef_apply_kernel(SvtHipCdefPlane pl, con
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void cdef_apply_kernel(SvtHipCdefPlane pl, const uint8_t *__restrict__ filt,
+                                                         const uint8_t *__restrict__ fb_strength, int damping, int coeff_shift,
+                                                         const uint8_t *__restrict__ gdir, const int32_t *__restrict__ gvar, int nhfb) {
+    cdef_apply_fb(pl, filt, fb_strength, damping, coeff_shift, gdir, gvar, nhfb, blockIdx.x);
+}
+// all planes of a picture in one launch (blockIdx.y = plane): a plane's 2040 filter blocks of a 4K picture are 1.3 rounds
+// of the 1536 workgroups the chip holds, three planes are 4.0
+struct ApplyFrame {
+    SvtHipCdefPlane pl[3];
+    const uint8_t  *strength[3];
+};
+__global__ __launch_bounds__(256) void cdef_apply_frame_kernel(ApplyFrame f, const uint8_t *__restrict__ filt, int damping, int coeff_shift,
+                                                               const uint8_t *__restrict__ gdir, const int32_t *__restrict__ gvar, int nhfb) {
+    const int p = blockIdx.y;
+    cdef_apply_fb(p == 0 ? f.pl[0] : (p == 1 ? f.pl[1] : f.pl[2]), filt, p == 0 ? f.strength[0] : (p == 1 ? f.strength[1] : f.strength[2]), damping,
+                  coeff_shift, gdir, gvar, nhfb, blockIdx.x);
 }
 
 // ---- Tier A kernels ----
@@ -671,6 +689,34 @@ extern "C" int32_t svt_hip_cdef_apply_plane(const SvtHipCdefPlane *plane, const 
 }
 
 // ------------------------------------------------------------------------------------------------ Tier A
+extern "C" int32_t svt_hip_cdef_apply_frame(const SvtHipCdefPlane *planes, uint32_t n_planes, const uint8_t *d_filt8x8,
+                                            const uint8_t *const *d_fb_strength, int32_t damping, int32_t coeff_shift, const uint8_t *d_dir,
+                                            const int32_t *d_var, void *stream) {
+    if (!planes || n_planes == 0 || n_planes > 3 || !d_filt8x8 || !d_fb_strength || !d_dir || !d_var) {
+        set_error("svt_hip_cdef_apply_frame: bad argument");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    ApplyFrame f{};
+    for (uint32_t p = 0; p < n_planes; p++) {
+        const int lw = (int)planes[p].width << planes[p].xdec, lh = (int)planes[p].height << planes[p].ydec;
+        const int lw0 = (int)planes[0].width << planes[0].xdec, lh0 = (int)planes[0].height << planes[0].ydec;
+        if (!plane_ok(&planes[p]) || !d_fb_strength[p] || planes[p].recon == planes[p].source || (lw + 63) / 64 != (lw0 + 63) / 64 ||
+            (lh + 63) / 64 != (lh0 + 63) / 64) {
+            set_error("svt_hip_cdef_apply_frame: plane %u: bad plane (input and output must differ; all planes must cover the same filter blocks)", p);
+            return SVT_HIP_ERR_BAD_PARAMETER;
+        }
+        f.pl[p] = planes[p], f.strength[p] = d_fb_strength[p];
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    const int lw = (int)planes[0].width << planes[0].xdec, lh = (int)planes[0].height << planes[0].ydec;
+    const int nhfb = (lw + 63) / 64, nvfb = (lh + 63) / 64;
+    hipLaunchKernelGGL(cdef_apply_frame_kernel, dim3(nhfb * nvfb, n_planes), dim3(256), 0, resolve_stream(stream), f, d_filt8x8, damping,
+                       coeff_shift, d_dir, d_var, nhfb);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
 extern "C" void svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2,
                                                int32_t coeff_shift, uint8_t *out1, uint8_t *out2) {
     if (!ensure_init())

@@ -120,10 +120,12 @@ def run_cdef_search(lib, inp, sp):
 
 
 def run_cdef_apply(lib, inp, sp):
-    for pli in range(3):
-        _chk(lib, lib.svt_hip_cdef_apply_plane(C.byref(inp["cdef_planes_apply"][pli]), C.c_void_p(inp["d_filt"].data_ptr()),
-                                               C.c_void_p(inp["d_fbs"].data_ptr()), 5, inp["bd"] - 8, C.c_void_p(inp["d_dir"].data_ptr()),
-                                               C.c_void_p(inp["d_var"].data_ptr()), sp))
+    """all three planes in one launch (svt_hip_cdef_apply_frame)"""
+    if "cdef_apply_frame" not in inp:
+        inp["cdef_apply_frame"] = ((abi.CdefPlane * 3)(*inp["cdef_planes_apply"]), (C.c_void_p * 3)(*[inp["d_fbs"].data_ptr()] * 3))
+    planes, strengths = inp["cdef_apply_frame"]
+    _chk(lib, lib.svt_hip_cdef_apply_frame(planes, C.c_uint32(3), C.c_void_p(inp["d_filt"].data_ptr()), strengths, 5, inp["bd"] - 8,
+                                           C.c_void_p(inp["d_dir"].data_ptr()), C.c_void_p(inp["d_var"].data_ptr()), sp))
 
 
 def run_sgr_filter(lib, inp, sp):

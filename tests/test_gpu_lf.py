@@ -138,6 +138,7 @@ def test_tier_b_picture(hip, orc, lw, lh, bd, is16, sub, fmt):
     ldir_o, lvar_o = np.zeros((n_fb, 64), np.uint8), np.zeros((n_fb, 64), np.int32)
     ddir, dvar = device.DeviceBuffer(hip, n_fb * 64), device.DeviceBuffer(hip, n_fb * 64 * 4)
     ddir.fill(0), dvar.fill(0)
+    planes = []
     for pli in range(3):
         xdec = int(pli > 0 and fmt != 444)
         ydec = int(pli > 0 and fmt == 420)
@@ -152,6 +153,27 @@ def test_tier_b_picture(hip, orc, lw, lh, bd, is16, sub, fmt):
         if pli == 0:
             assert np.array_equal(ddir.download(np.uint8, (n_fb, 64)), ldir_o)
             assert np.array_equal(dvar.download(np.int32, (n_fb, 64)), lvar_o)
+        planes.append((recon, w, h, xdec, ydec))
+    # the three planes in ONE launch (svt_hip_cdef_apply_frame), luma and chroma with their own strength per filter block
+    fbs_uv = rng.choice(np.array([s for s in strengths if s >= 0], np.uint8), size=n_fb).astype(np.uint8)
+    d_filt, d_fbs, d_fbs_uv = (device.DeviceBuffer(hip, a.nbytes) for a in (filt, fbs, fbs_uv))
+    d_filt.upload(filt), d_fbs.upload(fbs), d_fbs_uv.upload(fbs_uv)
+    arr, bufs, exp = (abi.CdefPlane * 3)(), [], []
+    for pli, (recon, w, h, xdec, ydec) in enumerate(planes):
+        d_in, d_out = device.DeviceBuffer(hip, recon.nbytes), device.DeviceBuffer(hip, recon.nbytes)
+        d_in.upload(recon), d_out.fill(0)
+        arr[pli] = abi.CdefPlane(d_in.ptr, d_out.ptr, recon.shape[1], recon.shape[1], w, h, is16, xdec, ydec, pli)
+        bufs.append((d_in, d_out))
+        out = np.zeros_like(recon)
+        plo = abi.CdefPlane(recon.ctypes.data, out.ctypes.data, recon.shape[1], recon.shape[1], w, h, is16, xdec, ydec, pli)
+        orc.orc_cdef_apply_plane(C.byref(plo), P(filt), P(fbs if pli == 0 else fbs_uv), damping, cs, P(ldir_o), P(lvar_o))
+        exp.append(out)
+    st = (C.c_void_p * 3)(d_fbs.ptr, d_fbs_uv.ptr, d_fbs_uv.ptr)
+    device.check(hip, hip.svt_hip_cdef_apply_frame(arr, C.c_uint32(3), V(d_filt.ptr), st, damping, cs, V(ddir.ptr), V(dvar.ptr), None), "cdef_apply_frame")
+    device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+    for pli, (recon, w, h, xdec, ydec) in enumerate(planes):
+        got = bufs[pli][1].download(recon.dtype, recon.shape)
+        assert np.array_equal(got[:, :w], exp[pli][:, :w]), ("frame", pli)
 
 
 def test_tier_b_golden(hip):
@@ -179,6 +201,7 @@ def test_tier_b_bad_arguments(hip):
     pl = abi.CdefPlane(0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     assert hip.svt_hip_cdef_search_plane(C.byref(pl), None, C.byref(prm), None, None, None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
     assert hip.svt_hip_cdef_apply_plane(C.byref(pl), None, None, 3, 0, None, None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+    assert hip.svt_hip_cdef_apply_frame(C.byref(pl), C.c_uint32(4), None, None, 3, 0, None, None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
 
 
 # ------------------------------------------------------------------------------------------------ deblocking
