@@ -46,7 +46,7 @@ struct Geo {
     static constexpr int PW = W + 1;
     static constexpr int NT = cmax(1, 64 / L);  // one wave per workgroup: its barriers cost nothing and waves never wait for each other
     static constexpr int IW = cmin(W, 32), IH = cmin(H, 32);
-    static constexpr int MINW = L == 32 ? 4 : 1;  // waves per SIMD the register allocation aims for: 4 for the 32-wide kernels (128 VGPRs + 48 B of scratch: 1.68 -> 1.83 TB/s); 6 for the 16-wide ones spills too much (1.74 vs 2.02 TB/s)
+    static constexpr int MINW = L == 32 ? 3 : 1;  // waves per SIMD the register allocation aims for: 3 for the 32-wide kernels (150 VGPRs, no scratch: 2.86 TB/s; at 4 waves / 128 VGPRs they spill 104 B per lane: 2.31 TB/s); the other widths take what they need (16-wide: 94 VGPRs, 5 waves)
     static constexpr int WI = clog2(W) - 2, HI = clog2(H) - 2;
     static constexpr bool RECT = (W == 2 * H) || (H == 2 * W);
 };
