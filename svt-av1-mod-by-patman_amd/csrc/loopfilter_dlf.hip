@@ -162,8 +162,16 @@ __device__ __forceinline__ int edge_decision(const LfGeom &g, const LfLevels &L,
     return 0;
 }
 
+// All planes of a pass in one launch (blockIdx.z = plane): a pass over one 4K plane is a 10 - 15 us kernel, so six separate
+// launches spend a good part of their time ramping up and draining.
+struct LfPassArgs {
+    LfGeom   g[3];
+    LfLevels L[3];
+};
 template <int DIR>
-__global__ __launch_bounds__(256) void dlf_pass_kernel(LfGeom g, LfLevels L) {
+__global__ __launch_bounds__(256) void dlf_pass_kernel(LfPassArgs a) {
+    const LfGeom   &g = a.g[blockIdx.z];
+    const LfLevels &L = a.L[blockIdx.z];
     // 64x4 thread tiles: consecutive lanes walk along x so that the horizontal-edge pass is fully coalesced
     const uint32_t ux = blockIdx.x * 64 + (threadIdx.x & 63), uy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ux >= g.units_x || uy >= g.units_y)
@@ -258,22 +266,27 @@ extern "C" int32_t svt_hip_loop_filter_frame(const SvtHipLfFrame *f, void *strea
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
     hipStream_t st = resolve_stream(stream);
+    LfPassArgs  a{};
+    uint32_t    np = 0, gx = 0, gy = 0;
     for (int p = f->plane_start; p < f->plane_end; p++) {
         if (p == 0 && !f->filter_level[0] && !f->filter_level[1])
             break;  // deblocking_filter.c:570-572
         if ((p == 1 && !f->filter_level_u) || (p == 2 && !f->filter_level_v))
             continue;
         const int ss = p > 0;
-        LfGeom    g{};
+        LfGeom   &g = a.g[np];
         g.plane = f->plane[p], g.stride = f->stride[p], g.width = f->width >> ss, g.height = f->height >> ss;
         g.mi = f->mi, g.mi_stride = f->mi_stride;
         g.units_x = (f->mi_cols >> ss), g.units_y = (f->mi_rows >> ss);
         g.ss = (uint8_t)ss, g.plane_id = (uint8_t)p, g.sharpness = f->sharpness_level, g.bit_depth = f->bit_depth, g.is_16bit = f->is_16bit;
-        LfLevels L;
-        memcpy(L.lvl, f->lvl[p], sizeof(L.lvl));
-        const dim3 grid((g.units_x + 63) / 64, (g.units_y + 3) / 4);
-        hipLaunchKernelGGL(dlf_pass_kernel<0>, grid, dim3(256), 0, st, g, L);
-        hipLaunchKernelGGL(dlf_pass_kernel<1>, grid, dim3(256), 0, st, g, L);
+        memcpy(a.L[np].lvl, f->lvl[p], sizeof(a.L[np].lvl));
+        gx = (g.units_x + 63) / 64 > gx ? (g.units_x + 63) / 64 : gx;
+        gy = (g.units_y + 3) / 4 > gy ? (g.units_y + 3) / 4 : gy;
+        np++;
+    }
+    if (np) {  // vertical edges of every plane, then horizontal edges of every plane (the planes are independent)
+        hipLaunchKernelGGL(dlf_pass_kernel<0>, dim3(gx, gy, np), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(dlf_pass_kernel<1>, dim3(gx, gy, np), dim3(256), 0, st, a);
     }
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
