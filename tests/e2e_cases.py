@@ -1,0 +1,70 @@
+"""Shared helpers of the end-to-end bitstream gate (test infrastructure): the synthetic clip of SURVEY.md 8d, the
+patched reference encoder built by `make -C oracle e2e` (oracle/_ref/e2e/SvtAv1EncApp = the reference's own sources +
+tools/reference_hip.patch) and md5 of what it writes."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+
+from svtav1_hip import frames
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+APP = os.path.join(ROOT, "oracle", "_ref", "e2e", "SvtAv1EncApp")
+HIP_LIB = os.path.join(ROOT, "svt-av1-mod-by-patman_amd", "csrc", "libsvtav1_hip.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "e2e_md5.json")
+
+# name -> (width, height, frames, bit depth, preset): <= 8 frames of 192x128
+CASES = {
+    "p12_8bit": (192, 128, 8, 8, 12),
+    "p8_8bit": (192, 128, 8, 8, 8),
+    "p8_10bit": (192, 128, 6, 10, 8),
+}
+
+
+def have_app():
+    return os.path.exists(APP)
+
+
+def write_clip(path, w, h, n, bd, seed=7):
+    """Planar I420 (8-bit) / I420p10le: luma = the panning low-pass noise of frames.synthetic_clip, chroma a
+    slow gradient so that the chroma transforms / filters see something; 10-bit = 8-bit * 4 + uniform {0..3}."""
+    rng = np.random.default_rng(seed + 100)
+    luma = frames.synthetic_clip(w, h, n, seed=seed)
+    yy, xx = np.mgrid[0:h // 2, 0:w // 2]
+    with open(path, "wb") as f:
+        for i, y in enumerate(luma):
+            u = ((xx * 2 + i * 3) % 256).astype(np.uint8)
+            v = ((yy * 3 + 255 - i * 2) % 256).astype(np.uint8)
+            for pl in (y, u, v):
+                if bd == 8:
+                    f.write(pl.tobytes())
+                else:
+                    f.write((pl.astype(np.uint16) * 4 + rng.integers(0, 4, size=pl.shape, dtype=np.uint16)).astype("<u2").tobytes())
+
+
+def encode(case, workdir, asm, lp=1, env_extra=None, timeout=900):
+    """Runs the encoder; returns ({'ivf': md5, 'recon': md5}, log text)."""
+    w, h, n, bd, preset = CASES[case]
+    clip = os.path.join(workdir, f"{case}.yuv")
+    if not os.path.exists(clip):
+        write_clip(clip, w, h, n, bd)
+    ivf, rec = os.path.join(workdir, f"{case}_{asm}.ivf"), os.path.join(workdir, f"{case}_{asm}_rec.yuv")
+    for p in (ivf, rec):
+        if os.path.exists(p):
+            os.remove(p)
+    cmd = [APP, "-i", clip, "-w", str(w), "-h", str(h), "--fps", "30", "-n", str(n), "--preset", str(preset),
+           "--lp", str(lp), "--asm", asm, "--input-depth", str(bd), "-b", ivf, "-o", rec]
+    env = dict(os.environ, SVTAV1_HIP_LIB=HIP_LIB)
+    env.update(env_extra or {})
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd)} failed ({r.returncode}):\n{r.stdout[-3000:]}")
+    md5 = {k: hashlib.md5(open(p, "rb").read()).hexdigest() for k, p in (("ivf", ivf), ("recon", rec))}
+    return md5, r.stdout
+
+
+def golden():
+    with open(GOLDEN) as f:
+        return json.load(f)

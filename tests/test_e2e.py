@@ -1,0 +1,54 @@
+"""End-to-end bitstream gate (.gitlab/workflows/linux/.gitlab-ci.yml:338-366 is the reference's own form of it):
+the reference encoder, built from its own sources with tools/reference_hip.patch (`make -C oracle e2e`), must write the
+SAME .ivf and reconstruction with `--asm hip` (C table + every Tier A HIP leaf installed by svt_hip_install_rtcd) as with
+`--asm c`.  The expected md5s (tests/golden/e2e_md5.json) were written by the C path in the build container.
+
+Skipped where the encoder binary is absent (it can only be built where /root/reference exists; the built binary travels
+with the repository snapshot to the GPU box)."""
+import os
+import re
+import tempfile
+
+import pytest
+
+import e2e_cases as E
+
+needs_app = pytest.mark.skipif(not E.have_app(), reason="oracle/_ref/e2e/SvtAv1EncApp not built (make -C oracle ref e2e)")
+
+
+@needs_app
+@pytest.mark.parametrize("case", ["p12_8bit", "p8_10bit"])
+def test_c_path_reproduces_golden(case):
+    """CPU: pins the committed md5s to the reference's C path (and the clip generator to its recipe)."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, _ = E.encode(case, d, "c")
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}
+
+
+@needs_app
+def test_asm_hip_without_device_keeps_cpu_kernels():
+    """CPU: `--asm hip` on a machine with no gfx950 device installs nothing, warns, and encodes with the C kernels
+    (never abort).  Only meaningful where no GPU is visible."""
+    from svtav1_hip import abi
+    if abi.load().svt_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode("p12_8bit", d, "hip")
+    assert "HIP hot path unavailable" in log
+    g = E.golden()["p12_8bit"]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}
+
+
+@needs_app
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(E.CASES))
+def test_asm_hip_bitstream_md5(hip, case):
+    """GPU: every RTCD pointer that has a HIP leaf is swapped, the encoder runs, the bitstream is unchanged."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip")
+    m = re.search(r"HIP hot path: (\d+) of (\d+) RTCD pointers", log)
+    assert m, "the HIP leaves were not installed:\n" + log[-2000:]
+    assert int(m.group(1)) == int(m.group(2)) >= 170
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the HIP leaves installed\n{log[-1500:]}"

@@ -1,0 +1,23 @@
+/*
+ * svt_hip_bind.h — what the reference encoder includes to get `--asm hip` (see tools/reference_hip.patch).
+ *
+ * EB_CPU_FLAGS_HIP is a new bit of EbCpuFlags (Source/API/EbSvtAv1.h:421-456: x86 uses bits 0-15, bit 63 is
+ * EB_CPU_FLAGS_INVALID and EB_CPU_FLAGS_ALL = bits 0-61, what `--asm max` sets).  Bit 62 is therefore neither part of
+ * "max" nor "invalid": only `--asm hip` selects it, and every SIMD bit stays clear, so svt_aom_setup_rtcd_internal
+ * (aom_dsp_rtcd.c:187) first installs the C functions and svt_hip_bind_install() then swaps in the HIP leaves.
+ */
+#ifndef SVT_HIP_BIND_H
+#define SVT_HIP_BIND_H
+
+#include <stdint.h>
+
+#define EB_CPU_FLAGS_HIP (1ULL << 62)
+
+/* Loads libsvtav1_hip.so (env SVTAV1_HIP_LIB, else next to the executable, else the loader's search path),
+ * initialises device `SVTAV1_HIP_DEVICE` (default 0) and assigns every Tier A export into the encoder's RTCD
+ * pointers.  Returns the number of pointers installed, or -1 with the CPU pointers untouched (library or device
+ * missing): the caller logs and carries on with its C kernels (SURVEY.md 8b "never abort").
+ * Env SVTAV1_HIP_ONLY / SVTAV1_HIP_SKIP: comma-separated name prefixes to restrict the set (bisecting aid). */
+int svt_hip_bind_install(char *msg, unsigned msg_len);
+
+#endif
