@@ -61,20 +61,74 @@ def gather_on_root(local_results):
     return merged
 
 
-def publish_reference(picture, owner, stream=None, async_op=True):
+def publish_reference(picture, owner, stream=None, async_op=True, producer=None):
     """Broadcast one reconstructed reference picture from its owner rank to every other rank (the reference publishes it at
     rest_process.c:659-660, 732-744 once restoration has finished).
 
     `picture` is ONE contiguous tensor holding the padded Y/U/V planes back to back (the planes the kernels use are views of
     it): a single large collective per picture instead of three small ones — xGMI rings are per-link bound (≈27 MB for a
-    padded 4K 10-bit 4:2:0 picture ≈ 0.2 ms per link).  Only `is_ref` pictures travel.  With `async_op` the work handle is
-    returned so that the broadcast overlaps the owner's next picture; pass the side `stream` it should be enqueued on
-    (NCCL / RCCL use the current stream of the tensor's device).  Returns None on a single rank."""
+    padded 4K 10-bit 4:2:0 picture ≈ 0.2 ms per link).  Only `is_ref` pictures travel.
+
+    Ordering: the in-loop filter kernels that wrote the picture run on a stream the caller handed to the library, not on
+    torch's current stream, so nothing orders the broadcast behind them by itself.  Pass that stream (a torch.cuda.Stream or
+    ExternalStream) as `producer`: the side `stream` waits for it before the broadcast is enqueued.  With `async_op` the work
+    handle is returned; consumers must `work.wait()` (CPU tensors) or make their stream wait for the side stream
+    (`consumer.wait_stream(stream)`) before predicting from the picture.  Returns None on a single rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return None
     assert picture.is_contiguous()
     raw = picture.view(-1).view(torch.uint8)      # bytes: every backend moves them, whatever the sample type
     if stream is not None:
+        if producer is not None:
+            stream.wait_stream(producer)
         with torch.cuda.stream(stream):
             return dist.broadcast(raw, src=owner, async_op=async_op)
     return dist.broadcast(raw, src=owner, async_op=async_op)
+
+
+def layer_of(pic_in_minigop, minigop=32):
+    """Temporal layer of a picture inside a hierarchical mini-GOP (display order 1..minigop; `minigop` = the base-layer
+    picture): 0 for the base picture, then 1 for minigop/2, 2 for the odd multiples of minigop/4, ...  (the reference's 6-layer
+    random-access structure for hierarchical_levels 5, enc_handle.c:4379-4387)."""
+    assert 1 <= pic_in_minigop <= minigop and minigop & (minigop - 1) == 0
+    layer, step = 0, minigop
+    while pic_in_minigop % step:
+        step //= 2
+        layer += 1
+    return layer
+
+
+def layer_aware_owner(pic_in_minigop, world, minigop=32):
+    """the closed-loop stages of a mini-GOP can only run as many pictures at once as the current layer holds
+    (1, 1, 2, 4, 8, 16 for a 32-picture mini-GOP), so the pictures of ONE layer go to DIFFERENT GPUs: picture k-th of its
+    layer (in display order) is owned by rank k mod world.  Open-loop stages ignore this (any GPU can take any picture)."""
+    layer = layer_of(pic_in_minigop, minigop)
+    if layer == 0:
+        return 0
+    step = minigop >> layer               # pictures of this layer: odd multiples of step
+    k = (pic_in_minigop // step) // 2     # 0-based index inside the layer
+    return k % world
+
+
+class ReferencePublisher:
+    """bench.py --gpus N: every rank owns one reconstructed 4K reference picture (padded Y/U/V in one allocation) and the
+    ranks take turns publishing theirs, one broadcast per step on a side stream that overlaps the next step's kernels."""
+
+    def __init__(self, width, height, bit_depth, device, rank, world, pad=160):
+        bps = 1 if bit_depth == 8 else 2
+        luma = (width + 2 * pad) * (height + 2 * pad)
+        chroma = (width // 2 + pad) * (height // 2 + pad)
+        self.nbytes = (luma + 2 * chroma) * bps
+        self.picture = torch.full((self.nbytes,), rank + 1, dtype=torch.uint8, device=device)
+        self.side = torch.cuda.Stream(device=device)
+        self.rank, self.world, self.pending = rank, world, None
+
+    def publish(self, producer, owner):
+        if self.pending is not None:
+            self.pending.wait()               # the previous broadcast: its buffer is about to be reused
+        self.pending = publish_reference(self.picture, owner, stream=self.side, async_op=True, producer=producer)
+
+    def finish(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
