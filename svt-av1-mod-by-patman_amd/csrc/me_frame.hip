@@ -107,22 +107,36 @@ __device__ __forceinline__ const uint8_t *plane_at(const SvtHipPlane8 &pl, int x
 }
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *g) { return load_u32_any(g); }
 
-// Workgroup-wide SAD between the staged 64x64 source (rows 0,2,4.. when `sub`) and a global block.
-// Result in L.st.wg_sum (valid after the trailing barrier).  width must be a multiple of 4.
+// This lane's share of the SAD between the staged 64x64 source (LDS rows of 16 dwords, every `row_step`-th row) and a block
+// in global memory at any byte address: 16 bytes per load, `ndw` = block width in dwords (b64_w / 4, a multiple of 2).
+__device__ __forceinline__ uint32_t block_sad16(const uint32_t *src, const uint8_t *ref, uint32_t ref_stride, uint32_t ndw, uint32_t rows,
+                                                uint32_t row_step, uint32_t lane, uint32_t nlanes) {
+    const uint32_t nch = (ndw + 3) >> 2, inv = make_inv(nch);
+    uint32_t       acc = 0;
+    for (uint32_t idx = lane; idx < nch * rows; idx += nlanes) {
+        const uint32_t r = fast_div(idx, inv), ch = idx - r * nch;
+        const uint4    sv = *(const uint4 *)&src[(r * row_step) * 16 + 4 * ch];
+        const u128v    v  = load_u128_any(ref + (size_t)((r * row_step) * ref_stride) + 16 * ch);
+        const uint32_t nd = ndw - 4 * ch;
+        acc = __builtin_amdgcn_sad_u8(sv.x, v.x, acc);
+        acc = __builtin_amdgcn_sad_u8(sv.y, v.y, acc);      // ndw is even: dword 1 of a chunk is always inside the block
+        if (nd > 2) {
+            acc = __builtin_amdgcn_sad_u8(sv.z, v.z, acc);
+            acc = __builtin_amdgcn_sad_u8(sv.w, v.w, acc);
+        }
+    }
+    return acc;
+}
+
+// Workgroup-wide SAD between the staged 64x64 source (rows 0,2,4.. when row_step == 2) and a global block.
+// Result in L.st.wg_sum (valid after the trailing barrier).  width must be a multiple of 8.
 template <class LDS>
 __device__ void wg_block_sad(LDS &L, const uint8_t *ref, uint32_t ref_stride, uint32_t width, uint32_t rows,
                              uint32_t row_step) {
     if (threadIdx.x == 0)
         L.st.wg_sum = 0;
     __syncthreads();
-    const uint32_t ndw = width >> 2;
-    uint32_t       acc = 0;
-    for (uint32_t idx = threadIdx.x; idx < ndw * rows; idx += blockDim.x) {
-        const uint32_t r = idx / ndw, i = idx - r * ndw;
-        const uint32_t s = L.src_full[(r * row_step) * 16 + i];
-        const uint32_t v = load_u32_unaligned(ref + (size_t)(r * row_step) * ref_stride + 4 * i);
-        acc              = __builtin_amdgcn_sad_u8(s, v, acc);
-    }
+    uint32_t acc = block_sad16(L.src_full, ref, ref_stride, width >> 2, rows, row_step, threadIdx.x, blockDim.x);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0)
         atomicAdd(&L.st.wg_sum, acc);
@@ -226,24 +240,7 @@ __device__ __forceinline__ uint32_t fp_pitch(uint32_t tw) { return (((tw + 3) >>
 
 template <class LDS>
 __device__ void fp_stage(LDS &L, const uint8_t *win_org, uint32_t stride, uint32_t tw, uint32_t th) {
-    // 32 lanes per window row (rows are 17..33 dwords), four rows in flight per lane
-    const uint32_t tid = threadIdx.x, pitch = fp_pitch(tw), rows = th + 63, rpp = blockDim.x >> 5;
-    const uint32_t c0 = tid & 31, r0 = tid >> 5;
-    for (uint32_t col = c0; col < pitch; col += 32)
-        for (uint32_t row = r0; row < rows; row += 4 * rpp) {
-            uint32_t v[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t rr = row + u * rpp;
-                v[u]              = rr < rows ? load_u32_unaligned(win_org + (size_t)rr * stride + 4 * col) : 0u;
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t rr = row + u * rpp;
-                if (rr < rows)
-                    L.win[rr * pitch + col] = v[u];
-            }
-        }
+    stage_rows16(L.win, fp_pitch(tw), win_org, stride, th + 63, blockDim.x, threadIdx.x);
     __syncthreads();
 }
 
@@ -263,6 +260,8 @@ __device__ void fp_search(LDS &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint
     const uint32_t zy = 2 * (zo >> 3) + ((zo >> 1) & 1), zx = 2 * ((zo >> 2) & 1) + (zo & 1);
     const uint32_t *s = &L.src_full[(16 * zy) * 16 + 4 * zx];
     for (uint32_t base = 0; base < nitems; base += blockDim.x) {
+        if (base + (tid & ~63u) >= nitems)
+            break;  // nothing left for this wave (the centre probe is ONE item group: three of the four waves skip it)
         const uint32_t item = base + tid;
         const bool     on   = item < nitems;  // uniform over each group of 16 lanes
         const uint32_t qi = on ? item >> 4 : 0, y = fast_div(qi, inv_nq), q = qi - y * nq;
@@ -550,21 +549,14 @@ __device__ bool make_ctx(Ctx &c, const SvtHipMeFrameJob &job, uint32_t bx) {
 template <class LDS>
 __device__ void stage_sources(LDS &L, const Ctx &c, int which) {
     ME_CTX_LOCALS(c);
+    // whole 64 x 64 / 32 x 32 / 16 x 16 tiles (a partial b64 at the picture edge reads into the padding, as the reference's
+    // SIMD kernels do; only the b64_w x b64_h part is ever used)
     if (which & 1)
-        for (uint32_t idx = tid; idx < 64 * 16; idx += blockDim.x) {
-            const uint32_t r = idx >> 4, i = idx & 15;
-            L.src_full[idx]  = load_u32_unaligned(plane_at(job.src.full, (int)org_x, (int)org_y) + (size_t)r * job.src.full.stride + 4 * i);
-        }
+        stage_rows16(L.src_full, 16, plane_at(job.src.full, (int)org_x, (int)org_y), job.src.full.stride, 64, blockDim.x, tid);
     if (which & 2)
-        for (uint32_t idx = tid; idx < 32 * 8; idx += blockDim.x) {
-            const uint32_t r = idx >> 3, i = idx & 7;
-            L.src_q[idx] = load_u32_unaligned(plane_at(job.src.quarter, (int)(org_x >> 1), (int)(org_y >> 1)) + (size_t)r * job.src.quarter.stride + 4 * i);
-        }
+        stage_rows16(L.src_q, 8, plane_at(job.src.quarter, (int)(org_x >> 1), (int)(org_y >> 1)), job.src.quarter.stride, 32, blockDim.x, tid);
     if (which & 4)
-        for (uint32_t idx = tid; idx < 16 * 4; idx += blockDim.x) {
-            const uint32_t r = idx >> 2, i = idx & 3;
-            L.src_s[idx] = load_u32_unaligned(plane_at(job.src.sixteenth, (int)(org_x >> 2), (int)(org_y >> 2)) + (size_t)r * job.src.sixteenth.stride + 4 * i);
-        }
+        stage_rows16(L.src_s, 4, plane_at(job.src.sixteenth, (int)(org_x >> 2), (int)(org_y >> 2)), job.src.sixteenth.stride, 16, blockDim.x, tid);
 }
 
 // init_me_hme_data (motion_estimation.c:3080-3140); lane 0 only
@@ -609,11 +601,7 @@ __device__ void zz_sad_all(LDS &L, const Ctx &c) {
             continue;
         const SvtHipPlane8 &rp  = job.ref[li][ri].full;
         const uint8_t      *ref = plane_at(rp, (int16_t)org_x, (int16_t)org_y);
-        uint32_t            acc = 0;
-        for (uint32_t idx = lane; idx < ndw * rows; idx += 64) {
-            const uint32_t r = idx / ndw, i = idx - r * ndw;
-            acc = __builtin_amdgcn_sad_u8(L.src_full[(2 * r) * 16 + i], load_u32_unaligned(ref + (size_t)(2 * r) * rp.stride + 4 * i), acc);
-        }
+        uint32_t            acc = block_sad16(L.src_full, ref, rp.stride, ndw, rows, 2, lane, 64);
         acc = wave_sum(acc);
         if (lane == 0) {
             uint32_t z = acc << 1;
@@ -1273,6 +1261,21 @@ __device__ void finalize_b64(LDS &L, const Ctx &c) {
 }
 
 
+// Tuning aid (make ABLATE=1): svt_hip_debug_me_stop(k) makes every workgroup return behind stage k, so that the time of the
+// kernel truncated there can be measured with the real overlap between workgroups (results are garbage).
+#ifdef SVT_HIP_ME_ABLATE
+__device__ int g_me_stop = 99;
+#define ME_STOP(k)          \
+    do {                    \
+        if (me_stop == (k)) \
+            return;         \
+    } while (0)
+#else
+#define ME_STOP(k) \
+    do {           \
+    } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // One launch, one workgroup per b64: all stages back to back.
 // ------------------------------------------------------------------------------------------------
@@ -1290,18 +1293,23 @@ __global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFra
     Ctx c;
     if (!make_ctx(c, sjob, blockIdx.x))
         return;
+#ifdef SVT_HIP_ME_ABLATE
+    const int me_stop = g_me_stop;
+#endif
     ME_CTX_LOCALS(c);
     stage_sources(L, c, 7);
     for (uint32_t i = tid; i < NL * NR * 85; i += blockDim.x) gs[i] = 0, gm[i] = 0;
     init_state_lane0(L, c);
     __syncthreads();
     ME_PHASE(0);
+    ME_STOP(0);
     if (p.me_early_exit_th || p.me_safe_limit_zz_th) {
         zz_sad_all(L, c);
         zz_prune_lane0(L, c);
         __syncthreads();
     }
     ME_PHASE(1);
+    ME_STOP(1);
     {
         // List 1 reads list 0's pre-HME results for the l1 early exit (:1771-1781) and for the tl == 0 mirror (:1853-1860):
         // only then does it need a round of its own.  With distance-based resizing, references other than the first read
@@ -1319,10 +1327,13 @@ __global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFra
                     __syncthreads();
                 }
                 ME_PHASE(2);
+                ME_STOP(2);
             } else if (step == 4) {
                 ME_PHASE(3);
+                ME_STOP(3);
             } else if (step == 5) {
                 ME_PHASE(4);
+                ME_STOP(4);
                 // the down-scaled stages' windows may have overwritten the full resolution source block: stage it again
                 // (the barrier that ends the last search orders the window reads before these writes)
                 if (pre || l0 || l1) {
@@ -1353,14 +1364,17 @@ __global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFra
         }
     }
     ME_PHASE(5);
+    ME_STOP(5);
     centre_prune_lane0(L, c);
     __syncthreads();
     ME_PHASE(6);
+    ME_STOP(6);
     for (int li = 0; li < nlists; ++li)
         for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
             if (S.sr[li][ri].do_ref)  // uniform: LDS value written before the last barrier
                 fullpel_ref(L, c, li, ri, true);
     ME_PHASE(7);
+    ME_STOP(7);
     if (p.enable_hme_flag && p.enable_me_hme_ref_pruning) {
         me_prune_lane0(L, c);
         __syncthreads();
@@ -1371,6 +1385,14 @@ __global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFra
 }
 
 }  // namespace
+
+#ifdef SVT_HIP_ME_ABLATE
+extern "C" __attribute__((visibility("default"))) int32_t svt_hip_debug_me_stop(int32_t k) {
+    SVT_HIP_CHECK(hipDeviceSynchronize());
+    SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_me_stop), &k, sizeof(k)));
+    return SVT_HIP_OK;
+}
+#endif
 
 #ifdef SVT_HIP_ME_PROFILE
 // tuning aid, only in PROF=1 builds: copies (and optionally clears) the phase counters

@@ -90,6 +90,50 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *g) {
     return *(const __attribute__((address_space(1))) u32_unaligned *)g;
 }
+// 16 bytes from any byte address: one global_load_dwordx4 (unaligned-access mode, as above)
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u128_unaligned;
+typedef uint32_t __attribute__((ext_vector_type(4))) u128v;
+__device__ __forceinline__ u128v load_u128_any(const uint8_t *g) {
+    return *(const __attribute__((address_space(1))) u128_unaligned *)g;
+}
+
+// Copy `rows` rows of `pitch` dwords from global memory (row r starts at byte g0 + r * rstride, any alignment) into LDS rows
+// of `pitch` dwords at w0, with `lanes` lanes of which this one is number `lid`.  2 / 4 / 8 / 16 / 32 lanes share a row, one
+// 16-byte load each (a fourth of the load / address instructions of a dword-per-lane copy), two rows in flight per lane.
+// Reads up to 15 bytes past the last dword of a row: callers guarantee those bytes exist (they are never used) — for
+// picture planes they are the next row's first bytes, see the contract in include/svt_hip_me.h.
+__device__ __forceinline__ void stage_rows16(uint32_t *__restrict__ w0, uint32_t pitch, const uint8_t *g0, uint32_t rstride,
+                                             uint32_t rows, uint32_t lanes, uint32_t lid) {
+    const uint32_t nch = (pitch + 3) >> 2;
+    const uint32_t lg  = nch <= 2 ? 1u : (nch <= 4 ? 2u : (nch <= 8 ? 3u : (nch <= 16 ? 4u : 5u)));
+    const uint32_t lpr = 1u << lg, rpi = lanes >> lg;  // lanes per row, rows per iteration
+    const uint32_t c0 = lid & (lpr - 1), r0 = lid >> lg;
+    for (uint32_t ch = c0; ch < nch; ch += lpr) {
+        const uint32_t  nd = pitch - 4 * ch;  // dwords of this chunk inside the row (>= 1)
+        const uint8_t  *g  = g0 + 16 * ch;
+        uint32_t       *w  = w0 + 4 * ch;
+        for (uint32_t row = r0; row < rows; row += 2 * rpi) {
+            const uint32_t row1 = row + rpi;
+            const bool     two  = row1 < rows;
+            const u128v    a    = load_u128_any(g + (size_t)(row * rstride));
+            u128v          b    = {0u, 0u, 0u, 0u};
+            if (two)
+                b = load_u128_any(g + (size_t)(row1 * rstride));
+            uint32_t *wa = w + row * pitch, *wb = w + row1 * pitch;
+            wa[0] = a.x;
+            if (nd > 1) wa[1] = a.y;
+            if (nd > 2) wa[2] = a.z;
+            if (nd > 3) wa[3] = a.w;
+            if (two) {
+                wb[0] = b.x;
+                if (nd > 1) wb[1] = b.y;
+                if (nd > 2) wb[2] = b.z;
+                if (nd > 3) wb[3] = b.w;
+            }
+        }
+    }
+}
+
 // n / d for n * d < 2^32 with inv = ceil(2^32 / d) (d >= 2; d == 1 is handled by the caller passing inv = 0)
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
 __device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? (uint32_t)((0x100000000ull + d - 1) / d) : 0u; }
@@ -290,41 +334,23 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
         const uint32_t nseg = sh.nseg;
         if (nseg == 0)
             break;
-        // stage.  Row-group mapping: G lanes share a window row (G = 8 / 16 / 32 by row length), so the row address is
-        // computed once per row and the inner loop is load + LDS store; four rows are in flight per lane.  With at least
-        // as many segments as waves every wave takes whole segments, otherwise all waves split each segment's rows.
+        // stage: 16-byte loads, 2..32 lanes per window row (stage_rows16).  With at least as many segments as waves every wave
+        // takes whole segments, otherwise all waves split each segment's rows.
         {
             const uint32_t nwv = blockDim.x >> 6;
             const bool     per_wave = nseg >= nwv;
             const uint32_t lanes = per_wave ? 64u : blockDim.x, lid = per_wave ? (tid & 63u) : tid;
             for (uint32_t s = per_wave ? (tid >> 6) : 0u; s < nseg; s += per_wave ? nwv : 1u) {
-                const SearchSeg   sg    = sh.seg[s];
-                const SearchDesc &ds    = sh.desc[sg.d];
-                const uint32_t    pitch = ds.pitch_dw, rows = sg.nstage, rstride = ds.raw_stride;
-                const uint32_t    G = pitch <= 8 ? 8u : (pitch <= 16 ? 16u : 32u), rpp = lanes / G;
-                const uint32_t    c0 = lid & (G - 1), r0 = lid / G;
-                const uint8_t    *g0 = ds.ref + (size_t)(ds.skip ? 2 * sg.j0 + 1 : sg.j0) * rstride;
-                uint32_t         *w0 = win + sg.lds_dw;
-                for (uint32_t col = c0; col < pitch; col += G)
-                    for (uint32_t row = r0; row < rows; row += 4 * rpp) {
-                        uint32_t v[4];
-#pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {
-                            const uint32_t rr = row + u * rpp;
-                            v[u]              = rr < rows ? load_u32_any(g0 + rr * rstride + 4 * col) : 0u;
-                        }
-#pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {
-                            const uint32_t rr = row + u * rpp;
-                            if (rr < rows)
-                                w0[rr * pitch + col] = v[u];
-                        }
-                    }
+                const SearchSeg   sg = sh.seg[s];
+                const SearchDesc &ds = sh.desc[sg.d];
+                const uint32_t    rstride = ds.raw_stride;
+                stage_rows16(win + sg.lds_dw, ds.pitch_dw, ds.ref + (size_t)(ds.skip ? 2 * sg.j0 + 1 : sg.j0) * rstride, rstride,
+                             sg.nstage, lanes, lid);
             }
         }
         __syncthreads();
         MS_PHASE(1);
-        // search
+        // search: one work item = four horizontally adjacent positions (a quad) of one searched row
         const uint32_t nitems = sh.nitems;
         for (uint32_t item = tid; item < nitems; item += blockDim.x) {
             const uint32_t   s  = find_seg<true, SH>(sh, nseg, item);

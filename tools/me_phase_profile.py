@@ -16,7 +16,7 @@ PHASES = ["init+stage", "zz_sad", "pre-HME", "HME L0", "HME L1", "HME L2", "cent
 
 def main():
     import torch  # noqa: F401  (bench imports it; keep the same process layout)
-    sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-lf"] + sys.argv[1:]
     sys.path.insert(0, ROOT)
     from svtav1_hip import abi
     lib = abi.load()
