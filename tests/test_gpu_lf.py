@@ -120,7 +120,8 @@ def run_plane_orc(orc, recon, source, w, h, is16, xdec, ydec, pli, filt, prm, fb
 
 @pytest.mark.parametrize("lw,lh,bd,is16,sub,fmt", [
     (200, 136, 8, 0, 2, 420), (200, 136, 10, 1, 1, 420), (64, 64, 8, 0, 4, 420), (328, 72, 8, 1, 1, 444), (136, 200, 10, 1, 2, 420),
-    (1920, 1080, 8, 0, 1, 420)])
+    (1920, 1080, 8, 0, 1, 420),
+    (3840, 2160, 10, 1, 1, 420)])      # BASELINE.json configs[3] size: 60 x 34 filter blocks, u16 strides > 4096 samples
 def test_tier_b_picture(hip, orc, lw, lh, bd, is16, sub, fmt):
     """Whole-picture CDEF search + apply, luma then both chroma planes, against the oracle."""
     rng = np.random.default_rng(lw * 7 + lh + bd + sub)
@@ -254,10 +255,12 @@ class OrcLvl:
         return lvl.reshape(-1)
 
 
-@pytest.mark.parametrize("variant", range(8))
+@pytest.mark.parametrize("variant", list(range(8)) + [10])
 def test_tier_b_deblock_frame(hip, orc, variant):
     rng = np.random.default_rng(300 + variant)
-    w, h = ((200, 136), (328, 184), (64, 64), (136, 264), (196, 134), (322, 182), (1920, 1080), (130, 258))[variant]
+    # variant 10: the configs[3] size, 3840 x 2160 10-bit (variant % 3 == 1), all three planes
+    w, h = {**dict(enumerate(((200, 136), (328, 184), (64, 64), (136, 264), (196, 134), (322, 182), (1920, 1080), (130, 258)))),
+            10: (3840, 2160)}[variant]
     bd, is16 = ((8, 0), (10, 1), (8, 1))[variant % 3]
     mi_cols, mi_rows = (w + 7) // 8 * 2, (h + 7) // 8 * 2
     mi_stride = mi_cols + 3
