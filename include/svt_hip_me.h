@@ -221,6 +221,18 @@ static inline uint32_t svt_hip_me_stored_pus(const SvtHipMeParams *p) {
     return p->enable_me_16x16 ? (p->enable_me_8x8 ? 85u : 21u) : 5u;
 }
 
+/* Memory contract of the picture planes (svt_hip_analysis_frames, svt_hip_pyramid_frame, svt_hip_variance_frame,
+ * svt_hip_me_frames[_dev]): a plane occupies exactly stride * (height + 2 * org_y) bytes from `buf` (the layout of
+ * EbPictureBufferDesc, pic_buffer_desc.h:34-75) and NOTHING outside those bytes is ever read or written — a plane may end
+ * at the last byte of an allocation.  This holds because svt_hip_me_validate_jobs enforces the reference's paddings
+ * (org_x, org_y >= 64 / 32 / 16 for the full / quarter / sixteenth plane; enc_handle.c:1276,1292,1308 allocate 68 / 32 /
+ * 16), and with those the search-area clamps of the reference (motion_estimation.c:837-888, 1442-1561) keep every
+ * search window at least one whole row above the plane's last row: the window stagers fetch 16-byte chunks and may
+ * read up to 31 bytes past the last byte a window row needs, which then are the first bytes of the following row.
+ * tests/test_gpu_me.py::test_me_frame_exact_size_planes pins this (planes packed back to back, results unchanged).
+ *
+ * svt_hip_sad_loop_batch (arbitrary windows in a caller-built arena) cannot make that argument: the arena must be
+ * readable for 64 bytes past the last byte addressed by any descriptor (window or source block). */
 typedef struct SvtHipPyramid8 {
     SvtHipPlane8 full, quarter, sixteenth; /* input_padded_pic, quarter_/sixteenth_downsampled_picture_ptr */
 } SvtHipPyramid8;

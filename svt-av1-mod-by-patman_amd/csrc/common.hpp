@@ -46,14 +46,43 @@ void  stage_commit(hipStream_t st);
         }                                                                                          \
     } while (0)
 
-// For void Tier A functions: they cannot report; they record the error and abort loudly — a silent
-// wrong result would corrupt the bitstream (and there is deliberately no CPU fallback in this library).
-#define SVT_HIP_CHECK_FATAL(expr)                                                                  \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) {                                                                    \
-            fprintf(stderr, "libsvtav1_hip fatal: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
-                    __FILE__, __LINE__);                                                           \
-            abort();                                                                               \
-        }                                                                                          \
+// ---- Tier A failure handling (SURVEY.md 8b "never abort") ---------------------------------------------------------------
+// A Tier A leaf has the reference's signature and cannot report an error.  When a HIP call fails inside one (device lost,
+// out of memory ...) it throws TierAError; the exported wrapper (TIER_A_CALL) catches it, and tier_a_fail() then, ONCE per
+// process: logs the cause, puts the CPU function pointers that svt_hip_install_rtcd() had replaced back into the encoder's
+// RTCD slots and latches the library as broken.  The failing call itself — and any call that was already on its way into a
+// leaf on another thread — is completed by the restored CPU function with the same arguments, so the encoder carries on with
+// its own kernels and an intact bitstream.  Without an installer-saved CPU pointer (the leaf was called directly, e.g.
+// through ctypes) there is nothing to fall back on: the process stops with the error message, as before.
+namespace svthip {
+struct TierAError {
+    char what[256];
+};
+[[noreturn]] void tier_a_throw(const char *fmt, ...);
+bool              tier_a_broken();
+void              tier_a_fail(const char *leaf, const char *what);
+void             *tier_a_cpu(const char *leaf);  // saved CPU function of <leaf> (never NULL: stops the process otherwise)
+bool              tier_a_inject_now();           // test hook (svt_hip_debug_inject_failure)
+}  // namespace svthip
+
+#define SVT_HIP_CHECK_FATAL(expr)                                                                            \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess || svthip::tier_a_inject_now())                                                 \
+            svthip::tier_a_throw("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Body of every exported Tier A function: NAME = the reference's pointer name, IMPL_EXPR = the call that does the work,
+// ARGS = the parenthesised argument list for the CPU function.
+#define TIER_A_CALL(NAME, IMPL_EXPR, ARGS)                             \
+    do {                                                               \
+        typedef decltype(&NAME##_hip) TierAFn_;                        \
+        if (__builtin_expect(!svthip::tier_a_broken(), 1)) {           \
+            try {                                                      \
+                return IMPL_EXPR;                                      \
+            } catch (const svthip::TierAError &e_) {                   \
+                svthip::tier_a_fail(#NAME, e_.what);                   \
+            }                                                          \
+        }                                                              \
+        return ((TierAFn_)svthip::tier_a_cpu(#NAME))ARGS;              \
     } while (0)

@@ -141,10 +141,7 @@ __global__ __launch_bounds__(256) void convolve_sr_kernel(const SvtHipConvolveDe
     }
 }
 
-void fatal(const char *what) {
-    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-    abort();
-}
+[[noreturn]] void fatal(const char *what) { svthip::tier_a_throw("%s: %s", what, svt_hip_last_error()); }
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 // Tier A: stage the block and its margins, run the batch kernel on one descriptor, copy the prediction back.
@@ -225,13 +222,13 @@ extern "C" int32_t svt_hip_convolve_batch(const SvtHipConvolveDesc *d_desc, uint
     extern "C" void svt_av1_convolve_##mode##_hip(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride,      \
                                                   int32_t w, int32_t h, SvtHipInterpFilterParams *fx, SvtHipInterpFilterParams *fy, \
                                                   const int32_t sx, const int32_t sy, SvtHipConvolveParams *cp) {               \
-        conv_tier_a(src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, UX, UY, 0, 8);                                   \
+        TIER_A_CALL(svt_av1_convolve_##mode, conv_tier_a(src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, UX, UY, 0, 8), (src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp)); \
     }                                                                                                                            \
     extern "C" void svt_av1_highbd_convolve_##mode##_hip(const uint16_t *src, int32_t src_stride, uint16_t *dst, int32_t dst_stride, \
                                                          int32_t w, int32_t h, const SvtHipInterpFilterParams *fx,              \
                                                          const SvtHipInterpFilterParams *fy, const int32_t sx, const int32_t sy, \
                                                          SvtHipConvolveParams *cp, int32_t bd) {                                \
-        conv_tier_a(src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, UX, UY, 1, bd);                                  \
+        TIER_A_CALL(svt_av1_highbd_convolve_##mode, conv_tier_a(src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, UX, UY, 1, bd), (src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, bd)); \
     }
 SVT_HIP_DEF_CONV(2d_sr, 1, 1)
 SVT_HIP_DEF_CONV(x_sr, 1, 0)
@@ -243,13 +240,13 @@ SVT_HIP_DEF_CONV(2d_copy_sr, 0, 0)
     extern "C" void svt_av1_jnt_convolve_##mode##_hip(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride,  \
                                                       int32_t w, int32_t h, SvtHipInterpFilterParams *fx, SvtHipInterpFilterParams *fy, \
                                                       const int32_t sx, const int32_t sy, SvtHipConvolveParams *cp) {           \
-        conv_tier_a(src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, UX, UY, 0, 8, 1);                                \
+        TIER_A_CALL(svt_av1_jnt_convolve_##mode, conv_tier_a(src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, UX, UY, 0, 8, 1), (src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp)); \
     }                                                                                                                            \
     extern "C" void svt_av1_highbd_jnt_convolve_##mode##_hip(const uint16_t *src, int32_t src_stride, uint16_t *dst,            \
                                                              int32_t dst_stride, int32_t w, int32_t h,                          \
                                                              const SvtHipInterpFilterParams *fx, const SvtHipInterpFilterParams *fy, \
                                                              const int32_t sx, const int32_t sy, SvtHipConvolveParams *cp, int32_t bd) { \
-        conv_tier_a(src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, UX, UY, 1, bd, 1);                               \
+        TIER_A_CALL(svt_av1_highbd_jnt_convolve_##mode, conv_tier_a(src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, UX, UY, 1, bd, 1), (src, src_stride, dst, dst_stride, w, h, fx, fy, sx, sy, cp, bd)); \
     }
 SVT_HIP_DEF_JNT(2d, 1, 1)
 SVT_HIP_DEF_JNT(x, 1, 0)

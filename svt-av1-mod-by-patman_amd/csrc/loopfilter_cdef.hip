@@ -645,10 +645,7 @@ __global__ __launch_bounds__(256) void search_one_dual_kernel(const uint64_t *__
         out[0] = s_tot[0], out[1] = s_id[0];
 }
 
-void fatal(const char *what) {
-    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-    abort();
-}
+[[noreturn]] void fatal(const char *what) { svthip::tier_a_throw("%s: %s", what, svt_hip_last_error()); }
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
@@ -717,8 +714,9 @@ extern "C" int32_t svt_hip_cdef_apply_frame(const SvtHipCdefPlane *planes, uint3
     return SVT_HIP_OK;
 }
 
-extern "C" void svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2,
-                                               int32_t coeff_shift, uint8_t *out1, uint8_t *out2) {
+static void svt_aom_cdef_find_dir_dual_hip_impl(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2, int32_t coeff_shift, uint8_t *out1, uint8_t *out2);
+extern "C" void svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2, int32_t coeff_shift, uint8_t *out1, uint8_t *out2) { TIER_A_CALL(svt_aom_cdef_find_dir_dual, svt_aom_cdef_find_dir_dual_hip_impl(img1, img2, stride, var1, var2, coeff_shift, out1, out2), (img1, img2, stride, var1, var2, coeff_shift, out1, out2)); }
+static void svt_aom_cdef_find_dir_dual_hip_impl(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2, int32_t coeff_shift, uint8_t *out1, uint8_t *out2) {
     if (!ensure_init())
         fatal("cdef_find_dir");
     hipStream_t  st   = resolve_stream(nullptr);
@@ -739,15 +737,17 @@ extern "C" void svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint1
     if (img2)
         *out2 = (uint8_t)r[2], *var2 = r[3];
 }
-extern "C" uint8_t svt_aom_cdef_find_dir_hip(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift) {
+static uint8_t svt_aom_cdef_find_dir_hip_impl(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift);
+extern "C" uint8_t svt_aom_cdef_find_dir_hip(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift) { TIER_A_CALL(svt_aom_cdef_find_dir, svt_aom_cdef_find_dir_hip_impl(img, stride, var, coeff_shift), (img, stride, var, coeff_shift)); }
+static uint8_t svt_aom_cdef_find_dir_hip_impl(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift) {
     uint8_t d = 0;
     svt_aom_cdef_find_dir_dual_hip(img, nullptr, stride, var, nullptr, coeff_shift, &d, nullptr);
     return d;
 }
 
-extern "C" void svt_cdef_filter_block_hip(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength,
-                                          int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize,
-                                          int32_t coeff_shift, uint8_t subsampling_factor) {
+static void svt_cdef_filter_block_hip_impl(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength, int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize, int32_t coeff_shift, uint8_t subsampling_factor);
+extern "C" void svt_cdef_filter_block_hip(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength, int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize, int32_t coeff_shift, uint8_t subsampling_factor) { TIER_A_CALL(svt_cdef_filter_block, svt_cdef_filter_block_hip_impl(dst8, dst16, dstride, in, pri_strength, sec_strength, dir, pri_damping, sec_damping, bsize, coeff_shift, subsampling_factor), (dst8, dst16, dstride, in, pri_strength, sec_strength, dir, pri_damping, sec_damping, bsize, coeff_shift, subsampling_factor)); }
+static void svt_cdef_filter_block_hip_impl(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength, int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize, int32_t coeff_shift, uint8_t subsampling_factor) {
     if (!ensure_init())
         fatal("cdef_filter_block");
     const int    bh = 4 << (bsize == 3 || bsize == 1), bw = 4 << (bsize == 3 || bsize == 2);
@@ -772,8 +772,9 @@ extern "C" void svt_cdef_filter_block_hip(uint8_t *dst8, uint16_t *dst16, int32_
 
 // Pure 8-bit -> 16-bit widening of a host rectangle: no arithmetic, evaluated on the calling thread
 // (the device-resident equivalent is the tile staging of the kernels above).
-extern "C" void svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v,
-                                                     int32_t hh) {
+static void svt_aom_copy_rect8_8bit_to_16bit_hip_impl(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v, int32_t hh);
+extern "C" void svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v, int32_t hh) { TIER_A_CALL(svt_aom_copy_rect8_8bit_to_16bit, svt_aom_copy_rect8_8bit_to_16bit_hip_impl(dst, dstride, src, sstride, v, hh), (dst, dstride, src, sstride, v, hh)); }
+static void svt_aom_copy_rect8_8bit_to_16bit_hip_impl(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v, int32_t hh) {
     for (int32_t i = 0; i < v; i++)
         for (int32_t j = 0; j < hh; j++) dst[i * dstride + j] = src[i * sstride + j];
 }
@@ -802,19 +803,22 @@ static uint64_t dist_tier_a(const void *dst, int32_t dstride, const void *src, c
     SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
     return *(const uint64_t *)(h + o_res);
 }
-extern "C" uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t dstride, const uint16_t *src, const SvtHipCdefList *dlist,
-                                                    int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) {
+static uint64_t svt_compute_cdef_dist_16bit_hip_impl(const uint16_t *dst, int32_t dstride, const uint16_t *src, const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub);
+extern "C" uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t dstride, const uint16_t *src, const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) { TIER_A_CALL(svt_compute_cdef_dist_16bit, svt_compute_cdef_dist_16bit_hip_impl(dst, dstride, src, dlist, cdef_count, bsize, coeff_shift, pli, sub), (dst, dstride, src, dlist, cdef_count, bsize, coeff_shift, pli, sub)); }
+static uint64_t svt_compute_cdef_dist_16bit_hip_impl(const uint16_t *dst, int32_t dstride, const uint16_t *src, const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) {
     return dist_tier_a(dst, dstride, src, dlist, cdef_count, bsize, coeff_shift, pli, sub, 1);
 }
-extern "C" uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const SvtHipCdefList *dlist,
-                                                   int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) {
+static uint64_t svt_compute_cdef_dist_8bit_hip_impl(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub);
+extern "C" uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) { TIER_A_CALL(svt_compute_cdef_dist_8bit, svt_compute_cdef_dist_8bit_hip_impl(dst8, dstride, src8, dlist, cdef_count, bsize, coeff_shift, pli, sub), (dst8, dstride, src8, dlist, cdef_count, bsize, coeff_shift, pli, sub)); }
+static uint64_t svt_compute_cdef_dist_8bit_hip_impl(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const SvtHipCdefList *dlist, int32_t cdef_count, int32_t bsize, int32_t coeff_shift, int32_t pli, uint8_t sub) {
     return dist_tier_a(dst8, dstride, src8, dlist, cdef_count, bsize, coeff_shift, pli, sub, 0);
 }
 
 // svt_search_one_dual (aom_dsp_rtcd.h:239): mse[0][i] / mse[1][i] are the luma / chroma tables of filter block i (TOTAL_STRENGTHS
 // entries each in the reference; entries below end_gi are read).  lev0 / lev1 hold nb_strengths chosen pairs and receive one more.
-extern "C" uint64_t svt_search_one_dual_hip(int *lev0, int *lev1, int nb_strengths, uint64_t **mse[2], int sb_count, int start_gi,
-                                            int end_gi) {
+static uint64_t svt_search_one_dual_hip_impl(int *lev0, int *lev1, int nb_strengths, uint64_t **mse[2], int sb_count, int start_gi, int end_gi);
+extern "C" uint64_t svt_search_one_dual_hip(int *lev0, int *lev1, int nb_strengths, uint64_t **mse[2], int sb_count, int start_gi, int end_gi) { TIER_A_CALL(svt_search_one_dual, svt_search_one_dual_hip_impl(lev0, lev1, nb_strengths, mse, sb_count, start_gi, end_gi), (lev0, lev1, nb_strengths, mse, sb_count, start_gi, end_gi)); }
+static uint64_t svt_search_one_dual_hip_impl(int *lev0, int *lev1, int nb_strengths, uint64_t **mse[2], int sb_count, int start_gi, int end_gi) {
     if (nb_strengths < 0 || nb_strengths >= 8 || start_gi < 0 || end_gi > 64 || sb_count < 0) {
         set_error("svt_search_one_dual: nb_strengths %d / strength range %d..%d outside CDEF's limits", nb_strengths, start_gi, end_gi);
         fatal("svt_search_one_dual");

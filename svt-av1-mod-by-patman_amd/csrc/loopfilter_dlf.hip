@@ -206,8 +206,7 @@ __global__ void lpf_leaf_kernel(T *s, int pitch, int vertical, int len, int blim
 // Tier A: stage the samples the reference call touches (4 lines x 2*reach taps), run the leaf, copy them back.
 template <typename T> void lpf_tier_a(T *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh, int bd, int len, int vertical) {
     if (!ensure_init()) {
-        fprintf(stderr, "libsvtav1_hip fatal: lpf: %s\n", svt_hip_last_error());
-        abort();
+        svthip::tier_a_throw("lpf: %s", svt_hip_last_error());
     }
     const int       reach = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
     const ptrdiff_t first = vertical ? -reach : -(ptrdiff_t)reach * pitch;
@@ -236,11 +235,11 @@ template <typename T> void lpf_tier_a(T *s, int32_t pitch, const uint8_t *blimit
 #define SVT_HIP_DEF_LPF(dir, n, vert)                                                                                              \
     extern "C" void svt_aom_lpf_##dir##_##n##_hip(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit,          \
                                                   const uint8_t *thresh) {                                                         \
-        lpf_tier_a<uint8_t>(s, pitch, blimit, limit, thresh, 8, n, vert);                                                          \
+        TIER_A_CALL(svt_aom_lpf_##dir##_##n, lpf_tier_a<uint8_t>(s, pitch, blimit, limit, thresh, 8, n, vert), (s, pitch, blimit, limit, thresh)); \
     }                                                                                                                              \
     extern "C" void svt_aom_highbd_lpf_##dir##_##n##_hip(uint16_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit,  \
                                                          const uint8_t *thresh, int32_t bd) {                                      \
-        lpf_tier_a<uint16_t>(s, pitch, blimit, limit, thresh, bd, n, vert);                                                        \
+        TIER_A_CALL(svt_aom_highbd_lpf_##dir##_##n, lpf_tier_a<uint16_t>(s, pitch, blimit, limit, thresh, bd, n, vert), (s, pitch, blimit, limit, thresh, bd)); \
     }
 SVT_HIP_DEF_LPF(horizontal, 4, 0)
 SVT_HIP_DEF_LPF(horizontal, 6, 0)

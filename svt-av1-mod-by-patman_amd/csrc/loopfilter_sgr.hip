@@ -379,10 +379,7 @@ SgrGeom geom_of(const SvtHipSgrUnit *u) {
     return SgrGeom{u->dat, u->dat_stride, u->width, u->height, u->is_16bit, u->bit_depth, u->pu_w, u->pu_h};
 }
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
-void          fatal(const char *what) {
-    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-    abort();
-}
+[[noreturn]] void fatal(const char *what) { svthip::tier_a_throw("%s: %s", what, svt_hip_last_error()); }
 template <typename T> const T *decode_ptr(const uint8_t *p, int highbd) {
     return highbd ? (const T *)((uintptr_t)p << 1) : (const T *)p;  // CONVERT_TO_SHORTPTR (definitions.h:953)
 }
@@ -477,8 +474,9 @@ template <typename T> static T *stage_region(uint8_t *d, uint8_t *h, size_t &off
     return dp;
 }
 
-extern "C" void svt_av1_selfguided_restoration_hip(const uint8_t *dgd8, int32_t width, int32_t height, int32_t dgd_stride, int32_t *flt0,
-                                                   int32_t *flt1, int32_t flt_stride, int32_t ep, int32_t bit_depth, int32_t highbd) {
+static void svt_av1_selfguided_restoration_hip_impl(const uint8_t *dgd8, int32_t width, int32_t height, int32_t dgd_stride, int32_t *flt0, int32_t *flt1, int32_t flt_stride, int32_t ep, int32_t bit_depth, int32_t highbd);
+extern "C" void svt_av1_selfguided_restoration_hip(const uint8_t *dgd8, int32_t width, int32_t height, int32_t dgd_stride, int32_t *flt0, int32_t *flt1, int32_t flt_stride, int32_t ep, int32_t bit_depth, int32_t highbd) { TIER_A_CALL(svt_av1_selfguided_restoration, svt_av1_selfguided_restoration_hip_impl(dgd8, width, height, dgd_stride, flt0, flt1, flt_stride, ep, bit_depth, highbd), (dgd8, width, height, dgd_stride, flt0, flt1, flt_stride, ep, bit_depth, highbd)); }
+static void svt_av1_selfguided_restoration_hip_impl(const uint8_t *dgd8, int32_t width, int32_t height, int32_t dgd_stride, int32_t *flt0, int32_t *flt1, int32_t flt_stride, int32_t ep, int32_t bit_depth, int32_t highbd) {
     if (!ensure_init())
         fatal("selfguided_restoration");
     if (width <= 0 || height <= 0 || width > 384 || height > 384 || ep < 0 || ep > 15) {
@@ -509,9 +507,9 @@ extern "C" void svt_av1_selfguided_restoration_hip(const uint8_t *dgd8, int32_t 
     }
 }
 
-extern "C" void svt_apply_selfguided_restoration_hip(const uint8_t *dat, int32_t width, int32_t height, int32_t stride, int32_t eps,
-                                                     const int32_t *xqd, uint8_t *dst, int32_t dst_stride, int32_t *tmpbuf, int32_t bit_depth,
-                                                     int32_t highbd) {
+static void svt_apply_selfguided_restoration_hip_impl(const uint8_t *dat, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t *xqd, uint8_t *dst, int32_t dst_stride, int32_t *tmpbuf, int32_t bit_depth, int32_t highbd);
+extern "C" void svt_apply_selfguided_restoration_hip(const uint8_t *dat, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t *xqd, uint8_t *dst, int32_t dst_stride, int32_t *tmpbuf, int32_t bit_depth, int32_t highbd) { TIER_A_CALL(svt_apply_selfguided_restoration, svt_apply_selfguided_restoration_hip_impl(dat, width, height, stride, eps, xqd, dst, dst_stride, tmpbuf, bit_depth, highbd), (dat, width, height, stride, eps, xqd, dst, dst_stride, tmpbuf, bit_depth, highbd)); }
+static void svt_apply_selfguided_restoration_hip_impl(const uint8_t *dat, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t *xqd, uint8_t *dst, int32_t dst_stride, int32_t *tmpbuf, int32_t bit_depth, int32_t highbd) {
     (void)tmpbuf;
     if (!ensure_init())
         fatal("apply_selfguided_restoration");
@@ -576,23 +574,23 @@ static void proj_tier_a(const uint8_t *src8, int width, int height, int src_stri
         memcpy(xq_solved, h + 2 * pl + 2 * fl + 64, 8);
 }
 
-extern "C" int64_t svt_av1_lowbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride,
-                                                      const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride,
-                                                      int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams *params) {
+static int64_t svt_av1_lowbd_pixel_proj_error_hip_impl(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams *params);
+extern "C" int64_t svt_av1_lowbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams *params) { TIER_A_CALL(svt_av1_lowbd_pixel_proj_error, svt_av1_lowbd_pixel_proj_error_hip_impl(src8, width, height, src_stride, dat8, dat_stride, flt0, flt0_stride, flt1, flt1_stride, xq, params), (src8, width, height, src_stride, dat8, dat_stride, flt0, flt0_stride, flt1, flt1_stride, xq, params)); }
+static int64_t svt_av1_lowbd_pixel_proj_error_hip_impl(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams *params) {
     long long out[6];
     proj_tier_a(src8, width, height, src_stride, dat8, dat_stride, 0, flt0, flt0_stride, flt1, flt1_stride, params, xq[0], xq[1], 0, out, nullptr);
     return out[5];
 }
-extern "C" int64_t svt_av1_highbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride,
-                                                       const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride,
-                                                       int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams *params) {
+static int64_t svt_av1_highbd_pixel_proj_error_hip_impl(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams *params);
+extern "C" int64_t svt_av1_highbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams *params) { TIER_A_CALL(svt_av1_highbd_pixel_proj_error, svt_av1_highbd_pixel_proj_error_hip_impl(src8, width, height, src_stride, dat8, dat_stride, flt0, flt0_stride, flt1, flt1_stride, xq, params), (src8, width, height, src_stride, dat8, dat_stride, flt0, flt0_stride, flt1, flt1_stride, xq, params)); }
+static int64_t svt_av1_highbd_pixel_proj_error_hip_impl(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams *params) {
     long long out[6];
     proj_tier_a(src8, width, height, src_stride, dat8, dat_stride, 1, flt0, flt0_stride, flt1, flt1_stride, params, xq[0], xq[1], 0, out, nullptr);
     return out[5];
 }
-extern "C" void svt_get_proj_subspace_hip(const uint8_t *src8, int width, int height, int src_stride, const uint8_t *dat8, int dat_stride,
-                                          int use_highbitdepth, int32_t *flt0, int flt0_stride, int32_t *flt1, int flt1_stride, int *xq,
-                                          const SvtHipSgrParams *params) {
+static void svt_get_proj_subspace_hip_impl(const uint8_t *src8, int width, int height, int src_stride, const uint8_t *dat8, int dat_stride, int use_highbitdepth, int32_t *flt0, int flt0_stride, int32_t *flt1, int flt1_stride, int *xq, const SvtHipSgrParams *params);
+extern "C" void svt_get_proj_subspace_hip(const uint8_t *src8, int width, int height, int src_stride, const uint8_t *dat8, int dat_stride, int use_highbitdepth, int32_t *flt0, int flt0_stride, int32_t *flt1, int flt1_stride, int *xq, const SvtHipSgrParams *params) { TIER_A_CALL(svt_get_proj_subspace, svt_get_proj_subspace_hip_impl(src8, width, height, src_stride, dat8, dat_stride, use_highbitdepth, flt0, flt0_stride, flt1, flt1_stride, xq, params), (src8, width, height, src_stride, dat8, dat_stride, use_highbitdepth, flt0, flt0_stride, flt1, flt1_stride, xq, params)); }
+static void svt_get_proj_subspace_hip_impl(const uint8_t *src8, int width, int height, int src_stride, const uint8_t *dat8, int dat_stride, int use_highbitdepth, int32_t *flt0, int flt0_stride, int32_t *flt1, int flt1_stride, int *xq, const SvtHipSgrParams *params) {
     long long out[6];
     int32_t   solved[2] = {0, 0};
     proj_tier_a(src8, width, height, src_stride, dat8, dat_stride, use_highbitdepth, flt0, flt0_stride, flt1, flt1_stride, params, 0, 0, 1, out,

@@ -265,10 +265,7 @@ __global__ __launch_bounds__(256) void wiener_convolve_kernel(const void *__rest
     }
 }
 
-void fatal(const char *what) {
-    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-    abort();
-}
+[[noreturn]] void fatal(const char *what) { svthip::tier_a_throw("%s: %s", what, svt_hip_last_error()); }
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct AuxBuf {  // per-thread grow-only device buffer for the raw first moments
@@ -378,13 +375,14 @@ static void stats_tier_a(int32_t win, const uint8_t *dgd8, const uint8_t *src8, 
     memcpy(M, hh + dbytes + sbytes, sizeof(int64_t) * w2);
     memcpy(H, hh + dbytes + sbytes + sizeof(int64_t) * W2MAX, sizeof(int64_t) * w2 * w2);
 }
-extern "C" void svt_av1_compute_stats_hip(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end,
-                                          int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H) {
+static void svt_av1_compute_stats_hip_impl(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H);
+extern "C" void svt_av1_compute_stats_hip(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H) { TIER_A_CALL(svt_av1_compute_stats, svt_av1_compute_stats_hip_impl(wiener_win, dgd8, src8, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H), (wiener_win, dgd8, src8, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H)); }
+static void svt_av1_compute_stats_hip_impl(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H) {
     stats_tier_a(wiener_win, dgd8, src8, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H, 0, 8);
 }
-extern "C" void svt_av1_compute_stats_highbd_hip(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end,
-                                                 int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H,
-                                                 int32_t bit_depth) {
+static void svt_av1_compute_stats_highbd_hip_impl(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H, int32_t bit_depth);
+extern "C" void svt_av1_compute_stats_highbd_hip(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H, int32_t bit_depth) { TIER_A_CALL(svt_av1_compute_stats_highbd, svt_av1_compute_stats_highbd_hip_impl(wiener_win, dgd8, src8, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H, bit_depth), (wiener_win, dgd8, src8, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H, bit_depth)); }
+static void svt_av1_compute_stats_highbd_hip_impl(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H, int32_t bit_depth) {
     stats_tier_a(wiener_win, dgd8, src8, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H, 1, bit_depth);
 }
 
@@ -411,15 +409,15 @@ static void convolve_tier_a(const uint8_t *src, ptrdiff_t src_stride, uint8_t *d
     SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
     for (int r = 0; r < h; r++) memcpy(ob + (size_t)r * dst_stride * px, hh + ibytes + (size_t)r * w * px, (size_t)w * px);
 }
-extern "C" void svt_av1_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride,
-                                                    const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h,
-                                                    const SvtHipConvolveParams *conv_params) {
+static void svt_av1_wiener_convolve_add_src_hip_impl(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params);
+extern "C" void svt_av1_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params) { TIER_A_CALL(svt_av1_wiener_convolve_add_src, svt_av1_wiener_convolve_add_src_hip_impl(src, src_stride, dst, dst_stride, filter_x, filter_y, w, h, conv_params), (src, src_stride, dst, dst_stride, filter_x, filter_y, w, h, conv_params)); }
+static void svt_av1_wiener_convolve_add_src_hip_impl(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params) {
     (void)conv_params;  // get_conv_params_wiener(8) is the only value the reference passes (restoration.c:443)
     convolve_tier_a(src, src_stride, dst, dst_stride, filter_x, filter_y, w, h, 0, 8);
 }
-extern "C" void svt_av1_highbd_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride,
-                                                           const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h,
-                                                           const SvtHipConvolveParams *conv_params, int32_t bd) {
+static void svt_av1_highbd_wiener_convolve_add_src_hip_impl(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params, int32_t bd);
+extern "C" void svt_av1_highbd_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params, int32_t bd) { TIER_A_CALL(svt_av1_highbd_wiener_convolve_add_src, svt_av1_highbd_wiener_convolve_add_src_hip_impl(src, src_stride, dst, dst_stride, filter_x, filter_y, w, h, conv_params, bd), (src, src_stride, dst, dst_stride, filter_x, filter_y, w, h, conv_params, bd)); }
+static void svt_av1_highbd_wiener_convolve_add_src_hip_impl(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params, int32_t bd) {
     (void)conv_params;
     convolve_tier_a(src, src_stride, dst, dst_stride, filter_x, filter_y, w, h, 1, bd);
 }

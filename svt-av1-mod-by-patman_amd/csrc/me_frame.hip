@@ -1439,6 +1439,23 @@ static int32_t validate_job(const SvtHipMeFrameJob &j, uint32_t idx) {
         return bad("unsupported picture size");
     if (j.src.full.org_x < 64 || j.src.full.org_y < 64)
         return bad("full-resolution planes need >= 64 samples of padding");
+    // geometry the kernels rely on (include/svt_hip_me.h "Memory contract"): decimated planes are exactly 1/2 and 1/4 of the
+    // full one, padded by at least 32 / 16 samples, rows at least as long as picture + both paddings
+    auto pyramid_ok = [](const SvtHipPyramid8 &y) {
+        const SvtHipPlane8 *pl[3] = {&y.full, &y.quarter, &y.sixteenth};
+        const uint32_t      pad[3] = {64, 32, 16};
+        for (int i = 0; i < 3; i++) {
+            if (pl[i]->org_x < pad[i] || pl[i]->org_y < pad[i])
+                return false;
+            if (pl[i]->width != (y.full.width >> i) || pl[i]->height != (y.full.height >> i))
+                return false;
+            if (pl[i]->stride < (uint32_t)pl[i]->width + 2u * pl[i]->org_x)
+                return false;
+        }
+        return true;
+    };
+    if (!pyramid_ok(j.src))
+        return bad("source pyramid: decimated planes must be width>>1 / width>>2 with >= 32 / 16 samples of padding and stride >= width + 2 * org_x");
     for (int l = 0; l < p.num_of_list_to_search; l++)
         for (int r = 0; r < p.num_of_ref_pic_to_search[l]; r++) {
             const SvtHipPyramid8 &y = j.ref[l][r];
@@ -1448,6 +1465,8 @@ static int32_t validate_job(const SvtHipMeFrameJob &j, uint32_t idx) {
                 return bad("reference size differs from the source (scaled references are not supported)");
             if (y.full.org_x < 64 || y.full.org_y < 64)
                 return bad("reference planes need >= 64 samples of padding");
+            if (!pyramid_ok(y))
+                return bad("reference pyramid: decimated planes must be width>>1 / width>>2 with >= 32 / 16 samples of padding and stride >= width + 2 * org_x");
         }
     const void *outs[] = {j.out.best_sad, j.out.best_mv, j.out.search_results, j.out.me_mv_array, j.out.me_candidate_array,
                           j.out.total_me_candidate_index, j.out.me_64x64_distortion, j.out.me_32x32_distortion,

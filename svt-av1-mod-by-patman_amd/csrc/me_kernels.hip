@@ -163,18 +163,14 @@ extern "C" int32_t svt_hip_sad_loop_batch(const uint8_t *d_base, const SvtHipSad
 // ------------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-extern "C" void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride,
-                                        uint32_t block_height, uint32_t block_width, uint64_t *best_sad,
-                                        int16_t *x_search_center, int16_t *y_search_center, uint32_t src_stride_raw,
-                                        uint8_t skip_search_line, int16_t search_area_width,
-                                        int16_t search_area_height) {
+static void svt_sad_loop_kernel_hip_impl(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center, uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height);
+extern "C" void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center, uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height) { TIER_A_CALL(svt_sad_loop_kernel, svt_sad_loop_kernel_hip_impl(src, src_stride, ref, ref_stride, block_height, block_width, best_sad, x_search_center, y_search_center, src_stride_raw, skip_search_line, search_area_width, search_area_height), (src, src_stride, ref, ref_stride, block_height, block_width, best_sad, x_search_center, y_search_center, src_stride_raw, skip_search_line, search_area_width, search_area_height)); }
+static void svt_sad_loop_kernel_hip_impl(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center, uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height) {
     *best_sad = 0xffffff;
     if (search_area_width <= 0 || search_area_height <= 0 || block_width == 0 || block_height == 0)
         return;
-    if (!ensure_init()) {
-        fprintf(stderr, "libsvtav1_hip fatal: %s\n", svt_hip_last_error());
-        abort();
-    }
+    if (!ensure_init()) 
+        svthip::tier_a_throw("%s", svt_hip_last_error());
     hipStream_t  st = resolve_stream(nullptr);
     Scratch     &sc = tls_scratch();
     const size_t src_span = (size_t)(block_height - 1) * src_stride + block_width;
@@ -207,14 +203,13 @@ extern "C" void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8
     }
 }
 
-extern "C" uint32_t svt_nxm_sad_kernel_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
-                                           uint32_t ref_stride, uint32_t height, uint32_t width) {
+static uint32_t svt_nxm_sad_kernel_hip_impl(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width);
+extern "C" uint32_t svt_nxm_sad_kernel_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) { TIER_A_CALL(svt_nxm_sad_kernel, svt_nxm_sad_kernel_hip_impl(src, src_stride, ref, ref_stride, height, width), (src, src_stride, ref, ref_stride, height, width)); }
+static uint32_t svt_nxm_sad_kernel_hip_impl(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
     if (height == 0 || width == 0)
         return 0;
-    if (!ensure_init()) {
-        fprintf(stderr, "libsvtav1_hip fatal: %s\n", svt_hip_last_error());
-        abort();
-    }
+    if (!ensure_init()) 
+        svthip::tier_a_throw("%s", svt_hip_last_error());
     hipStream_t  st = resolve_stream(nullptr);
     Scratch     &sc = tls_scratch();
     const size_t src_span = (size_t)(height - 1) * src_stride + width, ref_span = (size_t)(height - 1) * ref_stride + width;
@@ -231,16 +226,12 @@ extern "C" uint32_t svt_nxm_sad_kernel_hip(const uint8_t *src, uint32_t src_stri
     return *(uint32_t *)(h + off_res);
 }
 
-extern "C" void svt_ext_all_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref,
-                                                          uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8,
-                                                          uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8,
-                                                          uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8],
-                                                          uint32_t p_eight_sad8x8[64][8], uint8_t sub_sad) {
+static void svt_ext_all_sad_calculation_8x8_16x16_hip_impl(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8], uint32_t p_eight_sad8x8[64][8], uint8_t sub_sad);
+extern "C" void svt_ext_all_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8], uint32_t p_eight_sad8x8[64][8], uint8_t sub_sad) { TIER_A_CALL(svt_ext_all_sad_calculation_8x8_16x16, svt_ext_all_sad_calculation_8x8_16x16_hip_impl(src, src_stride, ref, ref_stride, mv, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, p_eight_sad16x16, p_eight_sad8x8, sub_sad), (src, src_stride, ref, ref_stride, mv, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, p_eight_sad16x16, p_eight_sad8x8, sub_sad)); }
+static void svt_ext_all_sad_calculation_8x8_16x16_hip_impl(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8], uint32_t p_eight_sad8x8[64][8], uint8_t sub_sad) {
     (void)p_eight_sad8x8;  // not written by the reference either (motion_estimation.c:218)
-    if (!ensure_init()) {
-        fprintf(stderr, "libsvtav1_hip fatal: %s\n", svt_hip_last_error());
-        abort();
-    }
+    if (!ensure_init()) 
+        svthip::tier_a_throw("%s", svt_hip_last_error());
     hipStream_t  st = resolve_stream(nullptr);
     Scratch     &sc = tls_scratch();
     const size_t src_span = (size_t)63 * src_stride + 64, ref_span = (size_t)63 * ref_stride + 64 + 7;
@@ -275,10 +266,9 @@ static inline uint32_t mv_add_x(uint32_t mv, uint32_t p) {
     const int16_t x = (int16_t)((int16_t)(mv & 0xffff) + (int16_t)p), y = (int16_t)(mv >> 16);
     return ((uint32_t)(uint16_t)y << 16) | (uint16_t)x;
 }
-extern "C" void svt_ext_eight_sad_calculation_32x32_64x64_hip(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32,
-                                                              uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
-                                                              uint32_t *p_best_mv64x64, uint32_t mv,
-                                                              uint32_t p_sad32x32[4][8]) {
+static void svt_ext_eight_sad_calculation_32x32_64x64_hip_impl(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]);
+extern "C" void svt_ext_eight_sad_calculation_32x32_64x64_hip(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]) { TIER_A_CALL(svt_ext_eight_sad_calculation_32x32_64x64, svt_ext_eight_sad_calculation_32x32_64x64_hip_impl(p_sad16x16, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, mv, p_sad32x32), (p_sad16x16, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, mv, p_sad32x32)); }
+static void svt_ext_eight_sad_calculation_32x32_64x64_hip_impl(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]) {
     for (uint32_t p = 0; p < 8; p++) {
         uint32_t t = 0;
         for (uint32_t k = 0; k < 4; k++) {
@@ -293,9 +283,9 @@ extern "C" void svt_ext_eight_sad_calculation_32x32_64x64_hip(uint32_t p_sad16x1
             p_best_sad_64x64[0] = t, p_best_mv64x64[0] = mv_add_x(mv, p);
     }
 }
-extern "C" void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32,
-                                                        uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
-                                                        uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32) {
+static void svt_ext_sad_calculation_32x32_64x64_hip_impl(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32);
+extern "C" void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32) { TIER_A_CALL(svt_ext_sad_calculation_32x32_64x64, svt_ext_sad_calculation_32x32_64x64_hip_impl(p_sad16x16, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, mv, p_sad32x32), (p_sad16x16, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, mv, p_sad32x32)); }
+static void svt_ext_sad_calculation_32x32_64x64_hip_impl(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32) {
     uint32_t t = 0;
     for (uint32_t k = 0; k < 4; k++) {
         const uint32_t s = p_sad16x16[4 * k] + p_sad16x16[4 * k + 1] + p_sad16x16[4 * k + 2] + p_sad16x16[4 * k + 3];
@@ -308,11 +298,9 @@ extern "C" void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, ui
         p_best_sad_64x64[0] = t, p_best_mv64x64[0] = mv;
 }
 
-extern "C" void svt_ext_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref,
-                                                      uint32_t ref_stride, uint32_t *p_best_sad_8x8,
-                                                      uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8,
-                                                      uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16,
-                                                      uint32_t *p_sad8x8, uint8_t sub_sad) {
+static void svt_ext_sad_calculation_8x8_16x16_hip_impl(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16, uint32_t *p_sad8x8, uint8_t sub_sad);
+extern "C" void svt_ext_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16, uint32_t *p_sad8x8, uint8_t sub_sad) { TIER_A_CALL(svt_ext_sad_calculation_8x8_16x16, svt_ext_sad_calculation_8x8_16x16_hip_impl(src, src_stride, ref, ref_stride, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, mv, p_sad16x16, p_sad8x8, sub_sad), (src, src_stride, ref, ref_stride, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, mv, p_sad16x16, p_sad8x8, sub_sad)); }
+static void svt_ext_sad_calculation_8x8_16x16_hip_impl(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16, uint32_t *p_sad8x8, uint8_t sub_sad) {
     // four 8x8 SADs of one 16x16 block at one position: four device N x M SADs
     uint32_t total = 0;
     for (uint32_t q = 0; q < 4; q++) {

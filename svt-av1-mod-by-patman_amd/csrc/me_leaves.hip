@@ -20,10 +20,7 @@ namespace {
 constexpr int WG = 256;
 
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
-[[noreturn]] void fatal(const char *what) {
-    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-    abort();
-}
+[[noreturn]] void fatal(const char *what) { svthip::tier_a_throw("%s: %s", what, svt_hip_last_error()); }
 
 __device__ __forceinline__ uint32_t wave_add(uint32_t v) {
 #pragma unroll
@@ -104,13 +101,15 @@ __global__ __launch_bounds__(WG) void pme_sad_kernel(PmeArgs a) {
 
 }  // namespace
 
-extern "C" uint32_t svt_nxm_sad_kernel_sub_sampled_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
-                                                       uint32_t height, uint32_t width) {
+static uint32_t svt_nxm_sad_kernel_sub_sampled_hip_impl(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width);
+extern "C" uint32_t svt_nxm_sad_kernel_sub_sampled_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) { TIER_A_CALL(svt_nxm_sad_kernel_sub_sampled, svt_nxm_sad_kernel_sub_sampled_hip_impl(src, src_stride, ref, ref_stride, height, width), (src, src_stride, ref, ref_stride, height, width)); }
+static uint32_t svt_nxm_sad_kernel_sub_sampled_hip_impl(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
     return svt_nxm_sad_kernel_hip(src, src_stride, ref, ref_stride, height, width);
 }
 
-extern "C" uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height,
-                                               uint32_t width) {
+static uint32_t svt_aom_sad_16b_kernel_hip_impl(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width);
+extern "C" uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) { TIER_A_CALL(svt_aom_sad_16b_kernel, svt_aom_sad_16b_kernel_hip_impl(src, src_stride, ref, ref_stride, height, width), (src, src_stride, ref, ref_stride, height, width)); }
+static uint32_t svt_aom_sad_16b_kernel_hip_impl(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
     if (!height || !width)
         return 0;
     if (!ensure_init())
@@ -131,7 +130,9 @@ extern "C" uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_strid
     return *(const uint32_t *)(h + off_res);
 }
 
-extern "C" void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value) {
+static void svt_initialize_buffer_32bits_hip_impl(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value);
+extern "C" void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value) { TIER_A_CALL(svt_initialize_buffer_32bits, svt_initialize_buffer_32bits_hip_impl(pointer, count128, count32, value), (pointer, count128, count32, value)); }
+static void svt_initialize_buffer_32bits_hip_impl(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value) {
     const uint32_t n = count128 * 4 + count32;
     if (!n)
         return;
@@ -148,11 +149,9 @@ extern "C" void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t cou
     memcpy(pointer, h, (size_t)n * 4);
 }
 
-extern "C" void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParam *mv_cost_params, uint8_t *src, uint32_t src_stride, uint8_t *ref,
-                                            uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint32_t *best_cost,
-                                            int16_t *best_mvx, int16_t *best_mvy, int16_t search_position_start_x,
-                                            int16_t search_position_start_y, int16_t search_area_width, int16_t search_area_height,
-                                            int16_t search_step, int16_t mvx, int16_t mvy) {
+static void svt_pme_sad_loop_kernel_hip_impl(const SvtHipMvCostParam *mv_cost_params, uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint32_t *best_cost, int16_t *best_mvx, int16_t *best_mvy, int16_t search_position_start_x, int16_t search_position_start_y, int16_t search_area_width, int16_t search_area_height, int16_t search_step, int16_t mvx, int16_t mvy);
+extern "C" void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParam *mv_cost_params, uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint32_t *best_cost, int16_t *best_mvx, int16_t *best_mvy, int16_t search_position_start_x, int16_t search_position_start_y, int16_t search_area_width, int16_t search_area_height, int16_t search_step, int16_t mvx, int16_t mvy) { TIER_A_CALL(svt_pme_sad_loop_kernel, svt_pme_sad_loop_kernel_hip_impl(mv_cost_params, src, src_stride, ref, ref_stride, block_height, block_width, best_cost, best_mvx, best_mvy, search_position_start_x, search_position_start_y, search_area_width, search_area_height, search_step, mvx, mvy), (mv_cost_params, src, src_stride, ref, ref_stride, block_height, block_width, best_cost, best_mvx, best_mvy, search_position_start_x, search_position_start_y, search_area_width, search_area_height, search_step, mvx, mvy)); }
+static void svt_pme_sad_loop_kernel_hip_impl(const SvtHipMvCostParam *mv_cost_params, uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint32_t *best_cost, int16_t *best_mvx, int16_t *best_mvy, int16_t search_position_start_x, int16_t search_position_start_y, int16_t search_area_width, int16_t search_area_height, int16_t search_step, int16_t mvx, int16_t mvy) {
     if (search_step <= 0) {
         set_error("svt_pme_sad_loop_kernel: search_step %d would never terminate", (int)search_step);
         fatal("svt_pme_sad_loop_kernel");

@@ -287,8 +287,7 @@ extern "C" int32_t svt_hip_analysis_frames(const SvtHipAnalysisJob *jobs, uint32
 // ------------------------------------------------------------------------------------------------
 static void fatal_if(bool bad, const char *what) {
     if (bad) {
-        fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-        abort();
+        svthip::tier_a_throw("%s: %s", what, svt_hip_last_error());
     }
 }
 
@@ -306,9 +305,9 @@ __global__ __launch_bounds__(256) static void downsample_plain_kernel(const uint
     out[(size_t)oy * out_stride + ox] = (uint8_t)((s + 2) >> 2);
 }
 
-extern "C" void svt_aom_downsample_2d_hip(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width,
-                                          uint32_t input_area_height, uint8_t *decim_samples, uint32_t decim_stride,
-                                          uint32_t decim_step) {
+static void svt_aom_downsample_2d_hip_impl(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height, uint8_t *decim_samples, uint32_t decim_stride, uint32_t decim_step);
+extern "C" void svt_aom_downsample_2d_hip(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height, uint8_t *decim_samples, uint32_t decim_stride, uint32_t decim_step) { TIER_A_CALL(svt_aom_downsample_2d, svt_aom_downsample_2d_hip_impl(input_samples, input_stride, input_area_width, input_area_height, decim_samples, decim_stride, decim_step), (input_samples, input_stride, input_area_width, input_area_height, decim_samples, decim_stride, decim_step)); }
+static void svt_aom_downsample_2d_hip_impl(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height, uint8_t *decim_samples, uint32_t decim_stride, uint32_t decim_step) {
     const uint32_t half = decim_step >> 1;
     if (decim_step == 0 || input_area_width <= half || input_area_height <= half)
         return;
@@ -366,8 +365,9 @@ static void block_stats_host(const uint8_t *in, uint32_t stride, uint32_t n8, ui
     memcpy(res, h + off, 8 * n8);
 }
 
-extern "C" void svt_compute_interm_var_four8x8_hip(uint8_t *input_samples, uint16_t input_stride,
-                                                   uint64_t *mean_of8x8_blocks, uint64_t *mean_of_squared8x8_blocks) {
+static void svt_compute_interm_var_four8x8_hip_impl(uint8_t *input_samples, uint16_t input_stride, uint64_t *mean_of8x8_blocks, uint64_t *mean_of_squared8x8_blocks);
+extern "C" void svt_compute_interm_var_four8x8_hip(uint8_t *input_samples, uint16_t input_stride, uint64_t *mean_of8x8_blocks, uint64_t *mean_of_squared8x8_blocks) { TIER_A_CALL(svt_compute_interm_var_four8x8, svt_compute_interm_var_four8x8_hip_impl(input_samples, input_stride, mean_of8x8_blocks, mean_of_squared8x8_blocks), (input_samples, input_stride, mean_of8x8_blocks, mean_of_squared8x8_blocks)); }
+static void svt_compute_interm_var_four8x8_hip_impl(uint8_t *input_samples, uint16_t input_stride, uint64_t *mean_of8x8_blocks, uint64_t *mean_of_squared8x8_blocks) {
     uint32_t r[8];
     block_stats_host(input_samples, input_stride, 4, 8, 8, 2, r);
     for (int k = 0; k < 4; k++) {
@@ -375,19 +375,23 @@ extern "C" void svt_compute_interm_var_four8x8_hip(uint8_t *input_samples, uint1
         mean_of_squared8x8_blocks[k] = (uint64_t)r[2 * k + 1] << 11;
     }
 }
-extern "C" uint64_t svt_compute_sub_mean_8x8_hip(uint8_t *input_samples, uint16_t input_stride) {
+static uint64_t svt_compute_sub_mean_8x8_hip_impl(uint8_t *input_samples, uint16_t input_stride);
+extern "C" uint64_t svt_compute_sub_mean_8x8_hip(uint8_t *input_samples, uint16_t input_stride) { TIER_A_CALL(svt_compute_sub_mean_8x8, svt_compute_sub_mean_8x8_hip_impl(input_samples, input_stride), (input_samples, input_stride)); }
+static uint64_t svt_compute_sub_mean_8x8_hip_impl(uint8_t *input_samples, uint16_t input_stride) {
     uint32_t r[2];
     block_stats_host(input_samples, input_stride, 1, 8, 8, 2, r);
     return (uint64_t)r[0] << 3;
 }
-extern "C" uint64_t svt_compute_mean_8x8_hip(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width,
-                                             uint32_t input_area_height) {
+static uint64_t svt_compute_mean_8x8_hip_impl(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height);
+extern "C" uint64_t svt_compute_mean_8x8_hip(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height) { TIER_A_CALL(svt_compute_mean_8x8, svt_compute_mean_8x8_hip_impl(input_samples, input_stride, input_area_width, input_area_height), (input_samples, input_stride, input_area_width, input_area_height)); }
+static uint64_t svt_compute_mean_8x8_hip_impl(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height) {
     uint32_t r[2];
     block_stats_host(input_samples, input_stride, 1, input_area_width, input_area_height, 1, r);
     return ((uint64_t)r[0] << 8) / (input_area_width * input_area_height);
 }
-extern "C" uint64_t svt_compute_mean_square_values_8x8_hip(uint8_t *input_samples, uint32_t input_stride,
-                                                           uint32_t input_area_width, uint32_t input_area_height) {
+static uint64_t svt_compute_mean_square_values_8x8_hip_impl(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height);
+extern "C" uint64_t svt_compute_mean_square_values_8x8_hip(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height) { TIER_A_CALL(svt_compute_mean_square_values_8x8, svt_compute_mean_square_values_8x8_hip_impl(input_samples, input_stride, input_area_width, input_area_height), (input_samples, input_stride, input_area_width, input_area_height)); }
+static uint64_t svt_compute_mean_square_values_8x8_hip_impl(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height) {
     uint32_t r[2];
     block_stats_host(input_samples, input_stride, 1, input_area_width, input_area_height, 1, r);
     return ((uint64_t)r[1] << 16) / (input_area_width * input_area_height);

@@ -11,7 +11,8 @@
 namespace svthip {
 
 static thread_local char tls_err[512] = "";
-static std::atomic<int>  g_device{-1};
+static std::atomic<int>  g_device{-1};   // the device every entry point works on; -1 until svt_hip_init succeeds
+static std::atomic<int>  g_sticky{-1};   // first device ever bound: per-thread streams / scratch / once-uploaded tables live there
 static std::mutex        g_mutex;
 
 void set_error(const char *fmt, ...) {
@@ -32,7 +33,10 @@ bool ensure_init() {
         }
         return true;
     }
-    return svt_hip_init(0) == SVT_HIP_OK;
+    // not initialised (or shut down): never pick a device silently — a rank that forgot svt_hip_init(local_rank) would
+    // otherwise run on GPU 0
+    set_error("library not initialised: call svt_hip_init(device_ordinal) first");
+    return false;
 }
 
 struct TlsStream {
@@ -48,9 +52,12 @@ hipStream_t resolve_stream(void *stream) {
         return (hipStream_t)stream;
     static thread_local TlsStream t;
     if (!t.s) {
+        // streams belong to the device that is current when they are created: bind this thread first
+        (void)ensure_init();
         if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) {
-            fprintf(stderr, "libsvtav1_hip fatal: cannot create a stream\n");
-            abort();
+            set_error("cannot create the calling thread's stream");
+            t.s = nullptr;
+            return nullptr;  // the legacy default stream: callers carry on, correct but serialised
         }
     }
     return t.s;
@@ -115,14 +122,81 @@ void stage_commit(hipStream_t st) {
     r.last = -1;
 }
 
+// ---- Tier A failure handling (common.hpp) ----
+namespace {
+struct SavedSlot {
+    char   name[96];
+    void **slot;
+    void  *cpu_fn;
+};
+std::mutex        g_slots_mutex;
+SavedSlot         g_slots[512];
+int               g_n_slots = 0;
+std::atomic<bool> g_tier_a_broken{false};
+std::atomic<int>  g_inject{-1};  // test hook: the n-th SVT_HIP_CHECK_FATAL from now fails (svt_hip_debug_inject_failure)
+}  // namespace
+
+[[noreturn]] void tier_a_throw(const char *fmt, ...) {
+    TierAError e;
+    va_list    ap;
+    va_start(ap, fmt);
+    vsnprintf(e.what, sizeof(e.what), fmt, ap);
+    va_end(ap);
+    throw e;
+}
+bool tier_a_broken() { return g_tier_a_broken.load(std::memory_order_relaxed); }
+void tier_a_fail(const char *leaf, const char *what) {
+    std::lock_guard<std::mutex> lk(g_slots_mutex);
+    if (g_tier_a_broken.exchange(true))
+        return;
+    int restored = 0;
+    for (int i = 0; i < g_n_slots; i++)
+        if (g_slots[i].slot && g_slots[i].cpu_fn)
+            *g_slots[i].slot = g_slots[i].cpu_fn, restored++;
+    fprintf(stderr, "libsvtav1_hip: %s: %s -- HIP hot path disabled, %d RTCD pointers restored to the CPU kernels\n", leaf, what,
+            restored);
+}
+void *tier_a_cpu(const char *leaf) {
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mutex);
+        for (int i = 0; i < g_n_slots; i++)
+            if (strcmp(g_slots[i].name, leaf) == 0 && g_slots[i].cpu_fn)
+                return g_slots[i].cpu_fn;
+    }
+    fprintf(stderr, "libsvtav1_hip fatal: %s_hip failed and no CPU function was saved for it (svt_hip_install_rtcd was not used): %s\n",
+            leaf, svt_hip_last_error());
+    abort();
+}
+static void remember_slot(const char *stem, void **slot, void *cpu_fn) {
+    std::lock_guard<std::mutex> lk(g_slots_mutex);
+    for (int i = 0; i < g_n_slots; i++)
+        if (strcmp(g_slots[i].name, stem) == 0) {
+            g_slots[i].slot = slot, g_slots[i].cpu_fn = cpu_fn;
+            return;
+        }
+    if (g_n_slots < (int)(sizeof(g_slots) / sizeof(g_slots[0]))) {
+        snprintf(g_slots[g_n_slots].name, sizeof(g_slots[g_n_slots].name), "%s", stem);
+        g_slots[g_n_slots].slot = slot, g_slots[g_n_slots].cpu_fn = cpu_fn;
+        g_n_slots++;
+    }
+}
+bool tier_a_inject_now() {
+    int v = g_inject.load();
+    while (v >= 0) {
+        if (g_inject.compare_exchange_weak(v, v - 1))
+            return v == 0;
+    }
+    return false;
+}
+
 uint8_t *Scratch::device(size_t bytes) {
     if (bytes > dev_cap) {
         if (dev)
             (void)hipFree(dev);
         size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
-        if (hipMalloc((void **)&dev, cap + 256) != hipSuccess) {
-            fprintf(stderr, "libsvtav1_hip fatal: hipMalloc(%zu) failed\n", cap);
-            abort();
+        if (tier_a_inject_now() || hipMalloc((void **)&dev, cap + 256) != hipSuccess) {
+            dev = nullptr, dev_cap = 0;
+            tier_a_throw("hipMalloc(%zu) for the Tier A scratch buffer failed", cap);
         }
         dev_cap = cap;
     }
@@ -134,8 +208,8 @@ uint8_t *Scratch::host(size_t bytes) {
             (void)hipHostFree(pinned);
         size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
         if (hipHostMalloc((void **)&pinned, cap + 256, hipHostMallocDefault) != hipSuccess) {
-            fprintf(stderr, "libsvtav1_hip fatal: hipHostMalloc(%zu) failed\n", cap);
-            abort();
+            pinned = nullptr, pinned_cap = 0;
+            tier_a_throw("hipHostMalloc(%zu) for the Tier A scratch buffer failed", cap);
         }
         pinned_cap = cap;
     }
@@ -170,6 +244,12 @@ int32_t svt_hip_init(int32_t device_ordinal) {
         set_error("device ordinal %d out of range (%d devices)", device_ordinal, n);
         return SVT_HIP_ERR_BAD_PARAMETER;
     }
+    if (g_sticky.load() >= 0 && g_sticky.load() != device_ordinal) {
+        // per-thread streams, scratch buffers and the once-uploaded constant tables stay on the first device: one process
+        // = one GPU (the multi-GPU layout is one process per GPU)
+        set_error("already bound to device %d: one process drives one GPU", g_sticky.load());
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
     SVT_HIP_CHECK(hipSetDevice(device_ordinal));
     hipDeviceProp_t prop;
     SVT_HIP_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
@@ -179,6 +259,7 @@ int32_t svt_hip_init(int32_t device_ordinal) {
         return SVT_HIP_ERR_NO_DEVICE;
     }
     g_device.store(device_ordinal);
+    g_sticky.store(device_ordinal);
     return SVT_HIP_OK;
 }
 
@@ -195,7 +276,8 @@ int32_t svt_hip_malloc(void **dptr, size_t bytes) {
         return SVT_HIP_ERR_BAD_PARAMETER;
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
-    // +256 B of slack: the window stagers read whole aligned dwords around unaligned rows.
+    // +256 B beyond what was asked for: a defensive margin, not part of any contract (the documented contracts — e.g. the
+    // plane contract of include/svt_hip_me.h — hold for caller-allocated memory of the exact size)
     SVT_HIP_CHECK(hipMalloc(dptr, bytes + 256));
     return SVT_HIP_OK;
 }
@@ -204,19 +286,27 @@ int32_t svt_hip_free(void *dptr) {
     return SVT_HIP_OK;
 }
 int32_t svt_hip_memset(void *dptr, int value, size_t bytes, void *stream) {
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
     SVT_HIP_CHECK(hipMemsetAsync(dptr, value, bytes, resolve_stream(stream)));
     return SVT_HIP_OK;
 }
 int32_t svt_hip_upload(void *dptr, const void *hptr, size_t bytes, void *stream) {
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
     SVT_HIP_CHECK(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, resolve_stream(stream)));
     return SVT_HIP_OK;
 }
 int32_t svt_hip_download(void *hptr, const void *dptr, size_t bytes, void *stream) {
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
     SVT_HIP_CHECK(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, resolve_stream(stream)));
     return SVT_HIP_OK;
 }
 int32_t svt_hip_upload_2d(void *dptr, size_t dpitch, const void *hptr, size_t hpitch, size_t width_bytes,
                           size_t height, void *stream) {
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
     SVT_HIP_CHECK(hipMemcpy2DAsync(dptr, dpitch, hptr, hpitch, width_bytes, height, hipMemcpyHostToDevice,
                                    resolve_stream(stream)));
     return SVT_HIP_OK;
@@ -236,6 +326,8 @@ int32_t svt_hip_stream_destroy(void *stream) {
     return SVT_HIP_OK;
 }
 int32_t svt_hip_stream_sync(void *stream) {
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
     SVT_HIP_CHECK(hipStreamSynchronize(resolve_stream(stream)));
     return SVT_HIP_OK;
 }
@@ -267,6 +359,16 @@ extern "C" void *svt_hip_rtcd_lookup(const char *name) {
     return dlsym(self, sym);
 }
 
+// Test hook: the n-th Tier A device check from now on reports a failure (n = 0: the next one; n < 0: off); and a way to
+// clear the latch again between tests.  Not declared in the public headers.
+extern "C" __attribute__((visibility("default"))) void svt_hip_debug_inject_failure(int32_t n) { svthip::g_inject.store(n); }
+extern "C" __attribute__((visibility("default"))) int32_t svt_hip_debug_tier_a_broken(int32_t reset) {
+    const int32_t was = svthip::g_tier_a_broken.load() ? 1 : 0;
+    if (reset)
+        svthip::g_tier_a_broken.store(false);
+    return was;
+}
+
 extern "C" int32_t svt_hip_install_rtcd(const SvtHipRtcdBinding *b, uint32_t n, uint32_t *n_installed) {
     if (n_installed)
         *n_installed = 0;
@@ -276,11 +378,21 @@ extern "C" int32_t svt_hip_install_rtcd(const SvtHipRtcdBinding *b, uint32_t n, 
     }
     if (!svthip::ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;  // nothing installed: the caller keeps its CPU pointers
+    if (svthip::tier_a_broken()) {
+        svthip::set_error("svt_hip_install_rtcd: the HIP path was disabled after a device failure");
+        return SVT_HIP_ERR_RUNTIME;
+    }
     uint32_t done = 0;
     for (uint32_t i = 0; i < n; i++) {
         void *fn = b[i].slot ? svt_hip_rtcd_lookup(b[i].name) : nullptr;
-        if (fn)
+        if (fn) {
+            // the export's stem is what TIER_A_CALL looks the CPU function up by (two pointers have no svt_ prefix)
+            const char *stem = strcmp(b[i].name, "downsample_2d") == 0 ? "svt_aom_downsample_2d"
+                : (strcmp(b[i].name, "sad_16b_kernel") == 0 ? "svt_aom_sad_16b_kernel" : b[i].name);
+            if (*b[i].slot != fn)
+                svthip::remember_slot(stem, b[i].slot, *b[i].slot);
             *b[i].slot = fn, done++;
+        }
     }
     if (n_installed)
         *n_installed = done;

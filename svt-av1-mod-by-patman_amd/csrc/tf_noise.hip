@@ -92,12 +92,10 @@ int32_t launch(const void *d_src, uint32_t width, uint32_t height, uint32_t stri
 int32_t tier_a(const void *src, int width, int height, int stride, int is16, int bd, const char *what) {
     if (width < 1 || height < 1 || stride < width || (is16 && (bd < 8 || bd > 16))) {
         set_error("%s: bad plane geometry %dx%d stride %d depth %d", what, width, height, stride, bd);
-        fprintf(stderr, "libsvtav1_hip fatal: %s\n", svt_hip_last_error());
-        abort();
+        svthip::tier_a_throw("%s", svt_hip_last_error());
     }
     if (!ensure_init()) {
-        fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-        abort();
+        svthip::tier_a_throw("%s: %s", what, svt_hip_last_error());
     }
     const size_t px = is16 ? 2 : 1, span = ((size_t)(height - 1) * stride + width) * px, off_out = (span + 255) / 256 * 256;
     Scratch     &sc = tls_scratch();
@@ -106,8 +104,7 @@ int32_t tier_a(const void *src, int width, int height, int stride, int is16, int
     hipStream_t st = resolve_stream(nullptr);
     SVT_HIP_CHECK_FATAL(hipMemcpyAsync(d, h, span, hipMemcpyHostToDevice, st));
     if (launch(d, (uint32_t)width, (uint32_t)height, (uint32_t)stride, is16, bd, (SvtHipTfNoise *)(d + off_out), st) != SVT_HIP_OK) {
-        fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-        abort();
+        svthip::tier_a_throw("%s: %s", what, svt_hip_last_error());
     }
     SVT_HIP_CHECK_FATAL(hipMemcpyAsync(h + off_out, d + off_out, sizeof(SvtHipTfNoise), hipMemcpyDeviceToHost, st));
     SVT_HIP_CHECK_FATAL(hipStreamSynchronize(st));
@@ -127,9 +124,13 @@ extern "C" int32_t svt_hip_tf_estimate_noise(const void *d_src, uint32_t width, 
     return launch(d_src, width, height, stride, is_16bit, bit_depth, d_out, resolve_stream(stream));
 }
 
-extern "C" int32_t svt_estimate_noise_fp16_hip(const uint8_t *src, uint16_t width, uint16_t height, uint16_t stride_y) {
+static int32_t svt_estimate_noise_fp16_hip_impl(const uint8_t *src, uint16_t width, uint16_t height, uint16_t stride_y);
+extern "C" int32_t svt_estimate_noise_fp16_hip(const uint8_t *src, uint16_t width, uint16_t height, uint16_t stride_y) { TIER_A_CALL(svt_estimate_noise_fp16, svt_estimate_noise_fp16_hip_impl(src, width, height, stride_y), (src, width, height, stride_y)); }
+static int32_t svt_estimate_noise_fp16_hip_impl(const uint8_t *src, uint16_t width, uint16_t height, uint16_t stride_y) {
     return tier_a(src, width, height, stride_y, 0, 8, "svt_estimate_noise_fp16");
 }
-extern "C" int32_t svt_estimate_noise_highbd_fp16_hip(const uint16_t *src, int width, int height, int stride, int bd) {
+static int32_t svt_estimate_noise_highbd_fp16_hip_impl(const uint16_t *src, int width, int height, int stride, int bd);
+extern "C" int32_t svt_estimate_noise_highbd_fp16_hip(const uint16_t *src, int width, int height, int stride, int bd) { TIER_A_CALL(svt_estimate_noise_highbd_fp16, svt_estimate_noise_highbd_fp16_hip_impl(src, width, height, stride, bd), (src, width, height, stride, bd)); }
+static int32_t svt_estimate_noise_highbd_fp16_hip_impl(const uint16_t *src, int width, int height, int stride, int bd) {
     return tier_a(src, width, height, stride, 1, bd, "svt_estimate_noise_highbd_fp16");
 }

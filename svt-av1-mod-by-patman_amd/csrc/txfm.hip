@@ -653,10 +653,7 @@ extern "C" int32_t svt_hip_quantize_batch(uint8_t *d_base, const SvtHipTxfmDesc 
 // ------------------------------------------------------------------------------------------------ Tier A
 namespace {
 
-void fatal(const char *what) {
-    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-    abort();
-}
+[[noreturn]] void fatal(const char *what) { svthip::tier_a_throw("%s: %s", what, svt_hip_last_error()); }
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 // One-block arena in the per-thread scratch: [desc][result][buffers...]
@@ -787,40 +784,42 @@ uint64_t handle_tier_a(int w, int h, int energy_on, int32_t *output) {
 }  // namespace
 
 #define FWD_DEF(W, H)                                                                                                          \
-    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { fwd_tier_a(W, H, 0, i, o, s, t, b); } \
-    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { fwd_tier_a(W, H, 1, i, o, s, t, b); } \
-    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { fwd_tier_a(W, H, 2, i, o, s, t, b); }
+    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { TIER_A_CALL(svt_av1_fwd_txfm2d_##W##x##H, fwd_tier_a(W, H, 0, i, o, s, t, b), (i, o, s, t, b)); } \
+    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { TIER_A_CALL(svt_av1_fwd_txfm2d_##W##x##H##_N2, fwd_tier_a(W, H, 1, i, o, s, t, b), (i, o, s, t, b)); } \
+    extern "C" void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *i, int32_t *o, uint32_t s, int32_t t, uint8_t b) { TIER_A_CALL(svt_av1_fwd_txfm2d_##W##x##H##_N4, fwd_tier_a(W, H, 2, i, o, s, t, b), (i, o, s, t, b)); }
 FWD_DEF(4, 4) FWD_DEF(8, 8) FWD_DEF(16, 16) FWD_DEF(32, 32) FWD_DEF(64, 64) FWD_DEF(4, 8) FWD_DEF(8, 4) FWD_DEF(8, 16) FWD_DEF(16, 8)
 FWD_DEF(16, 32) FWD_DEF(32, 16) FWD_DEF(32, 64) FWD_DEF(64, 32) FWD_DEF(4, 16) FWD_DEF(16, 4) FWD_DEF(8, 32) FWD_DEF(32, 8)
 FWD_DEF(16, 64) FWD_DEF(64, 16)
 
 #define INV_SQ(W, H)                                                                                                         \
     extern "C" void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *i, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, \
-                                                           int32_t t, int32_t bd) { inv_tier_a(W, H, i, r, sr, w, sw, t, bd); }
+                                                           int32_t t, int32_t bd) { TIER_A_CALL(svt_av1_inv_txfm2d_add_##W##x##H, inv_tier_a(W, H, i, r, sr, w, sw, t, bd), (i, r, sr, w, sw, t, bd)); }
 #define INV_TS(W, H)                                                                                                         \
     extern "C" void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *i, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, \
-                                                           int32_t t, int32_t, int32_t bd) { inv_tier_a(W, H, i, r, sr, w, sw, t, bd); }
+                                                           int32_t t, int32_t txs, int32_t bd) { TIER_A_CALL(svt_av1_inv_txfm2d_add_##W##x##H, inv_tier_a(W, H, i, r, sr, w, sw, t, bd), (i, r, sr, w, sw, t, txs, bd)); }
 #define INV_EOB(W, H)                                                                                                        \
     extern "C" void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *i, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, \
-                                                           int32_t t, int32_t, int32_t, int32_t bd) { inv_tier_a(W, H, i, r, sr, w, sw, t, bd); }
+                                                           int32_t t, int32_t txs, int32_t eob, int32_t bd) { TIER_A_CALL(svt_av1_inv_txfm2d_add_##W##x##H, inv_tier_a(W, H, i, r, sr, w, sw, t, bd), (i, r, sr, w, sw, t, txs, eob, bd)); }
 INV_SQ(4, 4) INV_SQ(8, 8) INV_SQ(16, 16) INV_SQ(32, 32) INV_SQ(64, 64) INV_TS(4, 8) INV_TS(8, 4) INV_TS(4, 16) INV_TS(16, 4)
 INV_EOB(8, 16) INV_EOB(16, 8) INV_EOB(16, 32) INV_EOB(32, 16) INV_EOB(32, 64) INV_EOB(64, 32) INV_EOB(8, 32) INV_EOB(32, 8)
 INV_EOB(16, 64) INV_EOB(64, 16)
 
 #define HANDLE_DEF(W, H)                                                                                                  \
-    extern "C" uint64_t svt_handle_transform##W##x##H##_hip(int32_t *o) { return handle_tier_a(W, H, 1, o); }             \
-    extern "C" uint64_t svt_handle_transform##W##x##H##_N2_N4_hip(int32_t *o) { return handle_tier_a(W, H, 0, o); }
+    extern "C" uint64_t svt_handle_transform##W##x##H##_hip(int32_t *o) { TIER_A_CALL(svt_handle_transform##W##x##H, handle_tier_a(W, H, 1, o), (o)); }             \
+    extern "C" uint64_t svt_handle_transform##W##x##H##_N2_N4_hip(int32_t *o) { TIER_A_CALL(svt_handle_transform##W##x##H##_N2_N4, handle_tier_a(W, H, 0, o), (o)); }
 HANDLE_DEF(16, 64) HANDLE_DEF(32, 64) HANDLE_DEF(64, 16) HANDLE_DEF(64, 32) HANDLE_DEF(64, 64)
 
 #define QA SVT_HIP_QARGS
 #define QP_ coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan
+#define QC_ coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, scan, iscan  /* the reference's full argument list */
 // svt_av1_inv_txfm_add (common_dsp_rtcd.h:150; inv_transforms.c:3177-3193): the 8-bit destination form, dispatched on
 // txfm_param->tx_size like highbd_inv_txfm_add (:3112-3146).  The reference widens the prediction to 16 bits, transforms at
 // txfm_param->bd and narrows; with bd == 8 (the only value its callers pass, :3101,3163) that equals the 8-bit pixel path of
 // the kernel.  Lossless (the 4x4 Walsh-Hadamard form) is never requested by this reference version (full_loop.c:1703,1715
 // and src_ops_process.c:1157 pass 0) and is refused loudly.
-extern "C" void svt_av1_inv_txfm_add_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w,
-                                         const SvtHipTxfmParam *txfm_param) {
+static void svt_av1_inv_txfm_add_hip_impl(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, const SvtHipTxfmParam *txfm_param);
+extern "C" void svt_av1_inv_txfm_add_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, const SvtHipTxfmParam *txfm_param) { TIER_A_CALL(svt_av1_inv_txfm_add, svt_av1_inv_txfm_add_hip_impl(dqcoeff, dst_r, stride_r, dst_w, stride_w, txfm_param), (dqcoeff, dst_r, stride_r, dst_w, stride_w, txfm_param)); }
+static void svt_av1_inv_txfm_add_hip_impl(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, const SvtHipTxfmParam *txfm_param) {
     static const uint8_t wide[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
     static const uint8_t high[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
     if (!txfm_param || txfm_param->tx_size >= 19 || txfm_param->lossless || txfm_param->bd != 8) {
@@ -832,13 +831,13 @@ extern "C" void svt_av1_inv_txfm_add_hip(const int32_t *dqcoeff, uint8_t *dst_r,
                         txfm_param->tx_type, 8);
 }
 
-extern "C" void svt_aom_quantize_b_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B, QP_, qm, iqm, ls); }
-extern "C" void svt_av1_quantize_b_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B, QP_, qm, iqm, ls); }
-extern "C" void svt_aom_highbd_quantize_b_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B_HBD, QP_, qm, iqm, ls); }
-extern "C" void svt_av1_highbd_quantize_b_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_B_HBD, QP_, qm, iqm, ls); }
-extern "C" void svt_av1_quantize_fp_hip(QA) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 0); }
-extern "C" void svt_av1_quantize_fp_32x32_hip(QA) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 1); }
-extern "C" void svt_av1_quantize_fp_64x64_hip(QA) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 2); }
-extern "C" void svt_av1_quantize_fp_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int16_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP, QP_, qm, iqm, ls); }
-extern "C" void svt_av1_highbd_quantize_fp_hip(QA, int16_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP_HBD, QP_, nullptr, nullptr, ls); }
-extern "C" void svt_av1_highbd_quantize_fp_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int16_t ls) { (void)scan; quant_tier_a(SVT_HIP_QUANT_FP_HBD, QP_, qm, iqm, ls); }
+extern "C" void svt_aom_quantize_b_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { TIER_A_CALL(svt_aom_quantize_b, quant_tier_a(SVT_HIP_QUANT_B, QP_, qm, iqm, ls), (QC_, qm, iqm, ls)); }
+extern "C" void svt_av1_quantize_b_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { TIER_A_CALL(svt_av1_quantize_b_qm, quant_tier_a(SVT_HIP_QUANT_B, QP_, qm, iqm, ls), (QC_, qm, iqm, ls)); }
+extern "C" void svt_aom_highbd_quantize_b_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { TIER_A_CALL(svt_aom_highbd_quantize_b, quant_tier_a(SVT_HIP_QUANT_B_HBD, QP_, qm, iqm, ls), (QC_, qm, iqm, ls)); }
+extern "C" void svt_av1_highbd_quantize_b_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int32_t ls) { TIER_A_CALL(svt_av1_highbd_quantize_b_qm, quant_tier_a(SVT_HIP_QUANT_B_HBD, QP_, qm, iqm, ls), (QC_, qm, iqm, ls)); }
+extern "C" void svt_av1_quantize_fp_hip(QA) { TIER_A_CALL(svt_av1_quantize_fp, quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 0), (QC_)); }
+extern "C" void svt_av1_quantize_fp_32x32_hip(QA) { TIER_A_CALL(svt_av1_quantize_fp_32x32, quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 1), (QC_)); }
+extern "C" void svt_av1_quantize_fp_64x64_hip(QA) { TIER_A_CALL(svt_av1_quantize_fp_64x64, quant_tier_a(SVT_HIP_QUANT_FP, QP_, nullptr, nullptr, 2), (QC_)); }
+extern "C" void svt_av1_quantize_fp_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int16_t ls) { TIER_A_CALL(svt_av1_quantize_fp_qm, quant_tier_a(SVT_HIP_QUANT_FP, QP_, qm, iqm, ls), (QC_, qm, iqm, ls)); }
+extern "C" void svt_av1_highbd_quantize_fp_hip(QA, int16_t ls) { TIER_A_CALL(svt_av1_highbd_quantize_fp, quant_tier_a(SVT_HIP_QUANT_FP_HBD, QP_, nullptr, nullptr, ls), (QC_, ls)); }
+extern "C" void svt_av1_highbd_quantize_fp_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int16_t ls) { TIER_A_CALL(svt_av1_highbd_quantize_fp_qm, quant_tier_a(SVT_HIP_QUANT_FP_HBD, QP_, qm, iqm, ls), (QC_, qm, iqm, ls)); }

@@ -89,10 +89,7 @@ __global__ __launch_bounds__(256) void distortion_batch_kernel(const uint8_t *__
         results[tb][0] = a, results[tb][1] = b;
 }
 
-void fatal(const char *what) {
-    fprintf(stderr, "libsvtav1_hip fatal: %s: %s\n", what, svt_hip_last_error());
-    abort();
-}
+[[noreturn]] void fatal(const char *what) { svthip::tier_a_throw("%s: %s", what, svt_hip_last_error()); }
 // sum (a - b)^2 over a w x h area of pixels (svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits)
 template <class PIX>
 __global__ __launch_bounds__(256) void spatial_sse_kernel(const PIX *__restrict__ a, int as, const PIX *__restrict__ b, int bs, int w, int h,
@@ -164,41 +161,47 @@ void subtract_tier_a(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, c
 
 }  // namespace
 
-extern "C" void svt_aom_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr,
-                                           ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride) {
+static void svt_aom_subtract_block_hip_impl(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride);
+extern "C" void svt_aom_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride) { TIER_A_CALL(svt_aom_subtract_block, svt_aom_subtract_block_hip_impl(rows, cols, diff_ptr, diff_stride, src_ptr, src_stride, pred_ptr, pred_stride), (rows, cols, diff_ptr, diff_stride, src_ptr, src_stride, pred_ptr, pred_stride)); }
+static void svt_aom_subtract_block_hip_impl(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride) {
     subtract_tier_a<uint8_t>(rows, cols, diff_ptr, diff_stride, src_ptr, src_stride, pred_ptr, pred_stride);
 }
-extern "C" void svt_aom_highbd_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr,
-                                                  ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride, int bd) {
+static void svt_aom_highbd_subtract_block_hip_impl(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride, int bd);
+extern "C" void svt_aom_highbd_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride, int bd) { TIER_A_CALL(svt_aom_highbd_subtract_block, svt_aom_highbd_subtract_block_hip_impl(rows, cols, diff_ptr, diff_stride, src_ptr, src_stride, pred_ptr, pred_stride, bd), (rows, cols, diff_ptr, diff_stride, src_ptr, src_stride, pred_ptr, pred_stride, bd)); }
+static void svt_aom_highbd_subtract_block_hip_impl(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride, int bd) {
     (void)bd;
     subtract_tier_a<uint16_t>(rows, cols, diff_ptr, diff_stride, (const uint16_t *)src_ptr, src_stride, (const uint16_t *)pred_ptr,
                               pred_stride);
 }
 // svt_residual_kernel8bit / 16bit (common_dsp_rtcd.h:163,174; pic_operators.c:101-143): the same difference with the
 // operands in another order
-extern "C" void svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual,
-                                            uint32_t residual_stride, uint32_t area_width, uint32_t area_height) {
+static void svt_residual_kernel8bit_hip_impl(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height);
+extern "C" void svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height) { TIER_A_CALL(svt_residual_kernel8bit, svt_residual_kernel8bit_hip_impl(input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height), (input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height)); }
+static void svt_residual_kernel8bit_hip_impl(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height) {
     subtract_tier_a<uint8_t>((int)area_height, (int)area_width, residual, residual_stride, input, input_stride, pred, pred_stride);
 }
-extern "C" void svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual,
-                                             uint32_t residual_stride, uint32_t area_width, uint32_t area_height) {
+static void svt_residual_kernel16bit_hip_impl(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height);
+extern "C" void svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height) { TIER_A_CALL(svt_residual_kernel16bit, svt_residual_kernel16bit_hip_impl(input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height), (input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height)); }
+static void svt_residual_kernel16bit_hip_impl(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height) {
     subtract_tier_a<uint16_t>((int)area_height, (int)area_width, residual, residual_stride, input, input_stride, pred, pred_stride);
 }
 // svt_spatial_full_distortion_kernel (common_dsp_rtcd.h:171; picture_operators_c.c:62-78) and svt_full_distortion_kernel16_bits
 // (common_dsp_rtcd.h:173; pic_operators.c:174-196: byte pointers reinterpreted as 16-bit samples, offsets in samples)
-extern "C" uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon,
-                                                           int32_t recon_offset, uint32_t recon_stride, uint32_t area_width,
-                                                           uint32_t area_height) {
+static uint64_t svt_spatial_full_distortion_kernel_hip_impl(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset, uint32_t recon_stride, uint32_t area_width, uint32_t area_height);
+extern "C" uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset, uint32_t recon_stride, uint32_t area_width, uint32_t area_height) { TIER_A_CALL(svt_spatial_full_distortion_kernel, svt_spatial_full_distortion_kernel_hip_impl(input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height), (input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height)); }
+static uint64_t svt_spatial_full_distortion_kernel_hip_impl(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset, uint32_t recon_stride, uint32_t area_width, uint32_t area_height) {
     return spatial_sse_tier_a<uint8_t>(input + input_offset, input_stride, recon + recon_offset, recon_stride, area_width, area_height,
                                        "svt_spatial_full_distortion_kernel");
 }
-extern "C" uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *pred,
-                                                          int32_t pred_offset, uint32_t pred_stride, uint32_t area_width,
-                                                          uint32_t area_height) {
+static uint64_t svt_full_distortion_kernel16_bits_hip_impl(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *pred, int32_t pred_offset, uint32_t pred_stride, uint32_t area_width, uint32_t area_height);
+extern "C" uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *pred, int32_t pred_offset, uint32_t pred_stride, uint32_t area_width, uint32_t area_height) { TIER_A_CALL(svt_full_distortion_kernel16_bits, svt_full_distortion_kernel16_bits_hip_impl(input, input_offset, input_stride, pred, pred_offset, pred_stride, area_width, area_height), (input, input_offset, input_stride, pred, pred_offset, pred_stride, area_width, area_height)); }
+static uint64_t svt_full_distortion_kernel16_bits_hip_impl(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *pred, int32_t pred_offset, uint32_t pred_stride, uint32_t area_width, uint32_t area_height) {
     return spatial_sse_tier_a<uint16_t>((const uint16_t *)input + input_offset, input_stride, (const uint16_t *)pred + pred_offset,
                                         pred_stride, area_width, area_height, "svt_full_distortion_kernel16_bits");
 }
-extern "C" int svt_aom_satd_hip(const int32_t *coeff, int length) {
+static int svt_aom_satd_hip_impl(const int32_t *coeff, int length);
+extern "C" int svt_aom_satd_hip(const int32_t *coeff, int length) { TIER_A_CALL(svt_aom_satd, svt_aom_satd_hip_impl(coeff, length), (coeff, length)); }
+static int svt_aom_satd_hip_impl(const int32_t *coeff, int length) {
     if (length <= 0)
         return 0;
     if (!ensure_init())
@@ -242,12 +245,14 @@ void distortion_tier_a(const int32_t *coeff, uint32_t cs, const int32_t *recon, 
 }
 }  // namespace
 
-extern "C" void svt_full_distortion_kernel32_bits_hip(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride,
-                                                      uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) {
+static void svt_full_distortion_kernel32_bits_hip_impl(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height);
+extern "C" void svt_full_distortion_kernel32_bits_hip(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) { TIER_A_CALL(svt_full_distortion_kernel32_bits, svt_full_distortion_kernel32_bits_hip_impl(coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height), (coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height)); }
+static void svt_full_distortion_kernel32_bits_hip_impl(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) {
     distortion_tier_a(coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height);
 }
-extern "C" void svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2],
-                                                               uint32_t area_width, uint32_t area_height) {
+static void svt_full_distortion_kernel_cbf_zero32_bits_hip_impl(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height);
+extern "C" void svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) { TIER_A_CALL(svt_full_distortion_kernel_cbf_zero32_bits, svt_full_distortion_kernel_cbf_zero32_bits_hip_impl(coeff, coeff_stride, distortion_result, area_width, area_height), (coeff, coeff_stride, distortion_result, area_width, area_height)); }
+static void svt_full_distortion_kernel_cbf_zero32_bits_hip_impl(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) {
     distortion_tier_a(coeff, coeff_stride, nullptr, 0, distortion_result, area_width, area_height);
 }
 

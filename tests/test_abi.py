@@ -59,3 +59,26 @@ def test_no_device_error_path():
         return
     assert lib.svt_hip_init(0) != 0
     assert b"no HIP device" in lib.svt_hip_last_error()
+
+
+def test_no_stream_ordered_allocator_on_the_launch_paths():
+    """The library neither allocates nor frees device memory stream-ordered (hipMallocAsync / hipFreeAsync): the round-1
+    abort was confined to the one call path that did; descriptors travel through the event-guarded
+    per-thread staging ring of runtime.cpp instead."""
+    import subprocess
+    so = os.path.join(abi.REPO_ROOT, "svt-av1-mod-by-patman_amd", "csrc", "libsvtav1_hip.so")
+    und = subprocess.run(["nm", "-D", "--undefined-only", so], check=True, capture_output=True, text=True).stdout
+    for sym in ("hipMallocAsync", "hipFreeAsync", "hipMallocFromPoolAsync"):
+        assert sym not in und, sym
+
+
+def test_uninitialised_library_refuses_to_pick_a_device():
+    """No silent fall-back to GPU 0 for a process that forgot svt_hip_init: without a successful init every entry
+    point that needs the device reports SVT_HIP_ERR_NO_DEVICE."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from svtav1_hip import abi; import ctypes as C; lib = abi.load(); p = C.c_void_p();"
+            "rc = lib.svt_hip_malloc(C.byref(p), C.c_size_t(64)); print(rc, lib.svt_hip_last_error().decode())") % os.path.join(abi.REPO_ROOT, "svt-av1-mod-by-patman_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
+    rc, msg = r.stdout.strip().split(" ", 1)
+    assert int(rc) == abi.SVT_HIP_ERR_NO_DEVICE and "not initialised" in msg

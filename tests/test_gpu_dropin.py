@@ -216,3 +216,33 @@ def test_tpl_block_cost_with_hip_leaves(dropin, ref):
         got.append([TR.ref_tpl_cost(ref, *c) for c in TR.tpl_cases()])
     dropin.restore()
     assert len(got[0]) == 54 and got[0] == got[1]
+
+
+def test_device_failure_restores_cpu_kernels(dropin, ref, hip):
+    """SURVEY 8b "never abort": a HIP failure inside a Tier A leaf (injected through the library's test hook) must (1) complete
+    that very call with the encoder's own CPU function, (2) put every RTCD pointer back to what svt_hip_install_rtcd had
+    replaced, (3) refuse to be installed again."""
+    sig = C.CFUNCTYPE(None, M.u8p if hasattr(M, "u8p") else C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32,
+                      C.POINTER(C.c_uint64), C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.c_uint32, C.c_uint8, C.c_int16, C.c_int16)
+    cases = list(M.iter_sad_loop_cases())[:6]
+    want = [M.call_sad_loop(ref.svt_sad_loop_kernel_c, prm, src, refw) for prm, src, refw in cases]
+    dropin.install()
+    try:
+        slot = C.c_void_p.in_dll(ref, "svt_sad_loop_kernel")
+        assert slot.value != dropin.saved["svt_sad_loop_kernel"]
+        got = [M.call_sad_loop(sig(slot.value), *cases[0])]               # healthy: the HIP leaf
+        hip.svt_hip_debug_inject_failure(0)                               # the next device check inside a leaf fails
+        got.append(M.call_sad_loop(sig(slot.value), *cases[1]))           # enters the HIP leaf, which fails and falls back
+        assert hip.svt_hip_debug_tier_a_broken(0) == 1
+        for n, v in dropin.saved.items():                                 # every pointer is the CPU function again
+            assert C.c_void_p.in_dll(ref, n).value == v, n
+        got += [M.call_sad_loop(sig(C.c_void_p.in_dll(ref, "svt_sad_loop_kernel").value), *c) for c in cases[2:]]
+        assert got == want
+        tab = (Binding * 1)()
+        tab[0].name, tab[0].slot = b"svt_sad_loop_kernel", C.addressof(C.c_void_p.in_dll(ref, "svt_sad_loop_kernel"))
+        assert hip.svt_hip_install_rtcd(tab, 1, None) == abi.SVT_HIP_ERR_RUNTIME
+        assert b"disabled" in hip.svt_hip_last_error()
+    finally:
+        hip.svt_hip_debug_inject_failure(-1)
+        hip.svt_hip_debug_tier_a_broken(1)                                # un-latch for the tests that follow
+        dropin.restore()

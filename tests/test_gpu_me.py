@@ -344,3 +344,68 @@ def test_me_frames_batch_is_deterministic(hip, orc):
     # and the whole 4K frame against the oracle
     want = me_cases.run_cpu(orc.orc_me_frame_range, prm, pyrs, cur, l0, l1, w, h)
     me_cases.assert_same(want, res[0], "4K frame")
+
+
+# ------------------------------------------------------------------------------------------------ memory contract
+def test_me_frame_exact_size_planes(hip, orc):
+    """include/svt_hip_me.h "Memory contract": planes of EXACTLY stride * (height + 2 * org_y) bytes, packed back to back in
+    one allocation (so that any byte a kernel reads past a plane belongs to the next plane, and past the last one to a
+    sentinel area filled first with 0x00 and then with 0xFF), give the oracle's results both times."""
+    w, h, cur, l0, l1 = 456, 264, 2, [1, 0], [3, 4]
+    clip = me_cases.make_clip("blocks", w, h, 5, seed=21)
+    pyrs = me_cases.build_pyramids(orc, clip)
+    prm = me_cases.scenario_params("m8_360p_tl2", cur, l0, l1, 2, 1)
+    want = me_cases.run_cpu(orc.orc_me_frame_range, prm, pyrs, cur, l0, l1, w, h)
+    planes = [pl for p in pyrs for pl in p.planes()]
+    total = sum(pl.nbytes for pl in planes)
+    SENT = 4096
+    big = device.DeviceBuffer(hip, total + SENT)
+    nb = frames.b64_count(w, h)
+    for sentinel in (0x00, 0xFF):
+        host = np.full(total + SENT, sentinel, np.uint8)
+        descs, off = [], 0
+        for pl in planes:
+            host[off:off + pl.nbytes] = pl.buf.reshape(-1)
+            descs.append(pl.desc(big.ptr + off))
+            off += pl.nbytes
+        big.upload(host)
+        pyr_desc = [abi.Pyramid8(*descs[3 * i:3 * i + 3]) for i in range(len(pyrs))]
+        out = device.DeviceMeOut(hip, prm, nb)
+        job = abi.MeFrameJob()
+        job.prm, job.src, job.out = prm, pyr_desc[cur], out.desc()
+        for r, poc in enumerate(l0):
+            job.ref[0][r] = pyr_desc[poc]
+        for r, poc in enumerate(l1):
+            job.ref[1][r] = pyr_desc[poc]
+        device.me_frames(hip, [job])
+        me_cases.assert_same(want, out.download(), f"exact-size planes, sentinel {sentinel:#x}")
+
+
+def test_me_frames_descriptor_lifetime(hip, orc):
+    """svt_hip_me_frames copies the HOST job array before it returns: six asynchronous calls in a row, each host array
+    overwritten right after its call, no synchronisation in between (the regression test for the round-1 abort:
+    DESIGN.md section 8)."""
+    w, h, cur, l0, l1 = 320, 200, 2, [1, 0], [3, 4]
+    clip = me_cases.make_clip("pan", w, h, 5, seed=5)
+    pyrs = me_cases.build_pyramids(orc, clip)
+    nb = frames.b64_count(w, h)
+    dpyr = {i: device.DevicePyramid(hip, pyrs[i]) for i in range(5)}
+    keys = ["m8_360p_tl2", "m4_360p_tl2", "m12_360p_tl2", "m8_360p_tl0", "m6_360p_tl2", "m10_360p_tl2"]
+    outs, wants = [], []
+    for key in keys:
+        prm = me_cases.scenario_params(key, cur, l0, l1)
+        wants.append(me_cases.run_cpu(orc.orc_me_frame_range, prm, pyrs, cur, l0, l1, w, h))
+        o = device.DeviceMeOut(hip, prm, nb)
+        job = abi.MeFrameJob()
+        job.prm, job.src, job.out = prm, dpyr[cur].desc(), o.desc()
+        for r, poc in enumerate(l0):
+            job.ref[0][r] = dpyr[poc].desc()
+        for r, poc in enumerate(l1):
+            job.ref[1][r] = dpyr[poc].desc()
+        arr = (abi.MeFrameJob * 1)(job)
+        device.check(hip, hip.svt_hip_me_frames(arr, C.c_uint32(1), None), "svt_hip_me_frames")
+        C.memset(arr, 0xFF, C.sizeof(arr))          # the caller's array is dead the moment the call returns
+        outs.append(o)
+    device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+    for key, o, want in zip(keys, outs, wants):
+        me_cases.assert_same(want, o.download(), key)
