@@ -558,7 +558,7 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
     if args.publish and world > 1:
         # one reconstructed 4K 10-bit reference picture (padded Y/U/V in one allocation) per step and rank, broadcast on a side
         # stream while the next step computes (rest_process.c:659-660, 732-744)
-        pub = shard.ReferencePublisher(W, H, 10, dev, rank, world)
+        pub = shard.ReferencePublisher(W, H, 10, dev, rank, world, transport=os.environ.get("SVTAV1_BENCH_PUBLISH", "torch"), lib=lib)
 
     def step(k=None):
         mw.analysis(sp)
@@ -631,7 +631,7 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
                    "width": W, "height": H, "bit_depth": 10, "pictures_per_step_per_gpu": F, "me_refs": mw.n_refs,
                    "coefficients_per_picture": tw.coeffs_per_picture,
                    "device_resident_bytes": int(mw.resident_bytes + tw.resident_bytes),
-                   "parallelism": f"frame-shard x{world} (no data-path collective" + (", one reference-picture broadcast per step on a side stream)" if pub else ")")},
+                   "parallelism": f"frame-shard x{world} (no data-path collective" + (f", one {pub.nbytes >> 20} MiB reference-picture broadcast per step on a side stream, transport {pub.transport})" if pub else ")")},
         "stage_ms": {"me_b64_kernel": round(ms["me"], 4), "txfm_4_launches": round(tx_ms, 4),
                      "analysis_and_gaps": round(step_ms - ms["me"] - tx_ms, 4)},
         "roofline": rl_me if ms["me"] >= tx_ms else max(rl_all[1:1 + len(sizes)], key=lambda r: r["launch_ms"]),

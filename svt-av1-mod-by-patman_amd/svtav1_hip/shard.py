@@ -112,9 +112,12 @@ def layer_aware_owner(pic_in_minigop, world, minigop=32):
 
 class ReferencePublisher:
     """bench.py --gpus N: every rank owns one reconstructed 4K reference picture (padded Y/U/V in one allocation) and the
-    ranks take turns publishing theirs, one broadcast per step on a side stream that overlaps the next step's kernels."""
+    ranks take turns publishing theirs, one broadcast per step on a side stream that overlaps the next step's kernels.
+    transport "torch": torch.distributed.broadcast (RCCL through PyTorch, the default); "c": the library's own
+    svt_hip_publish_reference over its own RCCL communicator (include/svt_hip_shard.h), falling back to "torch" if the
+    communicator cannot be created."""
 
-    def __init__(self, width, height, bit_depth, device, rank, world, pad=160):
+    def __init__(self, width, height, bit_depth, device, rank, world, pad=160, transport="torch", lib=None):
         bps = 1 if bit_depth == 8 else 2
         luma = (width + 2 * pad) * (height + 2 * pad)
         chroma = (width // 2 + pad) * (height // 2 + pad)
@@ -122,13 +125,37 @@ class ReferencePublisher:
         self.picture = torch.full((self.nbytes,), rank + 1, dtype=torch.uint8, device=device)
         self.side = torch.cuda.Stream(device=device)
         self.rank, self.world, self.pending = rank, world, None
+        self.transport, self.lib, self.comm, self.done = "torch", lib, None, None
+        if transport == "c" and lib is not None:
+            import ctypes as C
+            try:
+                ident = (C.c_uint8 * 128)()
+                if rank == 0:
+                    assert lib.svt_hip_comm_get_unique_id(ident) == 0, lib.svt_hip_last_error().decode()
+                box = [bytes(ident)]
+                dist.broadcast_object_list(box, src=0)
+                ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+                comm = C.c_void_p()
+                assert lib.svt_hip_comm_create(ident, world, rank, C.byref(comm)) == 0, lib.svt_hip_last_error().decode()
+                self.comm, self.done, self.transport = comm, C.c_void_p(), "c"
+            except Exception:       # noqa: BLE001  (keep the bench alive: the torch transport is always there)
+                self.transport = "torch"
 
     def publish(self, producer, owner):
+        if self.transport == "c":
+            import ctypes as C
+            rc = self.lib.svt_hip_publish_reference(C.c_void_p(self.picture.data_ptr()), C.c_size_t(self.nbytes), owner, self.comm,
+                                                    C.c_void_p(producer.cuda_stream), C.c_void_p(self.side.cuda_stream), C.byref(self.done))
+            assert rc == 0, self.lib.svt_hip_last_error().decode()
+            return
         if self.pending is not None:
             self.pending.wait()               # the previous broadcast: its buffer is about to be reused
         self.pending = publish_reference(self.picture, owner, stream=self.side, async_op=True, producer=producer)
 
     def finish(self):
+        if self.transport == "c":
+            self.side.synchronize()
+            return
         if self.pending is not None:
             self.pending.wait()
             self.pending = None

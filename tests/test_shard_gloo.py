@@ -40,6 +40,15 @@ def worker(rank, world, port, q):
     try:
         analyse = analyse_factory()
         first, last, c0, c1 = shard.segment(N, world, rank)
+        # the C-ABI form of the same decisions (include/svt_hip_shard.h), what a C host calls
+        import ctypes as C
+        from svtav1_hip import abi
+        lib = abi.load()
+        seg = (C.c_uint32 * 4)()
+        lib.svt_hip_shard_segment(N, world, rank, 2, 2, seg)
+        assert tuple(seg) == (first, last, c0, c1)
+        lib.svt_hip_shard_owner.restype = C.c_uint32
+        assert [lib.svt_hip_shard_owner(i, 32, world) for i in range(1, 33)] == [shard.layer_aware_owner(i, world) for i in range(1, 33)]
         local = shard.analyse_segment(lambda i: analyse(i, c0, c1), N, world, rank)
         assert sorted(local) == list(range(first, last))
         shard.barrier()
@@ -67,6 +76,32 @@ def free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def test_c_abi_assignment_matches_python():
+    """svt_hip_shard_layer / _owner / _segment (C) == shard.layer_of / layer_aware_owner / segment (Python)."""
+    import ctypes as C
+    from svtav1_hip import abi
+    lib = abi.load()
+    lib.svt_hip_shard_layer.restype = lib.svt_hip_shard_owner.restype = C.c_uint32
+    for mg in (8, 16, 32):
+        assert [lib.svt_hip_shard_layer(i, mg) for i in range(1, mg + 1)] == [shard.layer_of(i, mg) for i in range(1, mg + 1)]
+        for world in (1, 2, 3, 4, 8):
+            own = [lib.svt_hip_shard_owner(i, mg, world) for i in range(1, mg + 1)]
+            assert own == [shard.layer_aware_owner(i, world, mg) for i in range(1, mg + 1)]
+            # pictures of one layer sit on different GPUs as long as the layer has at most `world` of them
+            for layer in range(1, mg.bit_length()):
+                members = [own[i - 1] for i in range(1, mg + 1) if shard.layer_of(i, mg) == layer]
+                assert len(set(members)) == min(len(members), world)
+    seg = (C.c_uint32 * 4)()
+    for n in (5, 11, 20, 64):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lib.svt_hip_shard_segment(n, world, r, 2, 2, seg)
+                assert tuple(seg) == shard.segment(n, world, r)
+    if lib.svt_hip_device_count() == 0:      # no GPU: the communicator entry points fail loudly instead of pretending
+        ident = (C.c_uint8 * 128)()
+        assert lib.svt_hip_comm_get_unique_id(ident) == abi.SVT_HIP_ERR_NO_DEVICE
 
 
 def test_segments_partition_the_clip():
