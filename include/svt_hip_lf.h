@@ -90,10 +90,11 @@ SVT_HIP_API int32_t svt_hip_cdef_apply_plane(const SvtHipCdefPlane *plane, const
                                              const uint8_t *d_dir, const int32_t *d_var, void *stream);
 
 /* The same for up to three planes of one picture in ONE launch (svt_av1_cdef_frame, enc_cdef.c:284-610, walks the planes
- * of a filter block together): planes[p] / d_fb_strength[p] per plane (luma strength index for plane 0, chroma for 1, 2);
- * all planes must cover the same 64x64 (luma) filter-block grid. */
+ * of a filter block together): planes[p] / fb_strength_dptrs[p] per plane (luma strength index for plane 0, chroma for 1, 2);
+ * all planes must cover the same 64x64 (luma) filter-block grid.  `planes` and `fb_strength_dptrs` are HOST arrays of
+ * n_planes entries (the latter holds DEVICE pointers, one strength array per plane); everything else is device memory. */
 SVT_HIP_API int32_t svt_hip_cdef_apply_frame(const SvtHipCdefPlane *planes, uint32_t n_planes, const uint8_t *d_filt8x8,
-                                             const uint8_t *const *d_fb_strength, int32_t damping, int32_t coeff_shift,
+                                             const uint8_t *const *fb_strength_dptrs, int32_t damping, int32_t coeff_shift,
                                              const uint8_t *d_dir, const int32_t *d_var, void *stream);
 
 /* =============================================================================================
@@ -255,6 +256,44 @@ SVT_HIP_API int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units /* host *
 SVT_HIP_API int32_t svt_hip_wiener_convolve(const void *d_src, uint32_t src_stride, void *d_dst, uint32_t dst_stride, uint32_t w,
                                             uint32_t h, const int16_t filter_x[8], const int16_t filter_y[8], int32_t is_16bit,
                                             int32_t bit_depth, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Frame-level loop restoration: svt_av1_loop_restoration_filter_frame (restoration.c:1179-1248) = for every restoration
+ * unit svt_av1_loop_restoration_filter_unit (:1067-1147) = for every 64-row processing stripe of the unit
+ * {svt_aom_setup_processing_stripe_boundary (:288-384) -> stripe filter (Wiener :437-466, :1017-1038 or self-guided
+ * :994-1015, :1040-1062) -> svt_aom_restore_processing_stripe_boundary (:386-435)}.
+ *
+ * The reference patches the three rows above / below a stripe INTO the picture, filters, and patches them back.  On the
+ * device the same rows are selected while the stripe's tile is assembled in LDS (nothing is ever written into the source
+ * plane), one workgroup per (64 >> ss_x)-wide processing unit of a stripe, all planes in one launch:
+ *   rows above the first stripe / below the last stripe / left and right of the picture: edge replication (svt_extend_frame);
+ *   other stripes, optimized_lr == 0: two saved DEBLOCKED rows from stripe_boundary_above / _below, used 0,0,1 / 0,1,1
+ *                                     (svt_av1_loop_restoration_save_boundary_lines wrote them; row 2*stripe + k, element j is
+ *                                     picture column j - SVT_HIP_LR_EXTRA_HORZ);
+ *   optimized_lr == 1: the picture's own rows, the outermost of the three duplicated from its neighbour.
+ * src and dst must be different planes; RESTORE_NONE units are copied. */
+#define SVT_HIP_LR_EXTRA_HORZ 4 /* RESTORATION_EXTRA_HORZ (restoration.h) */
+typedef struct SvtHipLrUnit {   /* RestorationUnitInfo (restoration.h:176-181) */
+    uint8_t restoration_type;   /* 0 RESTORE_NONE, 1 RESTORE_WIENER, 2 RESTORE_SGRPROJ */
+    uint8_t ep;                 /* sgrproj_info.ep */
+    int16_t pad_;
+    int32_t xqd[2];             /* sgrproj_info.xqd */
+    int16_t hfilter[8], vfilter[8]; /* wiener_info (InterpKernel: 7 taps + 0, centre tap stored minus 128) */
+} SvtHipLrUnit;
+typedef struct SvtHipLrPlane {
+    const void *src;            /* device: CDEF output, pointer to sample (0, 0) */
+    void       *dst;            /* device: restored plane, sample (0, 0) */
+    uint32_t    src_stride, dst_stride; /* samples */
+    uint32_t    width, height;  /* plane size (cropped) */
+    uint8_t     ss_x, ss_y, is_16bit, bit_depth;
+    uint32_t    unit_size;      /* rsi->restoration_unit_size of this plane */
+    uint32_t    horz_units, vert_units; /* rsi->horz_units_per_tile, vert_units_per_tile */
+    const SvtHipLrUnit *units;  /* device [vert_units][horz_units] */
+    const void *boundary_above, *boundary_below; /* device: rsb->stripe_boundary_above / _below (NULL when optimized_lr) */
+    uint32_t    boundary_stride; /* samples */
+    uint32_t    optimized_lr;
+} SvtHipLrPlane;
+SVT_HIP_API int32_t svt_hip_restoration_filter_frame(const SvtHipLrPlane *planes, uint32_t n_planes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -687,9 +687,9 @@ extern "C" int32_t svt_hip_cdef_apply_plane(const SvtHipCdefPlane *plane, const 
 
 // ------------------------------------------------------------------------------------------------ Tier A
 extern "C" int32_t svt_hip_cdef_apply_frame(const SvtHipCdefPlane *planes, uint32_t n_planes, const uint8_t *d_filt8x8,
-                                            const uint8_t *const *d_fb_strength, int32_t damping, int32_t coeff_shift, const uint8_t *d_dir,
+                                            const uint8_t *const *fb_strength_dptrs, int32_t damping, int32_t coeff_shift, const uint8_t *d_dir,
                                             const int32_t *d_var, void *stream) {
-    if (!planes || n_planes == 0 || n_planes > 3 || !d_filt8x8 || !d_fb_strength || !d_dir || !d_var) {
+    if (!planes || n_planes == 0 || n_planes > 3 || !d_filt8x8 || !fb_strength_dptrs || !d_dir || !d_var) {
         set_error("svt_hip_cdef_apply_frame: bad argument");
         return SVT_HIP_ERR_BAD_PARAMETER;
     }
@@ -697,12 +697,12 @@ extern "C" int32_t svt_hip_cdef_apply_frame(const SvtHipCdefPlane *planes, uint3
     for (uint32_t p = 0; p < n_planes; p++) {
         const int lw = (int)planes[p].width << planes[p].xdec, lh = (int)planes[p].height << planes[p].ydec;
         const int lw0 = (int)planes[0].width << planes[0].xdec, lh0 = (int)planes[0].height << planes[0].ydec;
-        if (!plane_ok(&planes[p]) || !d_fb_strength[p] || planes[p].recon == planes[p].source || (lw + 63) / 64 != (lw0 + 63) / 64 ||
+        if (!plane_ok(&planes[p]) || !fb_strength_dptrs[p] || planes[p].recon == planes[p].source || (lw + 63) / 64 != (lw0 + 63) / 64 ||
             (lh + 63) / 64 != (lh0 + 63) / 64) {
             set_error("svt_hip_cdef_apply_frame: plane %u: bad plane (input and output must differ; all planes must cover the same filter blocks)", p);
             return SVT_HIP_ERR_BAD_PARAMETER;
         }
-        f.pl[p] = planes[p], f.strength[p] = d_fb_strength[p];
+        f.pl[p] = planes[p], f.strength[p] = fb_strength_dptrs[p];
     }
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;

@@ -18,6 +18,7 @@
 
 #include "../../include/svt_hip_lf.h"
 #include "common.hpp"
+#include "lr_device.hpp"
 
 using namespace svthip;
 
@@ -26,9 +27,7 @@ namespace {
 constexpr int TW = 64, TH = 32;  // samples per tile (TH shrinks to 8 for 12-bit so that int32 partials cannot overflow)
 constexpr int W2MAX = 49;  // WIENER_WIN2
 
-__device__ __forceinline__ int32_t ldpx(const void *p, size_t idx, int is16) {
-    return is16 ? ((const __attribute__((address_space(1))) uint16_t *)p)[idx] : ((const __attribute__((address_space(1))) uint8_t *)p)[idx];  // pictures are global memory: no flat loads
-}
+using svthip::lr::ldpx;
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -229,9 +228,9 @@ struct Taps {
 };
 __global__ __launch_bounds__(256) void wiener_convolve_kernel(const void *__restrict__ src, uint32_t src_stride, void *__restrict__ dst,
                                                               uint32_t dst_stride, int w, int h, Taps f, int is16, int bd, int r0, int r1) {
-    __shared__ uint16_t in[(64 + 7) * (64 + 8)];
+    __shared__ uint16_t in[(64 + 7) * lr::WIENER_IP];
     __shared__ uint16_t tmp[(64 + 7) * 64];
-    constexpr int IP = 64 + 8;
+    constexpr int IP = lr::WIENER_IP;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
     const int tw = min(64, w - x0), th = min(64, h - y0);
     for (int idx = threadIdx.x; idx < (th + 7) * (tw + 7); idx += 256) {
@@ -239,30 +238,7 @@ __global__ __launch_bounds__(256) void wiener_convolve_kernel(const void *__rest
         in[r * IP + c] = (uint16_t)ldpx(src, (size_t)((ptrdiff_t)(y0 + r - 3) * src_stride + (x0 + c - 3)), is16);
     }
     __syncthreads();
-    const int limit = (1 << (bd + 1 + 7 - r0)) - 1;
-    for (int idx = threadIdx.x; idx < (th + 7) * tw; idx += 256) {
-        const int r = idx / tw, c = idx - r * tw;
-        int32_t   sum = ((int32_t)in[r * IP + c + 3] << 7) + (1 << (bd + 7 - 1));
-#pragma unroll
-        for (int k = 0; k < 7; k++) sum += (int32_t)in[r * IP + c + k] * f.x[k];  // the 8th coefficient is zero by construction
-        const int32_t v = (sum + ((1 << r0) >> 1)) >> r0;
-        tmp[r * 64 + c] = (uint16_t)(v < 0 ? 0 : (v > limit ? limit : v));
-    }
-    __syncthreads();
-    const int hi = (1 << bd) - 1;
-    for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
-        const int r = idx / tw, c = idx - r * tw;
-        int32_t   sum = ((int32_t)tmp[(r + 3) * 64 + c] << 7) - (1 << (bd + r1 - 1));
-#pragma unroll
-        for (int k = 0; k < 7; k++) sum += (int32_t)tmp[(r + k) * 64 + c] * f.y[k];
-        int32_t v = (sum + ((1 << r1) >> 1)) >> r1;
-        v         = v < 0 ? 0 : (v > hi ? hi : v);
-        const size_t o = (size_t)(y0 + r) * dst_stride + x0 + c;
-        if (is16)
-            ((uint16_t *)dst)[o] = (uint16_t)v;
-        else
-            ((uint8_t *)dst)[o] = (uint8_t)v;
-    }
+    lr::wiener_tile_filter<256>(in, tmp, threadIdx.x, tw, th, x0, y0, f.x, f.y, bd, r0, r1, is16, dst, dst_stride);
 }
 
 [[noreturn]] void fatal(const char *what) { svthip::tier_a_throw("%s: %s", what, svt_hip_last_error()); }

@@ -230,6 +230,29 @@ class WienerUnit(C.Structure):    # SvtHipWienerUnit
                 ("h_start", C.c_int32), ("h_end", C.c_int32), ("v_start", C.c_int32), ("v_end", C.c_int32)]
 
 
+LR_EXTRA_HORZ = 4                   # SVT_HIP_LR_EXTRA_HORZ
+
+
+class LrUnit(C.Structure):          # SvtHipLrUnit
+    _fields_ = [("restoration_type", C.c_uint8), ("ep", C.c_uint8), ("pad_", C.c_int16), ("xqd", C.c_int32 * 2),
+                ("hfilter", C.c_int16 * 8), ("vfilter", C.c_int16 * 8)]
+
+
+import numpy as np  # noqa: E402
+
+LR_UNIT_DTYPE = np.dtype([("restoration_type", np.uint8), ("ep", np.uint8), ("pad_", np.int16), ("xqd", np.int32, 2),
+                          ("hfilter", np.int16, 8), ("vfilter", np.int16, 8)])
+assert LR_UNIT_DTYPE.itemsize == C.sizeof(LrUnit) == 44
+
+
+class LrPlane(C.Structure):         # SvtHipLrPlane
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_stride", C.c_uint32), ("dst_stride", C.c_uint32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("ss_x", C.c_uint8), ("ss_y", C.c_uint8), ("is_16bit", C.c_uint8),
+                ("bit_depth", C.c_uint8), ("unit_size", C.c_uint32), ("horz_units", C.c_uint32), ("vert_units", C.c_uint32),
+                ("units", C.c_void_p), ("boundary_above", C.c_void_p), ("boundary_below", C.c_void_p),
+                ("boundary_stride", C.c_uint32), ("optimized_lr", C.c_uint32)]
+
+
 class ConvolveParams(C.Structure):   # SvtHipConvolveParams == ConvolveParams (definitions.h:580-593)
     _fields_ = [("ref", C.c_int32), ("do_average", C.c_int32), ("dst", C.c_void_p), ("dst_stride", C.c_int32), ("round_0", C.c_int32),
                 ("round_1", C.c_int32), ("plane", C.c_int32), ("is_compound", C.c_int32), ("use_jnt_comp_avg", C.c_int32),
