@@ -181,12 +181,18 @@ typedef struct SvtHipMeParams {
     SvtHipSearchArea hme_l0_sa_min, hme_l0_sa_max, hme_l1_sa, hme_l2_sa;
     SvtHipSearchArea me_sa_min, me_sa_max;
     /* PreHmeCtrls (me_context.h) */
-    uint8_t prehme_enable, prehme_skip_search_line, prehme_l1_early_exit, pad0_;
+    uint8_t prehme_enable, prehme_skip_search_line, prehme_l1_early_exit;
+    uint8_t me_mctf; /* 1: me_ctx->me_type == ME_MCTF (the temporal filter's call of svt_aom_motion_estimation_b64,
+                      * temporal_filtering.c:3075): picture distance not scaled in the full-pel search area
+                      * (motion_estimation.c:1302), no HME / ME reference pruning (:3173), early exit on tf_me_exit_th
+                      * (:3179-3183), no candidate lists and no distortion statistics (:3196); 0: ME_OPEN_LOOP */
     SvtHipSearchArea prehme_sa_min[2], prehme_sa_max[2];
     /* MeHmeRefPruneCtrls */
     uint8_t  enable_me_hme_ref_pruning, pad1_;
     uint16_t prune_ref_if_hme_sad_dev_bigger_than_th, prune_ref_if_me_sad_dev_bigger_than_th;
-    uint16_t zz_sad_pct, phme_sad_pct, pad2_;
+    uint16_t zz_sad_pct, phme_sad_pct;
+    uint16_t tf_me_exit_th; /* me_ctx->tf_me_exit_th (me_mctf only): a b64 whose search_results[0][0].hme_sad is below it skips
+                             * the full-pel search; best_sad / best_mv stay zero, the caller reads hme_sad from search_results */
     uint32_t zz_sad_th, phme_sad_th;
     /* MeSrCtrls */
     uint8_t  enable_me_sr_adjustment, distance_based_hme_resizing;

@@ -189,7 +189,8 @@ static void params_to_ctx(MeContext *me, const SvtHipMeParams *p) {
     me->prev_me_stage_based_exit_th      = p->prev_me_stage_based_exit_th;
     me->prune_me_candidates_th           = p->prune_me_candidates_th;
     me->use_best_unipred_cand_only       = p->use_best_unipred_cand_only;
-    me->me_type                          = ME_OPEN_LOOP;
+    me->me_type                          = p->me_mctf ? ME_MCTF : ME_OPEN_LOOP;
+    me->tf_me_exit_th                    = p->tf_me_exit_th;
     me->num_of_list_to_search            = p->num_of_list_to_search;
     me->num_of_ref_pic_to_search[0]      = p->num_of_ref_pic_to_search[0];
     me->num_of_ref_pic_to_search[1]      = p->num_of_ref_pic_to_search[1];

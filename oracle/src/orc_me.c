@@ -576,7 +576,8 @@ static void integer_search_b64(Ctx *c) {
                 continue;
             int16_t xc = c->sr[li][ri].hme_sc_x, yc = c->sr[li][ri].hme_sc_y;
             int16_t sw = (int16_t)p->me_sa_min.width, sh = (int16_t)p->me_sa_min.height;
-            dist       = scaled_dist(dist);
+            if (!p->me_mctf) /* :1302 */
+                dist = scaled_dist(dist);
             sw         = (int16_t)MINV((sw * dist), p->me_sa_max.width);
             sh         = (int16_t)MINV((sh * dist), p->me_sa_max.height);
             if (p->mv_sa_adj_enabled && (!p->mv_sa_adj_nearest_ref_only || ri == 0)) {
@@ -854,7 +855,7 @@ static void me_b64(Ctx *c, const SvtHipMeFrameJob *job, uint32_t b64_index, uint
     c->src_full  = plane_at(&c->src->full, (int)c->org_x, (int)c->org_y);
     c->src_q     = plane_at(&c->src->quarter, (int)(c->org_x >> 1), (int)(c->org_y >> 1));
     c->src_s     = plane_at(&c->src->sixteenth, (int)(c->org_x >> 2), (int)(c->org_y >> 2));
-    const int prune_ref = p->enable_hme_flag; /* me_type != ME_MCTF */
+    const int prune_ref = p->enable_hme_flag && !p->me_mctf; /* :3173 */
     init_b64(c);
     /* hme_b64, :2511-2545 */
     if (p->me_early_exit_th || p->me_safe_limit_zz_th)
@@ -867,13 +868,23 @@ static void me_b64(Ctx *c, const SvtHipMeFrameJob *job, uint32_t b64_index, uint
         if (p->enable_hme_level2_flag) hme_level2_b64(c);
     }
     set_final_search_centre(c);
-    if (prune_ref)
-        hme_prune_ref_and_adjust_sr(c);
-    integer_search_b64(c);
-    if (prune_ref && p->enable_me_hme_ref_pruning)
-        me_prune_ref(c);
+    const SvtHipMeFrameOut *out = &job->out;
+    /* ME_MCTF: a block whose first reference already matches well keeps its HME vector (:3179-3183) */
+    const int tf_exit = p->me_mctf && c->sr[0][0].hme_sad < p->tf_me_exit_th;
+    if (!tf_exit) {
+        if (prune_ref)
+            hme_prune_ref_and_adjust_sr(c);
+        integer_search_b64(c);
+        if (prune_ref && p->enable_me_hme_ref_pruning)
+            me_prune_ref(c);
+    }
+    if (p->me_mctf) { /* no candidate lists, no distortion statistics (:3196) */
+        memcpy(out->best_sad + (size_t)b64_index * NL * NR * 85, c->best_sad, sizeof(c->best_sad));
+        memcpy(out->best_mv + (size_t)b64_index * NL * NR * 85, c->best_mv, sizeof(c->best_mv));
+        memcpy(out->search_results + (size_t)b64_index * NL * NR, c->sr, sizeof(c->sr));
+        return;
+    }
 
-    const SvtHipMeFrameOut *out    = &job->out;
     const uint32_t          stored = svt_hip_me_stored_pus(p);
     SbOut o = {out->me_mv_array + (size_t)b64_index * stored * p->max_refs,
                out->me_candidate_array + (size_t)b64_index * stored * p->max_cand,

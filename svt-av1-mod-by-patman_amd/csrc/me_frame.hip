@@ -972,7 +972,7 @@ __device__ void centre_prune_lane0(LDS &L, const Ctx &c) {
                 }
                 S.sr[li][ri].hme_sc_x = xc, S.sr[li][ri].hme_sc_y = yc, S.sr[li][ri].hme_sad = hsad;
             }
-        if (p.enable_hme_flag) {  // prune_ref = enable_hme_flag && me_type != ME_MCTF
+        if (p.enable_hme_flag && !p.me_mctf) {  // prune_ref = enable_hme_flag && me_type != ME_MCTF (:3173)
             const uint16_t th = p.prune_ref_if_hme_sad_dev_bigger_than_th;
             if (p.enable_me_hme_ref_pruning && th != (uint16_t)~0) {
                 uint64_t best = ~(uint64_t)0;
@@ -1011,7 +1011,8 @@ __device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store) {
         uint16_t dist = pic_dist(p, li, ri);
         int16_t  xc = S.sr[li][ri].hme_sc_x, yc = S.sr[li][ri].hme_sc_y;
         int16_t  sw = (int16_t)p.me_sa_min.width, sh_ = (int16_t)p.me_sa_min.height;
-        dist        = scaled_dist(dist);
+        if (!p.me_mctf)  // motion_estimation.c:1302
+            dist = scaled_dist(dist);
         sw          = (int16_t)MINV((sw * dist), p.me_sa_max.width);
         sh_         = (int16_t)MINV((sh_ * dist), p.me_sa_max.height);
         if (p.mv_sa_adj_enabled && (!p.mv_sa_adj_nearest_ref_only || ri == 0)) {
@@ -1369,12 +1370,21 @@ __global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFra
     __syncthreads();
     ME_PHASE(6);
     ME_STOP(6);
-    for (int li = 0; li < nlists; ++li)
-        for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
-            if (S.sr[li][ri].do_ref)  // uniform: LDS value written before the last barrier
-                fullpel_ref(L, c, li, ri, true);
+    // ME_MCTF (the temporal filter's use of this function): a block whose first reference already matches well keeps its HME
+    // vector and skips the full-pel search (:3179-3183); no pruning, candidates or distortion statistics (:3173, 3196)
+    const bool tf_exit = p.me_mctf && S.sr[0][0].hme_sad < p.tf_me_exit_th;  // uniform: LDS value written before the last barrier
+    if (!tf_exit)
+        for (int li = 0; li < nlists; ++li)
+            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
+                if (S.sr[li][ri].do_ref)  // uniform
+                    fullpel_ref(L, c, li, ri, true);
     ME_PHASE(7);
     ME_STOP(7);
+    if (p.me_mctf) {
+        if (tid < NL * NR)
+            job.out.search_results[(size_t)c.b64 * NL * NR + tid] = (&S.sr[0][0])[tid];
+        return;
+    }
     if (p.enable_hme_flag && p.enable_me_hme_ref_pruning) {
         me_prune_lane0(L, c);
         __syncthreads();

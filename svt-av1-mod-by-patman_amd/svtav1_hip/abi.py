@@ -32,12 +32,12 @@ class MeParams(C.Structure):
         ("hme_l0_sa_min", SearchArea), ("hme_l0_sa_max", SearchArea), ("hme_l1_sa", SearchArea),
         ("hme_l2_sa", SearchArea), ("me_sa_min", SearchArea), ("me_sa_max", SearchArea),
         ("prehme_enable", C.c_uint8), ("prehme_skip_search_line", C.c_uint8),
-        ("prehme_l1_early_exit", C.c_uint8), ("pad0_", C.c_uint8),
+        ("prehme_l1_early_exit", C.c_uint8), ("me_mctf", C.c_uint8),
         ("prehme_sa_min", SearchArea * 2), ("prehme_sa_max", SearchArea * 2),
         ("enable_me_hme_ref_pruning", C.c_uint8), ("pad1_", C.c_uint8),
         ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16),
         ("prune_ref_if_me_sad_dev_bigger_than_th", C.c_uint16),
-        ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("pad2_", C.c_uint16),
+        ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("tf_me_exit_th", C.c_uint16),
         ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
         ("enable_me_sr_adjustment", C.c_uint8), ("distance_based_hme_resizing", C.c_uint8),
         ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16),

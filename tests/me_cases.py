@@ -133,3 +133,19 @@ def call_sad_loop(fn, prm, src, refw):
        C.c_uint32(prm["bh"]), C.c_uint32(prm["bw"]), C.byref(best), C.byref(x), C.byref(y), C.c_uint32(prm["stride"]),
        C.c_uint8(prm["skip"]), C.c_int16(prm["sw"]), C.c_int16(prm["sh"]))
     return int(best.value), int(x.value), int(y.value)
+
+
+# ME_MCTF mode (the temporal filter's call of svt_aom_motion_estimation_b64, temporal_filtering.c:3075): one list, one
+# reference = the neighbouring picture being aligned to the central one.  (kind, w, h, params key, central, reference,
+# tf_me_exit_th, seed): thresholds from "never" over "some blocks" to "every block" exits behind HME.
+MCTF_SCENARIOS = [
+    ("pan", 328, 200, "m8_360p_tl0", 2, 1, 0, 61), ("static", 320, 192, "m8_360p_tl0", 2, 3, 1500, 62),
+    ("blocks", 456, 264, "m6_360p_tl0", 2, 0, 4000, 63), ("noise", 200, 136, "m4_360p_tl0", 2, 4, 65535, 64),
+    ("fastpan", 392, 232, "m8_360p_tl0", 1, 3, 900, 65),
+]
+
+
+def mctf_params(key, cur, refpoc, exit_th):
+    prm = scenario_params(key, cur, [refpoc], [], 0, 1)
+    prm.me_mctf, prm.tf_me_exit_th = 1, exit_th
+    return prm

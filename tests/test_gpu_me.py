@@ -269,6 +269,23 @@ def test_me_frame(hip, orc, sc):
     me_cases.assert_same(want, got, str(sc))
 
 
+@pytest.mark.parametrize("sc", me_cases.MCTF_SCENARIOS, ids=lambda s: f"{s[0]}-{s[1]}x{s[2]}-th{s[6]}")
+def test_me_frame_mctf(hip, orc, sc):
+    """ME_MCTF mode of the b64 kernel (the temporal filter's motion search) against the oracle and against
+    the outputs of the real svt_aom_motion_estimation_b64 with me_type = ME_MCTF (tests/golden/me_mctf.npz)."""
+    kind, w, h, key, cur, refpoc, th, seed = sc
+    clip = me_cases.make_clip(kind, w, h, 5, seed=seed)
+    pyrs = me_cases.build_pyramids(orc, clip)
+    prm = me_cases.mctf_params(key, cur, refpoc, th)
+    want = me_cases.run_cpu(orc.orc_me_frame_range, prm, pyrs, cur, [refpoc], [], w, h)
+    got = run_hip_me(hip, prm, pyrs, cur, [refpoc], [], w, h)[0]
+    me_cases.assert_same(want, got, str(sc))
+    gold = np.load(os.path.join(me_cases.GOLDEN, "me_mctf.npz"))
+    i = me_cases.MCTF_SCENARIOS.index(sc)
+    for k in ("best_sad", "best_mv", "search_results"):
+        assert np.array_equal(got[k], gold[f"s{i}_{k}"]), k
+
+
 def test_me_frame_golden(hip, orc):
     """HIP == committed outputs of the reference's svt_aom_motion_estimation_b64 (tests/golden/me_frames.npz)."""
     with open(os.path.join(me_cases.GOLDEN, "me_frames.json")) as f:

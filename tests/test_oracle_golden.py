@@ -51,3 +51,14 @@ def test_pyramid_variance_golden(orc):
         var = np.zeros((nb, 85), np.uint16)
         orc.orc_variance_frame(C.byref(d.full), var.ctypes.data_as(C.c_void_p), None, fp)
         assert np.array_equal(var, gold[key])
+
+
+def test_me_mctf_golden(orc):
+    """ME_MCTF mode against the outputs of the real svt_aom_motion_estimation_b64 (tests/golden/make_golden_mctf.py)."""
+    gold = np.load(os.path.join(G, "me_mctf.npz"))
+    for i, (kind, w, h, key, cur, refpoc, th, seed) in enumerate(me_cases.MCTF_SCENARIOS):
+        clip = me_cases.make_clip(kind, w, h, 5, seed=seed)
+        pyrs = me_cases.build_pyramids(orc, clip)
+        got = me_cases.run_cpu(orc.orc_me_frame_range, me_cases.mctf_params(key, cur, refpoc, th), pyrs, cur, [refpoc], [], w, h)
+        for k in ("best_sad", "best_mv", "search_results"):
+            assert np.array_equal(got[k], gold[f"s{i}_{k}"]), (i, k)

@@ -156,6 +156,21 @@ def test_me_frame(orc, ref, sc):
     me_cases.assert_same(a, b, str(sc))
 
 
+@pytest.mark.parametrize("sc", me_cases.MCTF_SCENARIOS, ids=lambda s: f"{s[0]}-{s[1]}x{s[2]}-th{s[6]}")
+def test_me_frame_mctf(orc, ref, sc):
+    """me_type == ME_MCTF: unscaled distance in the full-pel area, no pruning, tf_me_exit_th early exit, no candidates."""
+    kind, w, h, key, cur, refpoc, th, seed = sc
+    clip = me_cases.make_clip(kind, w, h, 5, seed=seed)
+    pyrs = me_cases.build_pyramids(orc, clip)
+    prm = me_cases.mctf_params(key, cur, refpoc, th)
+    a = me_cases.run_cpu(ref.ref_me_frame, prm, pyrs, cur, [refpoc], [], w, h)
+    b = me_cases.run_cpu(orc.orc_me_frame_range, prm, pyrs, cur, [refpoc], [], w, h)
+    me_cases.assert_same(a, b, str(sc))
+    searched = (a["best_sad"][:, 0, 0, 0] != 0).sum()
+    assert (th == 0) <= (searched == len(a["best_sad"]))  # hme_sad < th exits: never at th 0, noise blocks stay above 65535
+    assert (a["me_64x64_distortion"].view(np.uint8) == 0xA5).all()      # statistics / candidates are not produced in this mode
+
+
 def test_me_frame_param_variants(orc, ref):
     """Branches no preset reaches at qp 35: FULL_SAD search, pre-HME l1 early exit + skip lines, sr_adjustment 2,
     MV-based SA growth, stage-based exits, unipred-only, only_l_bwd."""
