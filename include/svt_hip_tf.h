@@ -17,6 +17,7 @@
 #define SVT_HIP_TF_H
 
 #include "svt_hip.h"
+#include "svt_hip_me.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -61,6 +62,75 @@ typedef struct SvtHipTfOut {
     uint32_t pad_;
 } SvtHipTfOut;
 SVT_HIP_API int32_t svt_hip_tf_normalise_batch(const SvtHipTfBlock *d_blocks, const SvtHipTfOut *d_out, uint32_t n_blocks, void *stream);
+
+/* ---- whole-picture driver: produce_temporally_filtered_pic (temporal_filtering.c:2752-3308) -------------------------------
+ * The block loop of the reference, for ONE centre picture against its window of reference pictures, device-resident:
+ *   per reference picture  svt_aom_motion_estimation_b64 in ME_MCTF mode (the b64 kernel of svt_hip_me.h)
+ *                          -> tf_64x64 / tf_32x32 / tf_16x16_sub_pel_search, tf_use_64x64_pred, the 64x64-vs-32x32 and the
+ *                             32x32-vs-16x16 decisions (derive_tf_32x32_block_split_flag)        (:1531-2105, 236-285, 2646, 3085-3245)
+ *                          -> tf_64x64 / tf_32x32_inter_prediction (sharp 8-tap, luma + chroma)     (:2226-2576)
+ *                          -> convert_64x64_info_to_32x32_info                                       (:2661-2728)
+ *                          -> apply_filtering_block_plane_wise                                       (:1382-1524)
+ *   apply_filtering_central before, get_final_filtered_pixels after; the centre picture is filtered IN PLACE.
+ * What stays with the caller (scalar control logic): which pictures enter the window (the ahd-error / brightness outlier
+ * tests, ref_frame_factor), tf_decay_factor_fp16 (noise levels, qp), tf_chroma, tf_mv_dist_th; packing 10-bit pictures into
+ * 16-bit planes before and unpacking / re-decimating the filtered centre picture after (svt_hip_pyramid_frame).
+ * 8x8 prediction (TfControls::enable_8x8_pred, tf level 1 only) is not provided: the call refuses it. */
+#define SVT_HIP_TF_MAX_REFS 32 /* ALTREF_MAX_NFRAMES - 1 */
+
+typedef struct SvtHipTfCtrls {      /* the TfControls fields (definitions.h:120-215) the block loop reads */
+    uint8_t  half_pel_mode, quarter_pel_mode, eight_pel_mode; /* 0 off, 1 all eight neighbours, >= 2 horizontal / vertical only */
+    uint8_t  use_2tap;               /* bilinear instead of regular 8-tap for the 64x64 and 32x32 searches */
+    uint8_t  sub_sampling_shift;     /* the centre position of a search is measured on every 2nd row */
+    uint8_t  use_pred_64x64_only_th; /* 0 off, 255 always 64x64, else tf_use_64x64_pred's deviation threshold */
+    uint8_t  subpel_early_exit_th;
+    uint8_t  use_8bit_subpel;        /* bit depth > 8: the sub-pel searches run on the 8-bit planes */
+    uint8_t  use_zz_based_filter, enable_8x8_pred, pad_[6];
+    uint64_t pred_error_32x32_th;
+} SvtHipTfCtrls;
+
+/* One picture of the window.  Every plane follows the EbPictureBufferDesc convention of SvtHipPlane8: sample (x, y) =
+ * buf[(org_y + y) * stride + org_x + x]; chroma planes have half the luma origin (4:2:0). */
+typedef struct SvtHipTfPic {
+    SvtHipPyramid8 pyr;        /* 8-bit luma: padded input picture, 1/4 and 1/16 versions (EbPaReferenceObject) */
+    uint8_t       *chroma8[2]; /* 8-bit Cb / Cr; origin (pyr.full.org_x / 2, pyr.full.org_y / 2) */
+    uint32_t       chroma8_stride, pad_;
+    uint16_t      *hbd[3];     /* bit depth > 8: 16-bit Y / Cb / Cr (altref_buffer_highbd) with the geometry and strides of the
+                                * 8-bit planes; NULL otherwise */
+    uint64_t       picture_number; /* replaces me.picture_number (centre) / me.ref_picture_number[0][0] (reference picture) */
+} SvtHipTfPic;
+
+typedef struct SvtHipTfPictureJob {
+    SvtHipMeParams me;         /* as for svt_hip_me_frames (hme_l0_sa = MeContext::hme_l0_sa_default_tf); me_mctf, the single list /
+                                * reference and tf_me_exit_th are taken from this struct as given */
+    SvtHipTfCtrls  ctrls;
+    uint32_t       decay_factor_fp16[3]; /* MeContext::tf_decay_factor_fp16 */
+    uint16_t       mv_dist_th;           /* MeContext::tf_mv_dist_th */
+    uint8_t        chroma;               /* MeContext::tf_chroma */
+    uint8_t        bit_depth;            /* 8 or 10 */
+    uint32_t       mi_rows, mi_cols;     /* Av1Common (4x4 units): the motion-vector clamp of the predictions */
+    uint32_t       n_refs;               /* pictures filtered against, at most SVT_HIP_TF_MAX_REFS */
+    SvtHipTfPic    centre;
+    SvtHipTfPic    ref[SVT_HIP_TF_MAX_REFS];
+    void          *workspace;            /* device, svt_hip_tf_workspace_bytes() */
+    uint64_t       workspace_bytes;
+    uint32_t      *tot_blks;             /* device [2] or NULL: += MeContext::tf_tot_horz_blks, tf_tot_vert_blks */
+} SvtHipTfPictureJob;
+
+SVT_HIP_API uint64_t svt_hip_tf_workspace_bytes(uint32_t width, uint32_t height, uint32_t n_refs);
+/* `job` is a HOST struct, every pointer inside is device memory.  Asynchronous on `stream`. */
+SVT_HIP_API int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void *stream);
+
+/* The per-64x64-block state of the motion refinement, as the reference keeps it in MeContext (tf_64x64_*, tf_32x32_*,
+ * tf_16x16_*): one record per (reference picture, b64) in the workspace; exposed for tests and for callers that run the
+ * stages themselves.  16x16 entries are in the order of tf_16x16_mv_x (idx_32x32 * 4 + idx_16x16). */
+typedef struct SvtHipTfB64State {
+    uint64_t err64, err32[4], err16[16];
+    int16_t  mv64_x, mv64_y, mv32_x[4], mv32_y[4], mv16_x[16], mv16_y[16];
+    uint8_t  split32[4];       /* tf_32x32_block_split_flag */
+    uint8_t  use_64x64;        /* the block is predicted as one 64x64 (convert_64x64_info_to_32x32_info applies) */
+    uint8_t  pad_[3];
+} SvtHipTfB64State;
 
 /* ---- noise estimate (svt_estimate_noise_fp16 / svt_estimate_noise_highbd_fp16, aom_dsp_rtcd.h:874-877;
  * temporal_filtering.c:3668-3736): over the interior of one plane, the mean absolute Laplacian of the samples whose

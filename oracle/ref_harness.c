@@ -138,6 +138,7 @@ REF_API int ref_derive_me_params(int enc_mode, int width, int height, int qp, in
     return 0;
 }
 
+void ref_params_to_ctx(MeContext *me, const SvtHipMeParams *p);
 static void params_to_ctx(MeContext *me, const SvtHipMeParams *p) {
     me->hme_search_method      = p->hme_search_method ? FULL_SAD_SEARCH : SUB_SAD_SEARCH;
     me->me_search_method       = p->me_search_method ? FULL_SAD_SEARCH : SUB_SAD_SEARCH;
@@ -197,6 +198,10 @@ static void params_to_ctx(MeContext *me, const SvtHipMeParams *p) {
     me->temporal_layer_index             = p->temporal_layer_index;
     me->is_ref                           = p->is_ref;
 }
+
+/* shared with ref_harness_tfme.c */
+void ref_params_to_ctx(MeContext *me, const SvtHipMeParams *p) { params_to_ctx(me, p); }
+void ref_b64_geom_init_pcs(SequenceControlSet *scs, PictureParentControlSet *pcs) { b64_geom_init_pcs(scs, pcs); }
 
 /* The b64 loop of me_process.c:174-290 around the real svt_aom_motion_estimation_b64.  Every pointer in
  * `job` is a host pointer.  Outputs follow include/svt_hip_me.h (SvtHipMeFrameOut). */

@@ -283,6 +283,33 @@ class TfOut(C.Structure):                # SvtHipTfOut
     _fields_ = [("dst", C.c_void_p * 3), ("dst_stride", C.c_uint32 * 3), ("pad_", C.c_uint32)]
 
 
+TF_MAX_REFS = 32
+
+
+class TfCtrls(C.Structure):              # SvtHipTfCtrls
+    _fields_ = [("half_pel_mode", C.c_uint8), ("quarter_pel_mode", C.c_uint8), ("eight_pel_mode", C.c_uint8), ("use_2tap", C.c_uint8),
+                ("sub_sampling_shift", C.c_uint8), ("use_pred_64x64_only_th", C.c_uint8), ("subpel_early_exit_th", C.c_uint8),
+                ("use_8bit_subpel", C.c_uint8), ("use_zz_based_filter", C.c_uint8), ("enable_8x8_pred", C.c_uint8), ("pad_", C.c_uint8 * 6),
+                ("pred_error_32x32_th", C.c_uint64)]
+
+
+class TfPic(C.Structure):                # SvtHipTfPic
+    _fields_ = [("pyr", Pyramid8), ("chroma8", C.c_void_p * 2), ("chroma8_stride", C.c_uint32), ("pad_", C.c_uint32), ("hbd", C.c_void_p * 3),
+                ("picture_number", C.c_uint64)]
+
+
+class TfPictureJob(C.Structure):         # SvtHipTfPictureJob
+    _fields_ = [("me", MeParams), ("ctrls", TfCtrls), ("decay_factor_fp16", C.c_uint32 * 3), ("mv_dist_th", C.c_uint16), ("chroma", C.c_uint8),
+                ("bit_depth", C.c_uint8), ("mi_rows", C.c_uint32), ("mi_cols", C.c_uint32), ("n_refs", C.c_uint32), ("centre", TfPic),
+                ("ref", TfPic * TF_MAX_REFS), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64), ("tot_blks", C.c_void_p)]
+
+
+class TfB64State(C.Structure):           # SvtHipTfB64State
+    _fields_ = [("err64", C.c_uint64), ("err32", C.c_uint64 * 4), ("err16", C.c_uint64 * 16), ("mv64_x", C.c_int16), ("mv64_y", C.c_int16),
+                ("mv32_x", C.c_int16 * 4), ("mv32_y", C.c_int16 * 4), ("mv16_x", C.c_int16 * 16), ("mv16_y", C.c_int16 * 16),
+                ("split32", C.c_uint8 * 4), ("use_64x64", C.c_uint8), ("pad_", C.c_uint8 * 3)]
+
+
 class Mv(C.Structure):                   # SvtHipMv == MV (block_structures.h:26-29)
     _fields_ = [("row", C.c_int16), ("col", C.c_int16)]
 
