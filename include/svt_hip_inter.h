@@ -69,7 +69,7 @@ typedef struct SvtHipConvolveDesc {
                              * left / above and taps/2 to the right / below */
     void       *dst;
     uint32_t    src_stride, dst_stride; /* in samples */
-    uint16_t    w, h;                   /* 2 .. 128 */
+    uint16_t    w, h;                   /* 2 .. 128; a descriptor with w == 0 or h == 0 is skipped */
     int16_t     filter_x[8], filter_y[8]; /* the kernels of this block's sub-pel phases (av1_get_interp_filter_subpel_kernel) */
     uint8_t     taps_x, taps_y;         /* 0, or an even number <= 8 */
     uint8_t     round_0, round_1;       /* ConvolveParams of get_conv_params (convolve.h:40-68) */

@@ -118,6 +118,8 @@ typedef struct SvtHipTfPictureJob {
 } SvtHipTfPictureJob;
 
 SVT_HIP_API uint64_t svt_hip_tf_workspace_bytes(uint32_t width, uint32_t height, uint32_t n_refs);
+/* byte offset inside the workspace of SvtHipTfB64State[n_b64] of reference picture `ref` (valid after the call has run) */
+SVT_HIP_API uint64_t svt_hip_tf_workspace_state_offset(uint32_t width, uint32_t height, uint32_t n_refs, uint32_t ref);
 /* `job` is a HOST struct, every pointer inside is device memory.  Asynchronous on `stream`. */
 SVT_HIP_API int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void *stream);
 

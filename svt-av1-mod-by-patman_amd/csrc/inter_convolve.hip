@@ -47,6 +47,8 @@ __global__ __launch_bounds__(256) void convolve_sr_kernel(const SvtHipConvolveDe
     __shared__ uint16_t in[(TILE + 7) * IP];
     __shared__ int16_t  im[(TILE + 7) * TILE];
     const SvtHipConvolveDesc d = descs[blockIdx.x];
+    if (d.w == 0 || d.h == 0)  // an unused slot of a fixed-size descriptor array (tf_picture.hip)
+        return;
     const int tiles_x = (d.w + TILE - 1) / TILE;
     const int x0 = (blockIdx.y % tiles_x) * TILE, y0 = (blockIdx.y / tiles_x) * TILE;
     if (y0 >= d.h)

@@ -1,0 +1,605 @@
+// tf_picture.hip — the temporal filter's block loop for one centre picture on gfx950 (the motion half).
+// Replaces produce_temporally_filtered_pic (temporal_filtering.c:2752-3308): per reference picture ME_MCTF motion estimation
+// (me_frame.hip), then — this file — tf_64x64 / tf_32x32 / tf_16x16_sub_pel_search (:1531-2104), tf_use_64x64_pred (:2646), the
+// 64-vs-32 and 32-vs-16 decisions (:3118-3245, derive_tf_32x32_block_split_flag :236-285), the descriptors of the final
+// sharp-filter predictions (tf_64x64 / tf_32x32_inter_prediction :2226-2576, run by inter_convolve.hip),
+// convert_64x64_info_to_32x32_info (:2661-2728) and the SvtHipTfBlock records the accumulate stage (tf_filter.hip) consumes.
+//
+// tf_refine_kernel: one workgroup per (reference picture, 64x64 block).  The source block lives in LDS for the whole search;
+// each square sub-block search stages ONE reference window (block + 10 samples each side: the 7/8-sample drift of the three
+// refinement rounds, the 8-tap margin and the doubled row step of the sub-sampled centre position) and evaluates every
+// candidate position from it: horizontal pass -> int16 intermediate in LDS -> vertical pass -> difference to the source ->
+// sum / sum of squares by wave shuffles.  The search itself is sequential in the reference (a position is skipped when the best
+// distortion so far is zero or below the early-exit threshold); every lane carries the same best distortion / vector, so the
+// control flow stays uniform and the skip rules are applied exactly as written.
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/svt_hip_inter.h"
+#include "../../include/svt_hip_tf.h"
+#include "common.hpp"
+
+using namespace svthip;
+
+namespace {
+
+// the AV1 interpolation kernels (inter_prediction.c:223-300): regular, sharp, bilinear — 16 phases x 8 taps
+__device__ const int16_t TF_KERNELS[3][16][8] = {
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 2, -6, 126, 8, -2, 0, 0}, {0, 2, -10, 122, 18, -4, 0, 0}, {0, 2, -12, 116, 28, -8, 2, 0},
+     {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -14, 102, 48, -12, 2, 0}, {0, 2, -16, 94, 58, -12, 2, 0}, {0, 2, -14, 84, 66, -12, 2, 0},
+     {0, 2, -14, 76, 76, -14, 2, 0}, {0, 2, -12, 66, 84, -14, 2, 0}, {0, 2, -12, 58, 94, -16, 2, 0}, {0, 2, -12, 48, 102, -14, 2, 0},
+     {0, 2, -10, 38, 110, -14, 2, 0}, {0, 2, -8, 28, 116, -12, 2, 0}, {0, 0, -4, 18, 122, -10, 2, 0}, {0, 0, -2, 8, 126, -6, 2, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {-2, 2, -6, 126, 8, -2, 2, 0}, {-2, 6, -12, 124, 16, -6, 4, -2}, {-2, 8, -18, 120, 26, -10, 6, -2},
+     {-4, 10, -22, 116, 38, -14, 6, -2}, {-4, 10, -22, 108, 48, -18, 8, -2}, {-4, 10, -24, 100, 60, -20, 8, -2},
+     {-4, 10, -24, 90, 70, -22, 10, -2}, {-4, 12, -24, 80, 80, -24, 12, -4}, {-2, 10, -22, 70, 90, -24, 10, -4},
+     {-2, 8, -20, 60, 100, -24, 10, -4}, {-2, 8, -18, 48, 108, -22, 10, -4}, {-2, 6, -14, 38, 116, -22, 10, -4},
+     {-2, 6, -10, 26, 120, -18, 8, -2}, {-2, 4, -6, 16, 124, -12, 6, -2}, {0, 2, -2, 8, 126, -6, 2, -2}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, 0, 120, 8, 0, 0, 0}, {0, 0, 0, 112, 16, 0, 0, 0}, {0, 0, 0, 104, 24, 0, 0, 0},
+     {0, 0, 0, 96, 32, 0, 0, 0}, {0, 0, 0, 88, 40, 0, 0, 0}, {0, 0, 0, 80, 48, 0, 0, 0}, {0, 0, 0, 72, 56, 0, 0, 0},
+     {0, 0, 0, 64, 64, 0, 0, 0}, {0, 0, 0, 56, 72, 0, 0, 0}, {0, 0, 0, 48, 80, 0, 0, 0}, {0, 0, 0, 40, 88, 0, 0, 0},
+     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 24, 104, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}, {0, 0, 0, 8, 120, 0, 0, 0}}};
+enum { K_REGULAR = 0, K_SHARP = 1, K_BILINEAR = 2 };
+constexpr int WIN_MARGIN = 10, WP = 64 + 2 * WIN_MARGIN + 1 /* odd pitch */, IM_ROWS = 64 + 14;
+constexpr int DESC_PER_B64 = 48;
+
+struct PicPlanes {  // one picture of the window; every pointer at sample (0,0) of its plane
+    const uint8_t  *y8, *c8[2];
+    const uint16_t *y16, *c16[2];
+    uint32_t        stride, stride_c;
+};
+struct RefineArgs {  // uniform for the call
+    SvtHipTfCtrls ctrls;
+    PicPlanes     centre;
+    uint32_t      decay[3];
+    uint32_t      tf_me_exit_th;
+    int32_t       mi_rows, mi_cols;
+    uint32_t      nb, bw;
+    int64_t       idx_min, idx_max;  // first / last sample of a padded luma plane relative to its sample (0,0)
+    uint16_t      mv_dist_th;
+    uint8_t       bit_depth, chroma;
+    uint32_t     *accum;  // [nb][3][4096]
+    uint16_t     *count;  // [nb][3][4096]
+};
+struct RefineRef {  // per reference picture
+    PicPlanes                   pic;
+    const uint32_t             *best_mv, *best_sad;  // [nb][2][4][85]
+    const SvtHipMeSearchResult *sr;                  // [nb][2][4]
+    uint8_t                    *pred;                // [nb][3][4096] samples of the filter's depth
+    SvtHipTfB64State           *state;               // [nb]
+    SvtHipConvolveDesc         *desc;                // [nb][48]
+    SvtHipTfBlock              *blocks;              // [nb][4]
+};
+
+__device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int32_t rnd(int32_t v, int n) { return (v + ((1 << n) >> 1)) >> n; }
+
+// compute_subpel_params + clamp_mv_to_umv_border_sb (enc_inter_prediction.c:28-48, 3166-3177) for a bw x bh block of a plane
+// with sub-sampling ss that belongs to the luma block (lx, ly, lsize): 1/16-sample column / row
+__device__ __forceinline__ void clamp_mv(int32_t mi_rows, int32_t mi_cols, int bw, int bh, int mvx, int mvy, int ss, int lx, int ly, int lsize,
+                                         int &col, int &row) {
+    const int     mirow = ly >> 2, micol = lx >> 2, bmi = lsize >> 2;
+    const int32_t to_top = -((mirow * 4) * 8), to_bottom = ((mi_rows - bmi - mirow) * 4) * 8;
+    const int32_t to_left = -((micol * 4) * 8), to_right = ((mi_cols - bmi - micol) * 4) * 8;
+    const int32_t spel_left = (4 + bw) << 4, spel_right = spel_left - 16, spel_top = (4 + bh) << 4, spel_bottom = spel_top - 16;
+    const int     m = 1 << (1 - ss);
+    col = (int16_t)clampi((int16_t)(mvx * m), to_left * m - spel_left, to_right * m + spel_right);
+    row = (int16_t)clampi((int16_t)(mvy * m), to_top * m - spel_top, to_bottom * m + spel_bottom);
+}
+
+struct Lds {
+    uint16_t src[64 * 64];
+    uint16_t win[(64 + 2 * WIN_MARGIN) * WP];
+    int16_t  im[IM_ROWS * 64];
+    int64_t  red_sum[4];
+    uint64_t red_sse[4];
+    uint64_t dist;
+};
+
+struct SearchCtx {
+    const RefineArgs *a;
+    const void       *ref0;  // search-depth luma of the reference picture
+    uint32_t          ref_stride;
+    int               ox, oy, is16, bd;
+};
+
+template <bool S16>
+__device__ __forceinline__ uint32_t ldg(const void *p, ptrdiff_t i) {
+    if (S16)
+        return ((const __attribute__((address_space(1))) uint16_t *)p)[i];
+    return ((const __attribute__((address_space(1))) uint8_t *)p)[i];
+}
+
+// distortion of ONE candidate vector from the staged window: prediction (svt_inter_predictor semantics, round_0 = 3,
+// round_1 = 11) against the source, fn_ptr->vf / vf_hbd_10 over every (1 << vshift)-th row.  Returns the same value on every lane.
+__device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int bsize, int lx, int ly, int kernel, int col, int row, int wx0, int wy0,
+                                  int tstep_log2, int vshift) {
+    const int tid = threadIdx.x, sx = col & 15, sy = row & 15, bd = s.bd;
+    const int px = s.ox + lx + (col >> 4) - wx0, py = s.oy + ly + (row >> 4) - wy0;  // block sample (0,0) in window coordinates
+    const int tstep = 1 << tstep_log2, rows_out = bsize >> vshift;
+    const int16_t *fx = TF_KERNELS[kernel][sx], *fy = TF_KERNELS[kernel][sy];
+    const int      k0 = kernel == K_BILINEAR ? 3 : 0, k1 = kernel == K_BILINEAR ? 5 : 8;  // the other bilinear taps are zero
+    const int      lb = 31 - __clz(bsize);
+    if (sx && sy) {  // svt_av1_[highbd_]convolve_2d_sr_c: horizontal pass over rows -3*tstep .. bsize-1 + 4*tstep
+        const int im_rows = bsize + 7 * tstep;
+        for (int i = tid; i < im_rows << lb; i += 256) {
+            const int r = i >> lb, c = i & (bsize - 1);
+            int32_t   sum = 1 << (bd + 7 - 1);
+            const uint16_t *w = &L.win[(py + r - 3 * tstep) * WP + px + c - 3];
+            for (int k = k0; k < k1; k++) sum += fx[k] * (int32_t)w[k];
+            L.im[(r << lb) + c] = (int16_t)(uint16_t)rnd(sum, 3);
+        }
+        __syncthreads();
+    }
+    int64_t  sum = 0;
+    uint64_t sse = 0;
+    for (int i = tid; i < rows_out << lb; i += 256) {
+        const int ro = i >> lb, c = i & (bsize - 1), r = ro << vshift;
+        int32_t   p;
+        if (sx && sy) {
+            const int offset_bits = bd + 2 * 7 - 3;
+            int32_t   v = 1 << offset_bits;
+            for (int k = k0; k < k1; k++) v += fy[k] * (int32_t)L.im[((r + k * tstep) << lb) + c];
+            int32_t res = rnd(v, 11) - ((1 << (offset_bits - 11)) + (1 << (offset_bits - 11 - 1)));
+            if (!s.is16)
+                res = (int16_t)res;
+            p = res;
+        } else if (sx) {  // x_sr
+            int32_t v = 0;
+            const uint16_t *w = &L.win[(py + r) * WP + px + c - 3];
+            for (int k = k0; k < k1; k++) v += fx[k] * (int32_t)w[k];
+            p = rnd(rnd(v, 3), 4);
+        } else if (sy) {  // y_sr
+            int32_t v = 0;
+            for (int k = k0; k < k1; k++) v += fy[k] * (int32_t)L.win[(py + r + (k - 3) * tstep) * WP + px + c];
+            p = rnd(v, 7);
+        } else {
+            p = L.win[(py + r) * WP + px + c];
+        }
+        const int32_t hi = (1 << bd) - 1;
+        p = (sx || sy) ? (p < 0 ? 0 : (p > hi ? hi : p)) : p;
+        const int32_t d = p - (int32_t)L.src[(ly + r) * 64 + lx + c];
+        sum += d, sse += (uint32_t)(d * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64), sse += __shfl_xor(sse, off, 64);
+    __syncthreads();  // the previous position's result has been read by everybody
+    if ((tid & 63) == 0)
+        L.red_sum[tid >> 6] = sum, L.red_sse[tid >> 6] = sse;
+    __syncthreads();
+    const int64_t  tsum = L.red_sum[0] + L.red_sum[1] + L.red_sum[2] + L.red_sum[3];
+    const uint64_t tsse = L.red_sse[0] + L.red_sse[1] + L.red_sse[2] + L.red_sse[3];
+    const int32_t  n    = bsize * rows_out;
+    uint64_t       var;
+    if (!s.is16) {  // svt_aom_variance*_c
+        const int32_t s32 = (int32_t)tsum;
+        var = (uint32_t)((uint32_t)tsse - (uint32_t)(((int64_t)s32 * s32) / n));
+    } else {  // svt_aom_highbd_10_variance*_c
+        const uint32_t e = (uint32_t)((tsse + 8) >> 4);
+        const int32_t  m = (int32_t)((tsum + 2) >> 2);
+        const int64_t  v = (int64_t)e - (((int64_t)m * m) / n);
+        var = v >= 0 ? (uint32_t)v : 0;
+    }
+    return var << vshift;
+}
+
+// tf_subpel_search of one square block; best / bx / by are uniform over the workgroup
+template <bool S16>
+__device__ void subpel_search(Lds &L, const SearchCtx &s, int bsize, int lx, int ly, int kernel, uint64_t &best, int &bx, int &by) {
+    const SvtHipTfCtrls &c = s.a->ctrls;
+    const int tid = threadIdx.x;
+    // window around the (clamped) starting vector
+    int col0, row0;
+    clamp_mv(s.a->mi_rows, s.a->mi_cols, bsize, bsize, bx, by, 0, s.ox + lx, s.oy + ly, bsize, col0, row0);
+    const int wx0 = s.ox + lx + (col0 >> 4) - WIN_MARGIN, wy0 = s.oy + ly + (row0 >> 4) - WIN_MARGIN, wd = bsize + 2 * WIN_MARGIN;
+    __syncthreads();  // the previous search is done with the window
+    for (int i = tid; i < wd * wd; i += 256) {
+        const int r = i / wd, cc = i - r * wd;
+        // the margin rows / columns nobody reads may lie outside the padded plane: keep the address inside it
+        int64_t idx = (int64_t)(wy0 + r) * s.ref_stride + wx0 + cc;
+        idx         = idx < s.a->idx_min ? s.a->idx_min : (idx > s.a->idx_max ? s.a->idx_max : idx);
+        L.win[r * WP + cc] = (uint16_t)ldg<S16>(s.ref0, (ptrdiff_t)idx);
+    }
+    __syncthreads();
+    const int modes[3] = {c.half_pel_mode, c.quarter_pel_mode, c.eight_pel_mode};
+    for (int round = -1; round < 3; round++) {
+        if (round >= 0 && !modes[round])
+            continue;
+        const int mode = round < 0 ? c.half_pel_mode : modes[round], step = round < 0 ? 0 : (4 >> round);
+        const int cx = bx, cy = by;
+        for (int i = -1; i <= 1; i++)
+            for (int j = -1; j <= 1; j++) {
+                const int xd = i * step, yd = j * step;
+                if (round < 0 ? (i || j) : (!i && !j))
+                    continue;
+                if (mode >= 2 && xd != 0 && yd != 0)  // svt_check_position
+                    continue;
+                if (best == 0)
+                    continue;
+                if (c.subpel_early_exit_th && best < (((uint64_t)(bsize * bsize) * c.subpel_early_exit_th) << s.is16))
+                    continue;
+                const int mvx = (int16_t)(cx + xd), mvy = (int16_t)(cy + yd);
+                int       col, row;
+                clamp_mv(s.a->mi_rows, s.a->mi_cols, bsize, bsize, mvx, mvy, 0, s.ox + lx, s.oy + ly, bsize, col, row);
+                const int      tl = (xd == 0 && yd == 0) ? c.sub_sampling_shift : 0;
+                const uint64_t d  = eval_position(L, s, bsize, lx, ly, kernel, col, row, wx0, wy0, tl, c.sub_sampling_shift);
+                if (d < best)
+                    best = d, bx = mvx, by = mvy;
+            }
+    }
+}
+
+__device__ __forceinline__ int mvx_of(uint32_t mv) { return (int16_t)(mv & 0xffff); }
+__device__ __forceinline__ int mvy_of(uint32_t mv) { return (int16_t)(mv >> 16); }
+
+// the static part of one SvtHipTfBlock (32x32 block q of b64 b)
+__device__ void fill_block(const RefineArgs &a, uint32_t b, int q, const uint8_t *pred, SvtHipTfBlock &t) {
+    const int is16 = a.bit_depth > 8, lx = (q & 1) * 32, ly = (q >> 1) * 32;
+    const int ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64;
+    memset(&t, 0, sizeof(t));
+    for (int p = 0; p < 3; p++) {
+        const int       ss = p ? 1 : 0, ps = p ? 32 : 64;
+        const size_t    stride = p ? a.centre.stride_c : a.centre.stride;
+        const size_t    org = (size_t)((oy + ly) >> ss) * stride + ((ox + lx) >> ss);
+        const uint8_t  *base = is16 ? (const uint8_t *)(p ? a.centre.c16[p - 1] : a.centre.y16) : (p ? a.centre.c8[p - 1] : a.centre.y8);
+        const size_t    po = (size_t)(ly >> ss) * ps + (lx >> ss);
+        t.src[p]   = base + (org << is16);
+        t.pred[p]  = pred + ((((size_t)b * 3 + p) * 4096 + po) << is16);
+        t.accum[p] = a.accum + ((size_t)b * 3 + p) * 4096 + po;
+        t.count[p] = a.count + ((size_t)b * 3 + p) * 4096 + po;
+        t.src_stride[p] = (uint32_t)stride, t.pred_stride[p] = (uint32_t)ps;
+        t.decay_factor_fp16[p] = a.decay[p];
+    }
+    t.mv_dist_th = a.mv_dist_th, t.chroma = a.chroma, t.ss_x = t.ss_y = 1;
+    t.is_16bit = (uint8_t)is16, t.bit_depth = a.bit_depth, t.zz_based = a.ctrls.use_zz_based_filter;
+}
+
+template <bool S16>
+__global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const RefineRef *__restrict__ refs, uint32_t *__restrict__ tot) {
+    __shared__ Lds              L;
+    __shared__ SvtHipTfB64State st;
+    const RefineRef     R = refs[blockIdx.y];
+    const uint32_t      b = blockIdx.x;
+    const int           tid = threadIdx.x, ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64;
+    const SvtHipTfCtrls &c = a.ctrls;
+    SearchCtx s;
+    s.a = &a, s.ox = ox, s.oy = oy, s.is16 = S16, s.bd = S16 ? a.bit_depth : 8;
+    s.ref0 = S16 ? (const void *)R.pic.y16 : (const void *)R.pic.y8, s.ref_stride = R.pic.stride;
+    const void *src0 = S16 ? (const void *)a.centre.y16 : (const void *)a.centre.y8;
+    for (int i = tid; i < 64 * 64; i += 256) L.src[i] = (uint16_t)ldg<S16>(src0, (ptrdiff_t)(oy + (i >> 6)) * a.centre.stride + ox + (i & 63));
+    for (int i = tid; i < (int)(sizeof(st) / 4); i += 256) ((uint32_t *)&st)[i] = 0;
+    const SvtHipMeSearchResult sr = R.sr[(size_t)b * 8];
+    const uint32_t *best_mv = R.best_mv + (size_t)b * 8 * 85, *best_sad = R.best_sad + (size_t)b * 8 * 85;
+    if (tid == 0 && tot)
+        atomicAdd(&tot[abs((int)sr.hme_sc_x) > abs((int)sr.hme_sc_y) ? 0 : 1], 1u);
+    // svt_aom_motion_estimation_b64 leaves after HME when the HME distortion is below tf_me_exit_th (motion_estimation.c:3179)
+    const int use64_th = sr.hme_sad < a.tf_me_exit_th ? 255 : c.use_pred_64x64_only_th;
+    const int k6432 = c.use_2tap ? K_BILINEAR : K_REGULAR;
+    // ---- tf_64x64_sub_pel_search
+    uint64_t err64 = 0x7fffffff;
+    int      mv64x = (int16_t)((use64_th == 255 ? sr.hme_sc_x : mvx_of(best_mv[0])) << 3);
+    int      mv64y = (int16_t)((use64_th == 255 ? sr.hme_sc_y : mvy_of(best_mv[0])) << 3);
+    subpel_search<S16>(L, s, 64, 0, 0, k6432, err64, mv64x, mv64y);
+    bool use64 = false;
+    if (use64_th) {
+        if (use64_th == 255) {
+            use64 = true;
+        } else {  // tf_use_64x64_pred
+            uint32_t d32 = 0;
+            for (int i = 0; i < 4; i++) d32 += best_sad[1 + i];
+            const int64_t x = best_sad[0] > 1 ? best_sad[0] : 1, y = d32 > 1 ? d32 : 1;
+            use64 = ((x - y) * 100) / y < use64_th;
+        }
+    }
+    uint64_t err32[4] = {0, 0, 0, 0};
+    int      mv32x[4] = {0, 0, 0, 0}, mv32y[4] = {0, 0, 0, 0};
+    if (!use64) {
+        uint64_t sum32 = 0;
+        for (int i = 0; i < 4; i++) {
+            err32[i] = 0x7fffffff;
+            mv32x[i] = (int16_t)(mvx_of(best_mv[1 + i]) << 3), mv32y[i] = (int16_t)(mvy_of(best_mv[1 + i]) << 3);
+            subpel_search<S16>(L, s, 32, (i & 1) * 32, (i >> 1) * 32, k6432, err32[i], mv32x[i], mv32y[i]);
+            sum32 += err32[i];
+        }
+        if (err64 * 14 < sum32 * 16 && err64 < (1u << 18))
+            use64 = true;
+    }
+    if (!use64) {
+        for (int i = 0; i < 4; i++) {
+            const int lx = (i & 1) * 32, ly = (i >> 1) * 32;
+            if (err32[i] < c.pred_error_32x32_th)
+                continue;  // split flag stays 0
+            // tf_16x16_sub_pel_search (always the regular 8-tap kernel), derive_tf_32x32_block_split_flag without 8x8
+            int64_t sum16 = 0;
+            for (int k = 0; k < 4; k++) {
+                const int q  = i * 4 + k;
+                uint64_t  e  = 0x7fffffff;
+                int       mx = (int16_t)(mvx_of(best_mv[5 + q]) << 3), my = (int16_t)(mvy_of(best_mv[5 + q]) << 3);
+                subpel_search<S16>(L, s, 16, lx + (k & 1) * 16, ly + (k >> 1) * 16, K_REGULAR, e, mx, my);
+                sum16 += (int)e;
+                if (tid == 0)
+                    st.err16[q] = e, st.mv16_x[q] = (int16_t)mx, st.mv16_y[q] = (int16_t)my;
+            }
+            if (tid == 0)
+                st.split32[i] = !((int)err32[i] * 14 < (int)sum16 * 16);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        st.err64 = err64, st.mv64_x = (int16_t)mv64x, st.mv64_y = (int16_t)mv64y, st.use_64x64 = use64;
+        for (int i = 0; i < 4; i++) st.err32[i] = err32[i], st.mv32_x[i] = (int16_t)mv32x[i], st.mv32_y[i] = (int16_t)mv32y[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)(sizeof(st) / 4); i += 256) ((uint32_t *)&R.state[b])[i] = ((const uint32_t *)&st)[i];
+    // ---- descriptors of the final predictions (sharp kernel, the filter's bit depth): 16 luma + 16 + 16 chroma slots
+    if (tid < DESC_PER_B64) {
+        const int plane = tid / 16, idx = tid % 16, q = idx >> 2, k = idx & 3;
+        const int is16 = a.bit_depth > 8;
+        int       lx, ly, bsz, mx, my;
+        bool      on;
+        if (st.use_64x64) {
+            on = idx == 0, lx = ly = 0, bsz = 64, mx = st.mv64_x, my = st.mv64_y;
+        } else if (st.split32[q]) {
+            on = true, lx = (q & 1) * 32 + (k & 1) * 16, ly = (q >> 1) * 32 + (k >> 1) * 16, bsz = 16, mx = st.mv16_x[idx], my = st.mv16_y[idx];
+        } else {
+            on = k == 0, lx = (q & 1) * 32, ly = (q >> 1) * 32, bsz = 32, mx = st.mv32_x[q], my = st.mv32_y[q];
+        }
+        on = on && (plane == 0 || a.chroma);
+        SvtHipConvolveDesc d;
+        memset(&d, 0, sizeof(d));
+        if (on) {
+            const int ss = plane ? 1 : 0, bw = bsz >> ss;
+            int       col, row;
+            clamp_mv(a.mi_rows, a.mi_cols, bw, bw, mx, my, ss, ox + lx, oy + ly, bsz, col, row);
+            const int pre_x = plane ? (((ox + lx) >> 3) << 3) / 2 : ox + lx, pre_y = plane ? (((oy + ly) >> 3) << 3) / 2 : oy + ly;
+            const int dx = plane ? ((lx >> 3) << 3) / 2 : lx, dy = plane ? ((ly >> 3) << 3) / 2 : ly, ps = plane ? 32 : 64;
+            const uint32_t stride = plane ? R.pic.stride_c : R.pic.stride;
+            const uint8_t *base = is16 ? (const uint8_t *)(plane ? R.pic.c16[plane - 1] : R.pic.y16) : (plane ? R.pic.c8[plane - 1] : R.pic.y8);
+            const int sx = col & 15, sy = row & 15;
+            d.src        = base + ((((ptrdiff_t)(pre_y + (row >> 4))) * (ptrdiff_t)stride + pre_x + (col >> 4)) * (is16 ? 2 : 1));
+            d.dst        = R.pred + ((((size_t)b * 3 + plane) * 4096 + (size_t)dy * ps + dx) << is16);
+            d.src_stride = stride, d.dst_stride = (uint32_t)ps, d.w = d.h = (uint16_t)bw;
+            for (int t = 0; t < 8; t++) d.filter_x[t] = TF_KERNELS[K_SHARP][sx][t], d.filter_y[t] = TF_KERNELS[K_SHARP][sy][t];
+            d.taps_x = sx ? 8 : 0, d.taps_y = sy ? 8 : 0, d.round_0 = 3, d.round_1 = 11;
+            d.bit_depth = a.bit_depth, d.is_16bit = (uint8_t)is16;
+        }
+        R.desc[(size_t)b * DESC_PER_B64 + tid] = d;
+    }
+}
+
+// after the predictions: convert_64x64_info_to_32x32_info for the blocks predicted as one 64x64, and the four SvtHipTfBlock
+// records of every block.  blockIdx.y == n_refs writes the reference-independent records used by the central / normalise
+// launches (and their SvtHipTfOut).
+__global__ __launch_bounds__(256) void tf_blocks_kernel(RefineArgs a, const RefineRef *__restrict__ refs, uint32_t n_refs,
+                                                        SvtHipTfBlock *__restrict__ static_blocks, SvtHipTfOut *__restrict__ outs) {
+    __shared__ int64_t  rs[4][4];
+    __shared__ uint64_t re[4][4];
+    const uint32_t b = blockIdx.x;
+    const int      tid = threadIdx.x;
+    if (blockIdx.y == n_refs) {
+        if (tid < 4) {
+            SvtHipTfBlock t;
+            fill_block(a, b, tid, refs[0].pred, t);
+            static_blocks[(size_t)b * 4 + tid] = t;
+            SvtHipTfOut o;
+            memset(&o, 0, sizeof(o));
+            for (int p = 0; p < 3; p++) o.dst[p] = (void *)t.src[p], o.dst_stride[p] = t.src_stride[p];
+            outs[(size_t)b * 4 + tid] = o;
+        }
+        return;
+    }
+    const RefineRef   R = refs[blockIdx.y];
+    SvtHipTfB64State *st = &R.state[b];
+    const int is16 = a.bit_depth > 8, ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64;
+    if (st->use_64x64) {  // uniform over the workgroup
+        const int      sh = a.ctrls.sub_sampling_shift;
+        const uint8_t *pred = R.pred + (((size_t)b * 3) * 4096 << is16);
+        const void    *src0 = is16 ? (const void *)a.centre.y16 : (const void *)a.centre.y8;
+        int64_t        sum[4] = {0, 0, 0, 0};
+        uint64_t       sse[4] = {0, 0, 0, 0};
+        for (int i = tid; i < (64 >> sh) * 64; i += 256) {
+            const int r = (i >> 6) << sh, cc = i & 63, q = (r >> 5) * 2 + (cc >> 5);
+            const int32_t p = is16 ? ((const uint16_t *)pred)[r * 64 + cc] : pred[r * 64 + cc];
+            const int32_t v = is16 ? ldg<true>(src0, (ptrdiff_t)(oy + r) * a.centre.stride + ox + cc) : ldg<false>(src0, (ptrdiff_t)(oy + r) * a.centre.stride + ox + cc);
+            const int32_t d = p - v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) sum[k] += k == q ? d : 0, sse[k] += k == q ? (uint32_t)(d * d) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum[k] += __shfl_xor(sum[k], off, 64), sse[k] += __shfl_xor(sse[k], off, 64);
+            if ((tid & 63) == 0)
+                rs[tid >> 6][k] = sum[k], re[tid >> 6][k] = sse[k];
+        }
+        __syncthreads();
+        if (tid < 4) {
+            const int64_t  tsum = rs[0][tid] + rs[1][tid] + rs[2][tid] + rs[3][tid];
+            const uint64_t tsse = re[0][tid] + re[1][tid] + re[2][tid] + re[3][tid];
+            const int32_t  n = 32 * (32 >> sh);
+            uint64_t       var;
+            if (!is16) {
+                const int32_t s32 = (int32_t)tsum;
+                var = (uint32_t)((uint32_t)tsse - (uint32_t)(((int64_t)s32 * s32) / n));
+            } else {
+                const uint32_t e = (uint32_t)((tsse + 8) >> 4);
+                const int32_t  m = (int32_t)((tsum + 2) >> 2);
+                const int64_t  v = (int64_t)e - (((int64_t)m * m) / n);
+                var = v >= 0 ? (uint32_t)v : 0;
+            }
+            st->err32[tid] = var << sh, st->mv32_x[tid] = st->mv64_x, st->mv32_y[tid] = st->mv64_y, st->split32[tid] = 0;
+        }
+        __syncthreads();
+    }
+    if (tid < 4) {
+        SvtHipTfBlock t;
+        fill_block(a, b, tid, R.pred, t);
+        t.split = st->split32[tid];
+        if (t.split) {
+            for (int k = 0; k < 4; k++) t.block_error[k] = st->err16[tid * 4 + k], t.mv_x[k] = st->mv16_x[tid * 4 + k], t.mv_y[k] = st->mv16_y[tid * 4 + k];
+        } else {
+            t.block_error[0] = st->err32[tid], t.mv_x[0] = st->mv32_x[tid], t.mv_y[0] = st->mv32_y[tid];
+        }
+        R.blocks[(size_t)b * 4 + tid] = t;
+    }
+}
+
+struct Layout {  // workspace, in bytes from its start (all 256-byte aligned)
+    size_t best_sad, best_mv, sr, me_scratch, states, desc, blocks, static_blocks, outs, pred, accum, count, refs, total;
+    size_t per_ref_best, per_ref_sr, per_ref_state, per_ref_desc, per_ref_blocks, per_ref_pred;
+};
+size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+Layout layout(uint32_t width, uint32_t height, uint32_t n_refs, int px) {
+    Layout       l;
+    const size_t nb = (size_t)((width + 63) / 64) * ((height + 63) / 64), n = n_refs ? n_refs : 1;
+    size_t       o = 0;
+    l.per_ref_best = al(nb * 2 * 4 * 85 * 4), l.per_ref_sr = al(nb * 8 * sizeof(SvtHipMeSearchResult));
+    l.per_ref_state = al(nb * sizeof(SvtHipTfB64State)), l.per_ref_desc = al(nb * DESC_PER_B64 * sizeof(SvtHipConvolveDesc));
+    l.per_ref_blocks = al(nb * 4 * sizeof(SvtHipTfBlock)), l.per_ref_pred = al(nb * 3 * 4096 * px);
+    l.best_sad = o, o += l.per_ref_best * n;
+    l.best_mv = o, o += l.per_ref_best * n;
+    l.sr = o, o += l.per_ref_sr * n;
+    l.me_scratch = o, o += al(nb * 85 * 16 * 4);  // arrays the ME_MCTF mode never writes (all point here)
+    l.states = o, o += l.per_ref_state * n;
+    l.desc = o, o += l.per_ref_desc * n;
+    l.blocks = o, o += l.per_ref_blocks * n;
+    l.static_blocks = o, o += l.per_ref_blocks;
+    l.outs = o, o += al(nb * 4 * sizeof(SvtHipTfOut));
+    l.pred = o, o += l.per_ref_pred * n;
+    l.accum = o, o += al(nb * 3 * 4096 * 4);
+    l.count = o, o += al(nb * 3 * 4096 * 2);
+    l.refs = o, o += al(SVT_HIP_TF_MAX_REFS * sizeof(RefineRef));
+    l.total = o;
+    return l;
+}
+
+PicPlanes planes_of(const SvtHipTfPic &p) {
+    PicPlanes            q;
+    const SvtHipPlane8  &f = p.pyr.full;
+    const size_t         yo = (size_t)f.org_y * f.stride + f.org_x, co = (size_t)(f.org_y / 2) * p.chroma8_stride + f.org_x / 2;
+    q.y8 = f.buf + yo, q.stride = f.stride, q.stride_c = p.chroma8_stride;
+    for (int i = 0; i < 2; i++) q.c8[i] = p.chroma8[i] ? p.chroma8[i] + co : nullptr, q.c16[i] = p.hbd[i + 1] ? p.hbd[i + 1] + co : nullptr;
+    q.y16 = p.hbd[0] ? p.hbd[0] + yo : nullptr;
+    return q;
+}
+
+}  // namespace
+
+extern "C" uint64_t svt_hip_tf_workspace_bytes(uint32_t width, uint32_t height, uint32_t n_refs) { return layout(width, height, n_refs, 2).total; }
+
+extern "C" uint64_t svt_hip_tf_workspace_state_offset(uint32_t width, uint32_t height, uint32_t n_refs, uint32_t ref) {
+    const Layout l = layout(width, height, n_refs, 2);
+    return l.states + l.per_ref_state * ref;
+}
+
+extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void *stream) {
+    auto bad = [](const char *m) {
+        set_error("svt_hip_tf_filter_picture: %s", m);
+        return (int32_t)SVT_HIP_ERR_BAD_PARAMETER;
+    };
+    if (!job)
+        return bad("NULL job");
+    const SvtHipPlane8 &f = job->centre.pyr.full;
+    if (job->n_refs == 0 || job->n_refs > SVT_HIP_TF_MAX_REFS)
+        return bad("n_refs must be 1 .. SVT_HIP_TF_MAX_REFS");
+    if (job->bit_depth != 8 && job->bit_depth != 10)
+        return bad("bit_depth must be 8 or 10");
+    if (job->ctrls.enable_8x8_pred)
+        return bad("8x8 prediction (enable_8x8_pred) is not provided");
+    if (job->ctrls.sub_sampling_shift > 1 || job->ctrls.use_2tap > 1)
+        return bad("sub_sampling_shift / use_2tap out of range");
+    if (!f.buf || f.width < 64 || f.height < 64 || f.org_x < 68 || f.org_y < 68 || (f.org_x & 1) || (f.org_y & 1))
+        return bad("centre picture: needs >= 64 x 64 samples and an even padding of >= 68 samples (the reference's 64 + 4)");
+    // every 64x64 block, the vectors the clamp allows around it and the 8-tap margin must stay inside the padded planes
+    const uint32_t cover_w = (f.width + 63) / 64 * 64 + 15, cover_h = (f.height + 63) / 64 * 64 + 15;
+    if (f.width + f.org_x < cover_w || f.height + f.org_y < cover_h || f.stride < f.width + 2u * f.org_x)
+        return bad("centre picture: padding does not cover the 64-aligned area + 15 samples");
+    const bool is16 = job->bit_depth > 8, chroma = job->chroma != 0;
+    auto pic_ok = [&](const SvtHipTfPic &p) {
+        const SvtHipPlane8 &g = p.pyr.full;
+        if (!g.buf || g.width != f.width || g.height != f.height || g.org_x != f.org_x || g.org_y != f.org_y || g.stride != f.stride)
+            return false;
+        if (p.chroma8_stride != job->centre.chroma8_stride)
+            return false;
+        if (chroma && !is16 && (!p.chroma8[0] || !p.chroma8[1]))
+            return false;
+        if (is16 && (!p.hbd[0] || (chroma && (!p.hbd[1] || !p.hbd[2]))))
+            return false;
+        return true;
+    };
+    if (!pic_ok(job->centre))
+        return bad("centre picture: planes missing");
+    if (chroma && job->centre.chroma8_stride * 2 != f.stride)
+        return bad("chroma stride must be half the luma stride (apply_filtering_central, temporal_filtering.c:356)");
+    for (uint32_t r = 0; r < job->n_refs; r++)
+        if (!pic_ok(job->ref[r]))
+            return bad("reference picture: geometry differs from the centre picture or planes missing");
+    const Layout l = layout(f.width, f.height, job->n_refs, 2);
+    if (!job->workspace || job->workspace_bytes < layout(f.width, f.height, job->n_refs, 2).total)
+        return bad("workspace too small (svt_hip_tf_workspace_bytes)");
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    hipStream_t    st = resolve_stream(stream);
+    uint8_t       *ws = (uint8_t *)job->workspace;
+    const uint32_t bw = (f.width + 63) / 64, nb = bw * ((f.height + 63) / 64);
+
+    // ---- ME_MCTF of the centre picture against every reference picture: one launch
+    SvtHipMeFrameJob *mj = new SvtHipMeFrameJob[job->n_refs];
+    RefineRef         refs[SVT_HIP_TF_MAX_REFS];
+    for (uint32_t r = 0; r < job->n_refs; r++) {
+        memset(&mj[r], 0, sizeof(mj[r]));
+        mj[r].prm = job->me;
+        mj[r].prm.me_mctf = 1, mj[r].prm.num_of_list_to_search = 1;
+        mj[r].prm.num_of_ref_pic_to_search[0] = 1, mj[r].prm.num_of_ref_pic_to_search[1] = 0;
+        mj[r].prm.picture_number = job->centre.picture_number, mj[r].prm.ref_picture_number[0][0] = job->ref[r].picture_number;
+        mj[r].src = job->centre.pyr, mj[r].ref[0][0] = job->ref[r].pyr;
+        SvtHipMeFrameOut &o = mj[r].out;
+        o.best_sad = (uint32_t *)(ws + l.best_sad + l.per_ref_best * r), o.best_mv = (uint32_t *)(ws + l.best_mv + l.per_ref_best * r);
+        o.search_results = (SvtHipMeSearchResult *)(ws + l.sr + l.per_ref_sr * r);
+        o.me_mv_array = (uint32_t *)(ws + l.me_scratch), o.me_candidate_array = ws + l.me_scratch, o.total_me_candidate_index = ws + l.me_scratch;
+        o.me_64x64_distortion = o.me_32x32_distortion = o.me_16x16_distortion = o.me_8x8_distortion = o.me_8x8_cost_variance = o.rc_me_distortion =
+            (uint32_t *)(ws + l.me_scratch);
+        refs[r].pic = planes_of(job->ref[r]);
+        refs[r].best_mv = o.best_mv, refs[r].best_sad = o.best_sad, refs[r].sr = o.search_results;
+        refs[r].pred = ws + l.pred + l.per_ref_pred * r;
+        refs[r].state = (SvtHipTfB64State *)(ws + l.states + l.per_ref_state * r);
+        refs[r].desc = (SvtHipConvolveDesc *)(ws + l.desc + l.per_ref_desc * r);
+        refs[r].blocks = (SvtHipTfBlock *)(ws + l.blocks + l.per_ref_blocks * r);
+    }
+    int32_t rc = svt_hip_me_frames(mj, job->n_refs, st);
+    delete[] mj;
+    if (rc != SVT_HIP_OK)
+        return rc;
+    RefineRef *d_refs = (RefineRef *)stage_descriptors(refs, sizeof(RefineRef) * job->n_refs, st);
+    if (!d_refs)
+        return SVT_HIP_ERR_RUNTIME;
+    RefineArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ctrls = job->ctrls, a.centre = planes_of(job->centre);
+    for (int p = 0; p < 3; p++) a.decay[p] = job->decay_factor_fp16[p];
+    a.tf_me_exit_th = job->me.tf_me_exit_th, a.mi_rows = (int32_t)job->mi_rows, a.mi_cols = (int32_t)job->mi_cols;
+    a.idx_min = -((int64_t)f.org_y * f.stride + f.org_x), a.idx_max = ((int64_t)f.height + f.org_y) * f.stride - f.org_x - 1;
+    a.nb = nb, a.bw = bw, a.mv_dist_th = job->mv_dist_th, a.bit_depth = job->bit_depth, a.chroma = chroma;
+    a.accum = (uint32_t *)(ws + l.accum), a.count = (uint16_t *)(ws + l.count);
+    SvtHipTfBlock *static_blocks = (SvtHipTfBlock *)(ws + l.static_blocks);
+    SvtHipTfOut   *outs = (SvtHipTfOut *)(ws + l.outs);
+    const bool     s16 = is16 && !job->ctrls.use_8bit_subpel;
+    if (s16)
+        hipLaunchKernelGGL(tf_refine_kernel<true>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
+    else
+        hipLaunchKernelGGL(tf_refine_kernel<false>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
+    SVT_HIP_CHECK(hipGetLastError());
+    // the final predictions of every (reference picture, block): the descriptor arrays are contiguous
+    for (uint32_t r = 0; r < job->n_refs; r++) {
+        rc = svt_hip_convolve_batch(refs[r].desc, nb * DESC_PER_B64, st);
+        if (rc != SVT_HIP_OK)
+            return rc;
+    }
+    hipLaunchKernelGGL(tf_blocks_kernel, dim3(nb, job->n_refs + 1), dim3(256), 0, st, a, d_refs, job->n_refs, static_blocks, outs);
+    SVT_HIP_CHECK(hipGetLastError());
+    stage_commit(st);
+    rc = svt_hip_tf_central_batch(static_blocks, nb * 4, st);
+    for (uint32_t r = 0; r < job->n_refs && rc == SVT_HIP_OK; r++) rc = svt_hip_tf_accumulate_batch(refs[r].blocks, nb * 4, st);
+    if (rc == SVT_HIP_OK)
+        rc = svt_hip_tf_normalise_batch(static_blocks, outs, nb * 4, st);
+    return rc;
+}
