@@ -1,0 +1,94 @@
+/*
+ * svt_hip_tpl.h — C-ABI for the TPL dispenser of one picture.
+ *
+ * Reference interface replaced (paths relative to /root/reference):
+ *   Source/Lib/Codec/src_ops_process.c:519-1207   tpl_mc_flow_dispenser_sb_generic, called per 64x64 block from
+ *                                                 tpl_mc_flow_dispenser (:1348-1410) / svt_aom_tpl_disp_kernel (:1964)
+ * for the configuration the reference runs at presets M7 ... M10 (tpl level 4 of set_tpl_params, initial_rc_process.c:359-370,
+ * and level 3 without its sub-pel refinement): 16x16 blocks (dispenser_search_level 0), DC intra prediction only
+ * (intra_mode_end == DC_PRED), SAD in the source-based search, full-pel vectors straight from the open-loop ME results,
+ * no transform sub-sampling, no rate estimate (compute_rate 0), any coefficient shape (pf_shape).  Per block:
+ *   source-based path  DC prediction from the SOURCE neighbours and its sub-sampled SAD; every single-reference ME candidate,
+ *                      vector clipped to the TPL padding, sub-sampled SAD against the reference's source picture; for an
+ *                      inter winner residual -> DCT 16x16 -> svt_av1_quantize_fp -> svt_av1_block_error  (srcrf_dist)
+ *   reconstruction     inter: the block of the reference's RECONSTRUCTION at that vector; intra: DC prediction from the
+ *                      reconstructed neighbours of this picture; residual -> DCT -> quantise -> error (recrf_dist) ->
+ *                      inverse transform + reconstruction into the TPL reconstruction picture
+ *   result_model_store TplStats on the 16x16 (or 8x8) grid, TplSrcStats
+ * The intra blocks depend on the reconstruction of their left / top / top-left neighbours: the kernel runs the source-based
+ * path of every block in parallel and orders only the reconstruction of intra blocks behind their neighbours' (flags in
+ * device memory).  The caller orders pictures (a reference picture's reconstruction must be complete before this call).
+ * Not provided: the other intra modes and the SATD source search (tpl levels 1, 2), sub-pel refinement (levels 1-3),
+ * 32x32 / 64x64 dispenser blocks with transform sub-sampling (level 5), the rate estimate.
+ */
+#ifndef SVT_HIP_TPL_H
+#define SVT_HIP_TPL_H
+
+#include "svt_hip.h"
+#include "svt_hip_me.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SvtHipTplStats { /* TplStats, coding_unit.h:312-321 */
+    int64_t  srcrf_dist, recrf_dist, srcrf_rate, recrf_rate, mc_dep_rate, mc_dep_dist;
+    int16_t  mv_row, mv_col;
+    uint32_t pad_;
+    uint64_t ref_frame_poc;
+} SvtHipTplStats;
+
+typedef struct SvtHipTplSrcStats { /* TplSrcStats, coding_unit.h:323-331 */
+    int64_t  srcrf_dist, srcrf_rate;
+    uint64_t ref_frame_poc;
+    int16_t  mv_row, mv_col;
+    int32_t  best_rf_idx;
+    uint8_t  best_mode;       /* PredictionMode: 0 DC_PRED, 16 NEWMV */
+    uint8_t  best_intra_mode; /* 0 */
+    uint8_t  pad_[6];
+} SvtHipTplSrcStats;
+
+typedef struct SvtHipTplRef { /* one entry of pcs->tpl_data.tpl_ref_ds_ptr_array[list][ref] */
+    const uint8_t *src;       /* luma of the reference's SOURCE picture, sample (0,0) (picture_ptr) */
+    const uint8_t *recon;     /* what the reconstruction path predicts from, sample (0,0): mc_flow_rec_picture_buffer of
+                               * that picture when ref_in_slide_window, else the same plane as src */
+    uint32_t       src_stride, recon_stride;
+    uint64_t       picture_number;
+    uint16_t       max_width, max_height; /* EbPictureBufferDesc::max_width / max_height of picture_ptr (the vector clip) */
+    uint8_t        usable;    /* 0: candidates of this reference are skipped (inside the window without valid TPL data, :780-782) */
+    uint8_t        pad_[3];
+} SvtHipTplRef;
+
+typedef struct SvtHipTplFrameJob {
+    SvtHipPlane8 src;    /* pcs->enhanced_pic luma */
+    SvtHipPlane8 recon;  /* enc_ctx->mc_flow_rec_picture_buffer[frame_idx] luma: written */
+    SvtHipTplRef ref[SVT_HIP_ME_MAX_LIST][SVT_HIP_ME_MAX_REF];
+    /* the open-loop ME results of this picture (SvtHipMeFrameOut of svt_hip_me_frames) */
+    const uint32_t *me_mv_array;
+    const uint8_t  *me_candidate_array, *total_me_candidate_index;
+    uint8_t  max_cand, max_refs, max_l0, enable_me_16x16; /* MotionEstimationData / pcs */
+    uint8_t  stored_pus;         /* PUs per b64 in the three arrays (svt_hip_me_stored_pus) */
+    uint8_t  pf_shape;           /* 0 default, 1 N2, 2 N4 (EB_TRANS_COEFF_SHAPE) */
+    uint8_t  disable_intra_pred; /* tpl_ctrls.disable_intra_pred_nref && temporal_layer_index == hierarchical_levels */
+    uint8_t  is_ref;             /* pcs->tpl_data.is_ref */
+    uint8_t  i_slice;            /* pcs->slice_type == I_SLICE: no ME candidates */
+    uint8_t  tpl_i_slice;        /* pcs->tpl_data.tpl_slice_type == I_SLICE */
+    uint8_t  src_data_ready;     /* pcs->tpl_src_data_ready: the source-based results are READ from src_stats */
+    uint8_t  store_src_stats;    /* scs->tpl_lad_mg > 0 */
+    uint8_t  synth_blk_size;     /* 16 or 8 (tpl_ctrls.synth_blk_size): grid of `stats` */
+    uint8_t  pad_[3];
+    /* quants_8bit / deq_8bit of the picture's qindex: [0] DC, [1] AC */
+    int16_t  round_fp[2], quant_fp[2], dequant[2];
+    uint16_t pad2_;
+    SvtHipTplStats    *stats;     /* [(aligned_h / blk)][stride]: stride = (aligned_width + 15) / 16 for 16, twice that for 8 */
+    SvtHipTplSrcStats *src_stats; /* [..][(aligned_width + 15) >> 4] */
+    uint32_t          *flags;     /* device scratch, one uint32 per 16x16 block of the 64-aligned picture; the call zeroes it */
+} SvtHipTplFrameJob;
+
+/* `job` is a HOST struct, every pointer inside is device memory.  Asynchronous on `stream`. */
+SVT_HIP_API int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_TPL_H */

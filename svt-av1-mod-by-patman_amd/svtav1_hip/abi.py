@@ -310,6 +310,32 @@ class TfB64State(C.Structure):           # SvtHipTfB64State
                 ("split32", C.c_uint8 * 4), ("use_64x64", C.c_uint8), ("pad_", C.c_uint8 * 3)]
 
 
+class TplStats(C.Structure):             # SvtHipTplStats (include/svt_hip_tpl.h)
+    _fields_ = [("srcrf_dist", C.c_int64), ("recrf_dist", C.c_int64), ("srcrf_rate", C.c_int64), ("recrf_rate", C.c_int64),
+                ("mc_dep_rate", C.c_int64), ("mc_dep_dist", C.c_int64), ("mv_row", C.c_int16), ("mv_col", C.c_int16), ("pad_", C.c_uint32),
+                ("ref_frame_poc", C.c_uint64)]
+
+
+class TplSrcStats(C.Structure):          # SvtHipTplSrcStats
+    _fields_ = [("srcrf_dist", C.c_int64), ("srcrf_rate", C.c_int64), ("ref_frame_poc", C.c_uint64), ("mv_row", C.c_int16), ("mv_col", C.c_int16),
+                ("best_rf_idx", C.c_int32), ("best_mode", C.c_uint8), ("best_intra_mode", C.c_uint8), ("pad_", C.c_uint8 * 6)]
+
+
+class TplRef(C.Structure):               # SvtHipTplRef
+    _fields_ = [("src", C.c_void_p), ("recon", C.c_void_p), ("src_stride", C.c_uint32), ("recon_stride", C.c_uint32), ("picture_number", C.c_uint64),
+                ("max_width", C.c_uint16), ("max_height", C.c_uint16), ("usable", C.c_uint8), ("pad_", C.c_uint8 * 3)]
+
+
+class TplFrameJob(C.Structure):          # SvtHipTplFrameJob
+    _fields_ = [("src", Plane8), ("recon", Plane8), ("ref", (TplRef * 4) * 2), ("me_mv_array", C.c_void_p), ("me_candidate_array", C.c_void_p),
+                ("total_me_candidate_index", C.c_void_p), ("max_cand", C.c_uint8), ("max_refs", C.c_uint8), ("max_l0", C.c_uint8),
+                ("enable_me_16x16", C.c_uint8), ("stored_pus", C.c_uint8), ("pf_shape", C.c_uint8), ("disable_intra_pred", C.c_uint8),
+                ("is_ref", C.c_uint8), ("i_slice", C.c_uint8), ("tpl_i_slice", C.c_uint8), ("src_data_ready", C.c_uint8),
+                ("store_src_stats", C.c_uint8), ("synth_blk_size", C.c_uint8), ("pad_", C.c_uint8 * 3), ("round_fp", C.c_int16 * 2),
+                ("quant_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2), ("pad2_", C.c_uint16), ("stats", C.c_void_p), ("src_stats", C.c_void_p),
+                ("flags", C.c_void_p)]
+
+
 class Mv(C.Structure):                   # SvtHipMv == MV (block_structures.h:26-29)
     _fields_ = [("row", C.c_int16), ("col", C.c_int16)]
 
