@@ -82,8 +82,15 @@ typedef struct SvtHipTplFrameJob {
     uint16_t pad2_;
     SvtHipTplStats    *stats;     /* [(aligned_h / blk)][stride]: stride = (aligned_width + 15) / 16 for 16, twice that for 8 */
     SvtHipTplSrcStats *src_stats; /* [..][(aligned_width + 15) >> 4] */
-    uint32_t          *flags;     /* device scratch, one uint32 per 16x16 block of the 64-aligned picture; the call zeroes it */
+    void              *workspace; /* device scratch of svt_hip_tpl_workspace_bytes(): the done-flags of the blocks, one status word
+                                   * (first uint32 behind the flags: non-zero if a dependency wait ran into its bound — the
+                                   * results are then unreliable; never observed) and the coefficient arrays of the blocks */
+    uint64_t           workspace_bytes;
 } SvtHipTplFrameJob;
+
+SVT_HIP_API uint64_t svt_hip_tpl_workspace_bytes(uint32_t width, uint32_t height);
+/* byte offset of the status word inside the workspace */
+SVT_HIP_API uint64_t svt_hip_tpl_status_offset(uint32_t width, uint32_t height);
 
 /* `job` is a HOST struct, every pointer inside is device memory.  Asynchronous on `stream`. */
 SVT_HIP_API int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, void *stream);

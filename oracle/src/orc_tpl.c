@@ -9,7 +9,7 @@
  *   get_quantize_error, result_model_store                             src_ops_process.c:225-249, 266-340
  * built on the pinned pieces orc_nxm_sad, orc_fwd_txfm2d, orc_quantize_fp, orc_inv_txfm2d_add_8bit.
  * Pinned against the REAL function through oracle/ref_harness_tpl.c (tests/test_tpl_oracle.py) and tests/golden/tpl_frame.npz.
- * Every pointer inside the job is a HOST pointer here; `flags` is not used.  Blocks run in the reference's order (64x64 blocks
+ * Every pointer inside the job is a HOST pointer here; `workspace` is not used.  Blocks run in the reference's order (64x64 blocks
  * in raster order, 16x16 blocks in z-order inside).
  */
 #include <stdlib.h>

@@ -1,0 +1,359 @@
+// tpl.hip — the TPL dispenser of one picture on gfx950: tpl_mc_flow_dispenser_sb_generic
+// (src_ops_process.c:519-1207) for the 16x16 / DC / SAD / full-pel configuration described in include/svt_hip_tpl.h.
+//
+// One wavefront per 16x16 block, all blocks of the picture in ONE launch:
+//   source-based path (no dependencies): the block's 256 source samples stay in registers (one dword per lane); DC prediction
+//     from the source neighbours, `v_sad_u8` against it and against every single-reference ME candidate; the inter winner's
+//     residual goes through the fused transform block of txfm_block.hpp (DCT 16x16 with the pf_shape zero-out, quantize_fp)
+//     and svt_av1_block_error is summed from the coefficient arrays it wrote;
+//   reconstruction path: inter blocks copy the reference's reconstruction, intra blocks build the DC prediction from their
+//     reconstructed neighbours — the only dependency inside the picture: an intra block first waits for the done-flags of its
+//     left / top / top-left neighbours (acquire), every block sets its own flag when its reconstruction is in memory (release);
+//     workgroups are dispatched in raster order and only ever wait for lower indices, and the wait is bounded;
+//   then residual -> transform -> quantise -> error -> inverse + reconstruction by the same transform block, TplStats.
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/svt_hip_tpl.h"
+#include "common.hpp"
+#include "txfm_block.hpp"
+
+using namespace svthip;
+using namespace svthip::txb;
+
+namespace {
+
+constexpr int      TPL_PAD = 32, NEWMV_MODE = 16;
+constexpr uint32_t SPIN_LIMIT = 1u << 22;  // x ~1 us: a neighbour that never finishes ends the wait instead of hanging the GPU
+__device__ const uint16_t TPL_ISCAN[256] = {0};  // the scan only orders the end-of-block position, which nothing here depends on
+
+struct TplArgs {
+    SvtHipTplFrameJob j;
+    const uint8_t    *src0;  // sample (0,0)
+    uint8_t          *rec0;
+    uint32_t          W, H, a16, rows16;
+    uint32_t         *flags;    // [blocks]
+    uint32_t         *error;    // [1]: set when a dependency wait ran into SPIN_LIMIT
+    int32_t          *scratch;  // [blocks][512]: coeff, dqcoeff
+};
+
+__device__ __forceinline__ uint32_t ld8(const uint8_t *p) { return *(const __attribute__((address_space(1))) uint8_t *)p; }
+// four samples of a row that need not be aligned
+__device__ __forceinline__ uint32_t ld4(const uint8_t *p) {
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    return *(const __attribute__((address_space(1))) u32u *)p;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int64_t wave_sum64(int64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// svt_aom_update_neighbor_samples_array_open_loop_mb[_recon] (enc_intra_prediction.c:1127-1300) for a 16x16 block with
+// use_top_right_bottom_left = update_top_neighbor = 1; above_ref / left_ref point at the [-1] entries.  One lane.
+__device__ void neighbours(uint8_t *above_ref, uint8_t *left_ref, const uint8_t *pic0, uint32_t stride, uint32_t x, uint32_t y, uint32_t width,
+                           uint32_t height) {
+    const uint32_t bw = 16, bh = 16, n = 32;
+    const uint8_t *src = pic0 + (size_t)y * stride + x;
+    for (uint32_t i = 0; i <= n; i++) above_ref[i] = 127, left_ref[i] = 129;
+    uint8_t *a = above_ref, *l = left_ref;
+    if (x != 0 && y != 0)
+        *a = *l = (uint8_t)ld8(src - stride - 1);
+    else
+        *a = *l = 128;
+    a++, l++;
+    uint32_t count = n;
+    if (x != 0) {
+        const uint8_t *rp = src - 1;
+        if (y == 0)
+            l[-1] = (uint8_t)ld8(rp);
+        count = (y + count > height) ? count - (y + count - height) : count;
+        for (uint32_t i = 0; i < count; i++, rp += stride) *l++ = (uint8_t)ld8(rp);
+        l += n - count;
+        for (uint32_t i = 0; i < bh; i++) l[-(int)bh + (int)i] = l[-(int)bh - 1];
+    } else if (y != 0) {
+        count = (y + count > height) ? count - (y + count - height) : count;
+        const uint8_t v = (uint8_t)ld8(src - stride);
+        for (uint32_t i = 0; i <= count; i++) l[(int)i - 1] = v;
+        a[-1] = v;
+    } else
+        l += count;
+    count = n;
+    if (y != 0) {
+        count = (x + count > width) ? count - (x + count - width) : count;
+        for (uint32_t i = 0; i < count; i++) a[i] = (uint8_t)ld8(src - stride + i);
+        if (x != 0)
+            for (uint32_t i = 0; i < bw; i++) a[bw + i] = a[bw - 1];
+    } else if (x != 0) {
+        count = (x + count > width) ? count - (x + count - width) : count;
+        const uint8_t v = *(l - count);
+        for (uint32_t i = 0; i <= count; i++) a[(int)i - 1] = v;
+    }
+}
+
+// DC_PRED value of the block at (x, y) of plane pic0 (svt_aom_dc_pred[x > 0][y > 0][TX_16X16]); uniform over the wave
+__device__ uint32_t dc_value(const uint8_t *pic0, uint32_t stride, uint32_t x, uint32_t y, uint32_t W, uint32_t H, uint8_t *lds_nb) {
+    const int  lane = threadIdx.x;
+    const bool inside = x + 16 <= W && y + 16 <= H;
+    uint32_t   sa, sl;
+    if (x > 0 && y > 0 && inside) {  // get_neighbor_samples_dc
+        const uint8_t *src = pic0 + (size_t)y * stride + x;
+        uint32_t       v = 0;
+        if (lane < 16)
+            v = ld8(src - stride + lane);
+        else if (lane < 32)
+            v = ld8(src + (size_t)(lane - 16) * stride - 1);
+        sa = wave_sum(lane < 16 ? v : 0), sl = wave_sum(lane >= 16 && lane < 32 ? v : 0);
+    } else {
+        uint8_t *above = lds_nb + 8, *left = lds_nb + 8 + 48;
+        if (lane == 0)
+            neighbours(above - 1, left - 1, pic0, stride, x, y, W, H);
+        __syncthreads();
+        sa = wave_sum(lane < 16 ? above[lane] : 0), sl = wave_sum(lane < 16 ? left[lane] : 0);
+        __syncthreads();
+    }
+    if (x > 0 && y > 0)
+        return (sa + sl + 16) / 32;
+    if (x > 0)
+        return (sl + 8) / 16;
+    if (y > 0)
+        return (sa + 8) / 16;
+    return 128;
+}
+
+// residual (source - prediction) -> DCT 16x16 (pf_shape) -> quantize_fp -> svt_av1_block_error >> 2, max 1 (get_quantize_error);
+// with `inv` the inverse transform reconstructs onto recon (prediction and reconstruction may be the same samples)
+__device__ int64_t quantize_error(const TplArgs &a, const uint8_t *src, uint32_t src_stride, const uint8_t *pred, uint32_t pred_stride,
+                                  uint8_t *recon, uint32_t recon_stride, bool inv, int32_t *scratch, int32_t *lds_tile) {
+    const int      lane = threadIdx.x;
+    SvtHipTxfmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.residual_off = (uint64_t)(uintptr_t)src, d.residual_stride = src_stride;
+    d.pred_off = (uint64_t)(uintptr_t)pred, d.pred_stride = pred_stride;
+    d.recon_off = (uint64_t)(uintptr_t)recon, d.recon_stride = recon_stride;
+    d.coeff_off = (uint64_t)(uintptr_t)scratch, d.dqcoeff_off = (uint64_t)(uintptr_t)(scratch + 256);
+    d.qcoeff_off = SVT_HIP_NO_OFFSET, d.qm_off = d.iqm_off = SVT_HIP_NO_OFFSET;
+    d.iscan_off = (uint64_t)(uintptr_t)TPL_ISCAN;
+    for (int i = 0; i < 2; i++) d.round[i] = a.j.round_fp[i], d.quant[i] = a.j.quant_fp[i], d.dequant[i] = a.j.dequant[i];
+    d.tx_type = 0, d.shape = a.j.pf_shape, d.bit_depth = 8, d.quant_mode = SVT_HIP_QUANT_FP, d.log_scale = 0;
+    d.flags = (uint8_t)(SVT_HIP_TX_FWD | SVT_HIP_TX_SRC_PRED | (inv ? SVT_HIP_TX_INV : 0));
+    SvtHipTxfmResult res;
+    txfm_block<16, 16>((uint8_t *)nullptr, d, &res, lane < 16, lane & 15, lds_tile + (lane >> 4) * (16 * 17));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the coefficient arrays (and the reconstruction) are in memory and visible
+    __syncthreads();
+    int64_t err = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int     i = lane + 64 * k;
+        const int64_t e = (int64_t)__hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+            (int64_t)__hip_atomic_load(scratch + 256 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        err += e * e;
+    }
+    err = wave_sum64(err) >> 2;
+    return err > 1 ? err : 1;
+}
+
+__device__ __forceinline__ int64_t max64(int64_t x, int64_t y) { return x > y ? x : y; }
+
+__global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
+    __shared__ int32_t tile[4 * 16 * 17];
+    __shared__ uint8_t nb[8 + 48 + 48];
+    const SvtHipTplFrameJob &j = a.j;
+    const int      lane = threadIdx.x;
+    const uint32_t blk = blockIdx.x, bx = blk % a.a16, by = blk / a.a16, x = bx * 16, y = by * 16;
+    if (x + 8 > a.W || y + 8 > a.H)  // at least half of the block inside
+        return;
+    const uint32_t ss = j.src.stride, rs = j.recon.stride;
+    const uint8_t *src = a.src0 + (size_t)y * ss + x;
+    uint8_t       *dst = a.rec0 + (size_t)y * rs + x;
+    int32_t       *scratch = a.scratch + (size_t)blk * 512;
+    SvtHipTplSrcStats *sst = &j.src_stats[(size_t)by * a.a16 + bx];
+    const int      lr = lane >> 2, lc = (lane & 3) * 4;  // this lane's four samples: row lr, columns lc .. lc + 3
+    const uint32_t spx = ld4(src + (size_t)lr * ss + lc);
+
+    int64_t  srcrf_dist = 0, recon_error = 1;
+    uint64_t best_ref_poc = 0;
+    int32_t  best_rf_idx = -1;
+    int      mv_row = 0, mv_col = 0;
+    uint32_t best_mode = 0;
+    if (!j.src_data_ready) {
+        int64_t best_inter = INT64_MAX, best_intra = INT64_MAX;
+        if (!j.disable_intra_pred) {
+            const uint32_t dc = dc_value(a.src0, ss, x, y, a.W, a.H, nb);
+            best_intra = wave_sum(__builtin_amdgcn_sad_u8(spx, dc * 0x01010101u, 0));
+        }
+        const uint32_t sb = (y >> 6) * ((((a.W + 7) & ~7u) + 63) >> 6) + (x >> 6);
+        uint32_t       me_off = 5 + ((y >> 4) & 3) * 4 + ((x >> 4) & 3);  // tpl_blk_idx_tab[1]
+        if (!j.enable_me_16x16)
+            me_off = (me_off - 1) / 4;
+        const size_t   pu = (size_t)sb * j.stored_pus + me_off;
+        const uint8_t *cands = j.me_candidate_array + pu * j.max_cand;
+        const uint32_t n_cand = j.i_slice ? 0 : j.total_me_candidate_index[pu];
+        for (uint32_t ci = 0; ci < n_cand; ci++) {
+            const uint32_t cb = cands[ci], dir = cb & 3;
+            if (dir > 1)
+                continue;
+            const uint32_t      ri = dir == 0 ? (cb >> 2) & 3 : (cb >> 4) & 3;
+            const SvtHipTplRef &rf = j.ref[dir][ri];
+            if (!rf.usable)
+                continue;
+            const uint32_t mv = j.me_mv_array[pu * j.max_refs + (dir ? j.max_l0 : 0) + ri];
+            int            mx = (int16_t)((int16_t)(mv & 0xffff) << 3), my = (int16_t)((int16_t)(mv >> 16) << 3);
+            if ((int)x + (mx >> 3) < -TPL_PAD)
+                mx = (int16_t)((-TPL_PAD - (int)x) << 3);
+            if ((int)x + 16 + (mx >> 3) > TPL_PAD + (int)rf.max_width - 1)
+                mx = (int16_t)(((TPL_PAD + (int)rf.max_width - 1) - ((int)x + 16)) << 3);
+            if ((int)y + (my >> 3) < -TPL_PAD)
+                my = (int16_t)((-TPL_PAD - (int)y) << 3);
+            if ((int)y + 16 + (my >> 3) > TPL_PAD + (int)rf.max_height - 1)
+                my = (int16_t)(((TPL_PAD + (int)rf.max_height - 1) - ((int)y + 16)) << 3);
+            const uint8_t *rp = rf.src + ((ptrdiff_t)y + my / 8 + lr) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + mx / 8 + lc;
+            const int64_t  cost = wave_sum(__builtin_amdgcn_sad_u8(spx, ld4(rp), 0));
+            if (cost < best_inter)
+                best_inter = cost, best_ref_poc = rf.picture_number, best_rf_idx = (int32_t)(dir * 4 + ri), mv_row = my, mv_col = mx;
+        }
+        if (best_inter < best_intra)
+            best_mode = NEWMV_MODE;
+        if (best_mode == NEWMV_MODE) {
+            const SvtHipTplRef &rf = j.ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
+            const uint8_t      *rp = rf.src + ((ptrdiff_t)y + (mv_row >> 3)) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + (mv_col >> 3);
+            srcrf_dist = quantize_error(a, src, ss, rp, rf.src_stride, nullptr, 0, false, scratch, tile) << 4;
+        }
+        if (j.store_src_stats && lane == 0) {
+            SvtHipTplSrcStats s;
+            memset(&s, 0, sizeof(s));
+            s.srcrf_dist = srcrf_dist, s.srcrf_rate = 0, s.mv_row = (int16_t)mv_row, s.mv_col = (int16_t)mv_col, s.best_rf_idx = best_rf_idx;
+            s.ref_frame_poc = best_ref_poc, s.best_mode = (uint8_t)best_mode, s.best_intra_mode = 0;
+            *sst = s;
+        }
+    } else {
+        srcrf_dist = sst->srcrf_dist, mv_row = sst->mv_row, mv_col = sst->mv_col, best_rf_idx = sst->best_rf_idx;
+        best_ref_poc = sst->ref_frame_poc, best_mode = sst->best_mode;
+    }
+    // ---- reconstruction path
+    if (best_mode == NEWMV_MODE) {
+        const SvtHipTplRef &rf = j.ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
+        const uint8_t      *rp = rf.recon + ((ptrdiff_t)y + (mv_row >> 3) + lr) * (ptrdiff_t)rf.recon_stride + (ptrdiff_t)x + (mv_col >> 3) + lc;
+        const uint32_t      v = ld4(rp);
+        uint8_t            *o = dst + (size_t)lr * rs + lc;
+        o[0] = (uint8_t)v, o[1] = (uint8_t)(v >> 8), o[2] = (uint8_t)(v >> 16), o[3] = (uint8_t)(v >> 24);
+    } else {
+        // the DC prediction reads reconstructed samples of the left / top / top-left blocks: wait for them
+        if (lane == 0) {
+            const uint32_t deps[3] = {bx ? blk - 1 : ~0u, by ? blk - a.a16 : ~0u, (bx && by) ? blk - a.a16 - 1 : ~0u};
+            for (int k = 0; k < 3; k++) {
+                if (deps[k] == ~0u)
+                    continue;
+                uint32_t spins = 0;
+                while (__hip_atomic_load(&a.flags[deps[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (++spins > SPIN_LIMIT) {
+                        atomicExch(a.error, 1u);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t dc = dc_value(a.rec0, rs, x, y, a.W, a.H, nb);
+        uint8_t       *o  = dst + (size_t)lr * rs + lc;
+        o[0] = o[1] = o[2] = o[3] = (uint8_t)dc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the prediction is in memory before the transform block reads it back
+    __syncthreads();
+    const bool inv = !j.disable_intra_pred || j.is_ref;
+    recon_error = quantize_error(a, src, ss, dst, rs, dst, rs, inv, scratch, tile);  // (its fence also publishes the reconstruction)
+    if (lane == 0) {
+        SvtHipTplStats st;
+        memset(&st, 0, sizeof(st));
+        st.srcrf_dist = srcrf_dist, st.recrf_dist = recon_error << 4;
+        if (best_mode != NEWMV_MODE)
+            st.srcrf_dist = recon_error << 4;
+        st.recrf_dist = max64(st.srcrf_dist, st.recrf_dist);
+        if (!j.tpl_i_slice && best_rf_idx != -1)
+            st.mv_row = (int16_t)mv_row, st.mv_col = (int16_t)mv_col, st.ref_frame_poc = best_ref_poc;
+        st.srcrf_dist = max64(1, st.srcrf_dist), st.recrf_dist = max64(1, st.recrf_dist), st.srcrf_rate = 1, st.recrf_rate = 1;
+        if (j.synth_blk_size == 16) {
+            j.stats[(size_t)by * a.a16 + bx] = st;
+        } else {  // the 16x16 data is duplicated on an 8x8 grid
+            const uint32_t stride = a.a16 << 1;
+            st.srcrf_dist = max64(1, st.srcrf_dist / 4), st.recrf_dist = max64(1, st.recrf_dist / 4);
+            SvtHipTplStats *d = &j.stats[(size_t)(y >> 3) * stride + (x >> 3)];
+            d[0] = st, d[1] = st, d[stride] = st, d[stride + 1] = st;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&a.flags[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+size_t flag_bytes(uint32_t width, uint32_t height) {
+    const uint32_t aw = (width + 7) & ~7u, ah = (height + 7) & ~7u;
+    return ((size_t)((aw + 15) >> 4) * ((ah + 15) >> 4) * sizeof(uint32_t) + 255) & ~(size_t)255;
+}
+
+}  // namespace
+
+extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, void *stream) {
+    auto bad = [](const char *m) {
+        set_error("svt_hip_tpl_dispenser_frame: %s", m);
+        return (int32_t)SVT_HIP_ERR_BAD_PARAMETER;
+    };
+    if (!job)
+        return bad("NULL job");
+    const SvtHipPlane8 &s = job->src, &r = job->recon;
+    if (!s.buf || !r.buf || s.width < 16 || s.height < 16 || r.width != s.width || r.height != s.height)
+        return bad("source / reconstruction planes missing or of different size");
+    if (s.org_x < TPL_PAD + 16 || s.org_y < TPL_PAD + 16 || r.org_x < TPL_PAD + 16 || r.org_y < TPL_PAD + 16)
+        return bad("planes need >= 48 samples of padding (TPL_PADX + one block)");
+    if (s.stride < s.width + 2u * s.org_x || r.stride < r.width + 2u * r.org_x)
+        return bad("stride smaller than the padded width");
+    if (job->synth_blk_size != 16 && job->synth_blk_size != 8)
+        return bad("synth_blk_size must be 16 or 8");
+    if (job->pf_shape > 2)
+        return bad("pf_shape must be 0, 1 or 2");
+    if (!job->stats || !job->src_stats)
+        return bad("NULL output array");
+    if (!job->workspace || job->workspace_bytes < svt_hip_tpl_workspace_bytes(s.width, s.height))
+        return bad("workspace too small (svt_hip_tpl_workspace_bytes)");
+    const bool need_me = !job->src_data_ready && !job->i_slice;
+    if (need_me && (!job->me_mv_array || !job->me_candidate_array || !job->total_me_candidate_index || !job->max_cand || !job->max_refs || !job->stored_pus))
+        return bad("ME results missing");
+    for (int l = 0; l < SVT_HIP_ME_MAX_LIST; l++)
+        for (int q = 0; q < SVT_HIP_ME_MAX_REF; q++) {
+            const SvtHipTplRef &f = job->ref[l][q];
+            if (!f.src)
+                continue;
+            if (!f.recon || f.src_stride < s.width + 2u * TPL_PAD || f.recon_stride < s.width + 2u * TPL_PAD)
+                return bad("reference picture: reconstruction missing or stride too small");
+            // the clipped vector keeps a block inside max_width + TPL_PAD: that must be inside the padded plane
+            if (f.max_width > s.width + (uint32_t)(s.org_x - TPL_PAD) || f.max_height > s.height + (uint32_t)(s.org_y - TPL_PAD))
+                return bad("reference picture: max_width / max_height reach beyond the padding");
+        }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    hipStream_t    st = resolve_stream(stream);
+    const uint32_t aw = (s.width + 7) & ~7u, ah = (s.height + 7) & ~7u, a16 = (aw + 15) >> 4, rows16 = (ah + 15) >> 4;
+    const size_t   blocks = (size_t)a16 * rows16;
+    uint8_t       *ws = (uint8_t *)job->workspace;
+    const size_t   fb = flag_bytes(s.width, s.height);
+    SVT_HIP_CHECK(hipMemsetAsync(ws, 0, fb + 256, st));
+    TplArgs a;
+    a.j = *job;
+    a.src0 = s.buf + (size_t)s.org_y * s.stride + s.org_x, a.rec0 = r.buf + (size_t)r.org_y * r.stride + r.org_x;
+    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb), a.scratch = (int32_t *)(ws + fb + 256);
+    hipLaunchKernelGGL(tpl_kernel, dim3((uint32_t)blocks), dim3(64), 0, st, a);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+extern "C" uint64_t svt_hip_tpl_workspace_bytes(uint32_t width, uint32_t height) {
+    const uint32_t aw = (width + 7) & ~7u, ah = (height + 7) & ~7u;
+    return flag_bytes(width, height) + 256 + (uint64_t)((aw + 15) >> 4) * ((ah + 15) >> 4) * 512 * sizeof(int32_t);
+}
+extern "C" uint64_t svt_hip_tpl_status_offset(uint32_t width, uint32_t height) { return flag_bytes(width, height); }

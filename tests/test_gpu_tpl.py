@@ -1,0 +1,89 @@
+"""GPU parity: svt_hip_tpl_dispenser_frame (one launch, intra blocks ordered behind their neighbours by flags) against the
+oracle's restatement of tpl_mc_flow_dispenser_sb_generic and the golden results of the reference, bit-exact: the TPL
+reconstruction picture, TplStats and TplSrcStats."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import tpl_cases as T
+from svtav1_hip import abi, device
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tpl_frame.npz")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def quant():
+    T.load_quant(np.load(GOLD))
+
+
+class DevMap:
+    """Uploads host arrays on first use and hands out their device addresses (keyed by the host address)."""
+
+    def __init__(self, hip):
+        self.hip, self.m = hip, {}
+
+    def __call__(self, arr):
+        key = arr.ctypes.data
+        if key not in self.m:
+            b = device.DeviceBuffer(self.hip, arr.nbytes)
+            b.upload(arr)
+            self.m[key] = (b, arr)
+        return self.m[key][0].ptr
+
+    def download(self, arr):
+        b, a = self.m[arr.ctypes.data]
+        return b.download(a.dtype, a.shape)
+
+
+def run_gpu(hip, scene):
+    name, kind, w, h, qindex, opt = scene.case
+    dm = DevMap(hip)
+    job = scene.job(dm)
+    hip.svt_hip_tpl_workspace_bytes.restype = C.c_uint64
+    hip.svt_hip_tpl_status_offset.restype = C.c_uint64
+    wsb = hip.svt_hip_tpl_workspace_bytes(w, h)
+    ws = device.DeviceBuffer(hip, wsb)
+    ws.fill(0xCD)
+    job.workspace, job.workspace_bytes = ws.ptr, wsb
+    device.check(hip, hip.svt_hip_tpl_dispenser_frame(C.byref(job), None), "svt_hip_tpl_dispenser_frame")
+    device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+    off = hip.svt_hip_tpl_status_offset(w, h)
+    status = ws.download(np.uint8, (wsb,))[off:off + 4].view(np.uint32)[0]
+    assert status == 0, "a dependency wait ran into its bound"
+    return {"recon": dm.download(scene.out.buf), "stats": dm.download(scene.stats).view(np.uint8),
+            "src_stats": dm.download(scene.src_stats).view(np.uint8)}
+
+
+@pytest.mark.parametrize("case", T.CASES, ids=lambda c: c[0])
+def test_dispenser_frame(hip, orc, case):
+    gold = np.load(GOLD)
+    a, b = T.TplScene(orc, case), T.TplScene(orc, case)
+    if case[5]["src_data_ready"]:
+        T.prime_second_pass(orc, a), T.prime_second_pass(orc, b)
+    got = run_gpu(hip, a)
+    assert orc.orc_tpl_dispenser_frame(C.byref(b.job())) == 0
+    for k, v in b.results().items():
+        assert np.array_equal(got[k], v), (case[0], k, int((got[k] != v).sum()))
+        assert np.array_equal(got[k], gold[f"{case[0]}_{k}"]), (case[0], k, "golden")
+
+
+def test_all_intra_wavefront_1080p(hip, orc):
+    """Every block intra (I slice): the longest dependency chains the flags have to carry, on a 1920x1080 picture."""
+    case = ("islice_1080p", "pan", 1920, 1080, 120, dict(T.BASE, i_slice=1, tpl_i_slice=1))
+    a, b = T.TplScene(orc, case), T.TplScene(orc, case)
+    got = run_gpu(hip, a)
+    assert orc.orc_tpl_dispenser_frame(C.byref(b.job())) == 0
+    for k, v in b.results().items():
+        assert np.array_equal(got[k], v), (k, int((got[k] != v).sum()))
+
+
+def test_argument_checks(hip, orc):
+    s = T.TplScene(orc, T.CASES[0])
+    dm = DevMap(hip)
+    job = s.job(dm)
+    assert hip.svt_hip_tpl_dispenser_frame(C.byref(job), None) == abi.SVT_HIP_ERR_BAD_PARAMETER  # no workspace
+    assert b"workspace" in hip.svt_hip_last_error()
+    assert hip.svt_hip_tpl_dispenser_frame(None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
