@@ -255,10 +255,15 @@ class TxfmWorkload:
                     d[k] = v
                 # neighbouring blocks alternate DCT_DCT / ADST_DCT for the sizes that have ADST: the worst case for a
                 # kernel whose waves hold several blocks (the library groups by type internally, see svt_hip_txfm.h)
-                d["tx_type"] = (i % 2).astype(np.uint8) if max(w, h) <= 16 else 0
+                d["tx_type"] = (i % 2).astype(np.uint8) if max(w, h) <= 16 and os.environ.get("SVTAV1_BENCH_TXTYPE", "mix") == "mix" else 0
                 d["shape"], d["bit_depth"], d["quant_mode"] = 0, 10, abi.QUANT_B_HBD
                 d["log_scale"] = 2 if w == 64 else (1 if w == 32 else 0)
                 d["flags"] = abi.TX_FWD | abi.TX_INV | abi.TX_PIXEL16
+                txmode = os.environ.get("SVTAV1_BENCH_TXMODE", "full")  # kernel-analysis aid: drop stages of the fused block
+                if txmode in ("fwdq", "fwd"):
+                    d["flags"] = abi.TX_FWD | abi.TX_PIXEL16
+                if txmode == "fwd":
+                    d["quant_mode"] = 0
                 descs[(w, h)].append(d)
         self.launches = {}
         for s in sizes:

@@ -17,7 +17,7 @@
  *   result_model_store TplStats on the 16x16 (or 8x8) grid, TplSrcStats
  * The intra blocks depend on the reconstruction of their left / top / top-left neighbours: the kernel runs the source-based
  * path of every block in parallel and orders only the reconstruction of intra blocks behind their neighbours' (flags in
- * device memory).  The caller orders pictures (a reference picture's reconstruction must be complete before this call).
+ * device memory; block indices are handed out by a ticket counter, so no dispatch order is assumed).  The caller orders pictures (a reference picture's reconstruction must be complete before this call).
  * Not provided: the other intra modes and the SATD source search (tpl levels 1, 2), sub-pel refinement (levels 1-3),
  * 32x32 / 64x64 dispenser blocks with transform sub-sampling (level 5), the rate estimate.
  */

@@ -9,7 +9,9 @@
 //   reconstruction path: inter blocks copy the reference's reconstruction, intra blocks build the DC prediction from their
 //     reconstructed neighbours — the only dependency inside the picture: an intra block first waits for the done-flags of its
 //     left / top / top-left neighbours (acquire), every block sets its own flag when its reconstruction is in memory (release);
-//     workgroups are dispatched in raster order and only ever wait for lower indices, and the wait is bounded;
+//     a workgroup takes its block index from a ticket counter when it STARTS, so every lower index belongs to a workgroup that
+//     is already running or done whatever order the hardware dispatches in (no assumption about dispatch order or placement),
+//     and the wait is bounded;
 //   then residual -> transform -> quantise -> error -> inverse + reconstruction by the same transform block, TplStats.
 #include <cstdio>
 #include <cstring>
@@ -33,7 +35,7 @@ struct TplArgs {
     uint8_t          *rec0;
     uint32_t          W, H, a16, rows16;
     uint32_t         *flags;    // [blocks]
-    uint32_t         *error;    // [1]: set when a dependency wait ran into SPIN_LIMIT
+    uint32_t         *error;    // [0]: set when a dependency wait ran into SPIN_LIMIT; [1]: the ticket counter
     int32_t          *scratch;  // [blocks][512]: coeff, dqcoeff
 };
 
@@ -164,8 +166,12 @@ __global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
     __shared__ int32_t tile[4 * 16 * 17];
     __shared__ uint8_t nb[8 + 48 + 48];
     const SvtHipTplFrameJob &j = a.j;
+    __shared__ uint32_t s_ticket;
     const int      lane = threadIdx.x;
-    const uint32_t blk = blockIdx.x, bx = blk % a.a16, by = blk / a.a16, x = bx * 16, y = by * 16;
+    if (lane == 0)
+        s_ticket = atomicAdd(a.error + 1, 1u);
+    __syncthreads();
+    const uint32_t blk = s_ticket, bx = blk % a.a16, by = blk / a.a16, x = bx * 16, y = by * 16;
     if (x + 8 > a.W || y + 8 > a.H)  // at least half of the block inside
         return;
     const uint32_t ss = j.src.stride, rs = j.recon.stride;

@@ -38,7 +38,7 @@ struct Geo {
     static constexpr int PW = W + 1;
     static constexpr int NT = cmax(1, 64 / L);  // one wave per workgroup: its barriers cost nothing and waves never wait for each other
     static constexpr int IW = cmin(W, 32), IH = cmin(H, 32);
-    static constexpr int MINW = L == 32 ? 3 : 1;  // waves per SIMD the register allocation aims for: 3 for the 32-wide kernels (150 VGPRs, no scratch: 2.86 TB/s; at 4 waves / 128 VGPRs they spill 104 B per lane: 2.31 TB/s); the other widths take what they need (16-wide: 94 VGPRs, 5 waves)
+    static constexpr int MINW = L == 32 ? 3 : (L == 8 ? 8 : 1);  // waves per SIMD the register allocation aims for: 3 for the 32-wide kernels (150 VGPRs, no scratch: 2.86 TB/s; at 4 waves / 128 VGPRs they spill 104 B per lane: 2.31 TB/s); 8 for the 8-wide ones (64 VGPRs, 12 B of scratch: +4 %); the 16-wide take what they need (96 VGPRs, 5 waves: capped at 80 they spill 64 B and lose 15 %)
     static constexpr int WI = clog2(W) - 2, HI = clog2(H) - 2;
     static constexpr bool RECT = (W == 2 * H) || (H == 2 * W);
 };
@@ -141,17 +141,20 @@ __device__ __forceinline__ void quant_small(const QP &q, int32_t c, int ac, int3
     if (BTYPE) {
         int32_t t = absc + q.round[ac];  // < 2^16
         t         = q.mode == SVT_HIP_QUANT_B && t > 32767 ? 32767 : t;
-        const int32_t x = (__mul24(t, q.quant[ac]) >> 11) + (t << 5);  // 0 <= x < 2^22
-        aq              = (int32_t)(((int64_t)x * (int64_t)q.qshift[ac]) >> (21 - ls));
+        const int32_t x = (mul_i24(t, q.quant[ac]) >> 11) + (t << 5);  // 0 <= x < 2^22
+        // x * quant_shift is a 38-bit product of two 24-bit values: low word + high 16 bits by the full-rate 24-bit multipliers and
+        // one v_alignbit for the shift, instead of a quarter-rate 64-bit multiply-add and a 64-bit shift
+        const uint32_t lo = mul_u24((uint32_t)x, (uint32_t)q.qshift[ac]), hi = mulhi_u24((uint32_t)x, (uint32_t)q.qshift[ac]);
+        aq                = (int32_t)__builtin_amdgcn_alignbit(hi, lo, (uint32_t)(21 - ls));
         aq              = absc >= q.zbin[ac] ? aq : 0;
     } else {
         int32_t a2 = absc + q.round[ac];
         a2         = q.mode == SVT_HIP_QUANT_FP && a2 > 32767 ? 32767 : a2;
-        aq         = __mul24(a2, q.quant[ac]) >> (16 - ls);
+        aq         = mul_i24(a2, q.quant[ac]) >> (16 - ls);
         aq         = (absc << (1 + ls)) >= q.dequant[ac] ? aq : 0;
     }
     qc                = (aq ^ sign) - sign;
-    const int32_t adq = __mul24(aq, q.dequant[ac]) >> ls;  // aq < 2^19, dequant < 2^15
+    const int32_t adq = mul_i24(aq, q.dequant[ac]) >> ls;  // aq < 2^19, dequant < 2^15
     dqc               = (adq ^ sign) - sign;
 }
 

@@ -122,18 +122,23 @@ struct Exact {
     static TXD_FN bool all_zero4(T a, T b, T c, T d) { return !(a | b | c | d); }
 };
 #if defined(__HIPCC__)
+// v_mul_i32_i24 by its LLVM intrinsic: HIP's __mul24 is ((x << 8) >> 8) * ((y << 8) >> 8) in IR, and once the optimiser has proven the
+// shifts redundant the instruction selector may not re-derive the 24-bit range and falls back to the quarter-rate v_mul_lo_u32
+extern "C" __device__ int mul_i24(int, int) __asm("llvm.amdgcn.mul.i24");
+extern "C" __device__ unsigned mul_u24(unsigned, unsigned) __asm("llvm.amdgcn.mul.u24");
+extern "C" __device__ unsigned mulhi_u24(unsigned, unsigned) __asm("llvm.amdgcn.mulhi.u24");
 struct Fast {
     using T = int32_t;
     static TXD_FN T add(T a, T b) { return a + b; }
     static TXD_FN T sub(T a, T b) { return a - b; }
     static TXD_FN T neg(T a) { return -a; }
-    static TXD_FN T mul(int32_t w, T a) { return __mul24(w, a); }
+    static TXD_FN T mul(int32_t w, T a) { return mul_i24(w, a); }
     static TXD_FN T btf(int32_t w0, T a, int32_t w1, T b, int bit) {
-        return (__mul24(w0, a) + __mul24(w1, b) + (1 << (bit - 1))) >> bit;
+        return (mul_i24(w0, a) + mul_i24(w1, b) + (1 << (bit - 1))) >> bit;
     }
     static TXD_FN T rs(T v, int bit) { return (v + (1 << (bit - 1))) >> bit; }
-    static TXD_FN T scale(T v, int32_t k, int bit) { return (__mul24(v, k) + (1 << (bit - 1))) >> bit; }
-    static TXD_FN T times(T v, int32_t k) { return __mul24(v, k); }
+    static TXD_FN T scale(T v, int32_t k, int bit) { return (mul_i24(v, k) + (1 << (bit - 1))) >> bit; }
+    static TXD_FN T times(T v, int32_t k) { return mul_i24(v, k); }
     template <bool INV> static TXD_FN T clamp(T v, int bit) { return clampv<INV>(v, bit); }
     static TXD_FN bool all_zero4(T a, T b, T c, T d) { return !(a | b | c | d); }
 };
