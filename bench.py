@@ -549,6 +549,101 @@ def lf_stage_rooflines(lib, dev, args, sp, stream, rank):
     return out
 
 
+def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
+    """Temporal filter of one 4K picture against 4 neighbours (8-bit, luma + chroma, tf level 6 = preset 8 at 4K) and the TPL
+    dispenser of one 4K picture (tpl level 4 = preset 8), on the ME workload's device-resident pictures and ME results."""
+    W, H, out = mw.W, mw.H, []
+    c = mw.lead + mw.F // 2
+    # ---- temporal filter
+    hp = mw.dpyr[c].full.h
+    cstride, crows = hp.stride // 2, hp.rows // 2
+    chroma = [[torch.randint(0, 256, (crows * cstride + 256,), dtype=torch.uint8, device=dev) for _ in range(2)] for _ in range(5)]
+    job = abi.TfPictureJob()
+    prm = abi.MeParams.from_buffer_copy(mw.base_prm)
+    frames.set_refs(prm, c, [c - 1], [])
+    prm.me_mctf, prm.hme_search_method, prm.tf_me_exit_th = 1, 1, 0
+    prm.num_of_list_to_search, prm.is_ref = 1, 1
+    prm.num_of_ref_pic_to_search[0], prm.num_of_ref_pic_to_search[1] = 1, 0
+    job.me = prm
+    ctl = dict(half_pel_mode=2, quarter_pel_mode=1, eight_pel_mode=0, use_2tap=1, sub_sampling_shift=0, use_pred_64x64_only_th=0,
+               subpel_early_exit_th=1, use_8bit_subpel=1, pred_error_32x32_th=20 * 32 * 32)
+    for k, v in ctl.items():
+        setattr(job.ctrls, k, v)
+    for i, v in enumerate((2247286, 6156426, 6156426)):
+        job.decay_factor_fp16[i] = v
+    job.mv_dist_th, job.chroma, job.bit_depth = 450, 1, 8
+    job.mi_rows, job.mi_cols, job.n_refs = ((H + 7) // 8) * 2, ((W + 7) // 8) * 2, 4
+
+    def pic(i, k):
+        t = abi.TfPic()
+        t.pyr = mw.dpyr[i].desc()
+        t.chroma8[0], t.chroma8[1], t.chroma8_stride = chroma[k][0].data_ptr(), chroma[k][1].data_ptr(), cstride
+        t.picture_number = i
+        return t
+    job.centre = pic(c, 0)
+    for k, i in enumerate((c - 1, c + 1, c - 2, c + 2)):
+        job.ref[k] = pic(i, k + 1)
+    lib.svt_hip_tf_workspace_bytes.restype = C.c_uint64
+    wsb = int(lib.svt_hip_tf_workspace_bytes(W, H, 4))
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+    job.workspace, job.workspace_bytes = ws.data_ptr(), wsb
+    luma0 = mw.dpyr[c].full.t.clone()              # the call filters the centre picture in place: restore it afterwards
+
+    def run_tf():
+        check(lib, lib.svt_hip_tf_filter_picture(C.byref(job), sp))
+    ms = timed_launches(stream, 3, 1, run_tf)
+    torch.cuda.synchronize()
+    mw.dpyr[c].full.t.copy_(luma0)
+    P = W * H
+    # per reference: centre + reference pyramids through ME, sub-pel windows, prediction written + read, accumulators; once: normalise
+    alg = 4 * (1.3125 * 2 * P + 2 * P + 1.5 * P * (1 + 1 + 6 + 6)) + 1.5 * P * (6 + 1 + 1)
+    out.append(roof("svt_hip_tf_filter_picture (ME_MCTF + sub-pel + predict + accumulate, 4 refs, luma + chroma)", alg, ms,
+                    unit_of_work="one 4K 8-bit 4:2:0 picture against 4 reference pictures"))
+    del ws
+    # ---- TPL dispenser
+    o = mw.outs[c - mw.lead]
+    prm_c, l0, l1 = mw.prm_for(c)
+    tj = abi.TplFrameJob()
+    full = mw.dpyr[c].full
+
+    def plane8(t, h):
+        return abi.Plane8(t.data_ptr(), h.stride, h.pad, h.pad, h.width, h.height)
+    recon = torch.zeros_like(full.t)
+    tj.src, tj.recon = plane8(full.t, full.h), plane8(recon, full.h)
+    recs = {}
+    for l, pocs in enumerate((l0, l1)):
+        for r, poc in enumerate(pocs):
+            f, sp_ = tj.ref[l][r], mw.dpyr[poc].full
+            s0 = sp_.t.data_ptr() + sp_.h.pad * sp_.h.stride + sp_.h.pad
+            recs[poc] = sp_.t.clone()
+            f.src, f.src_stride = s0, sp_.h.stride
+            f.recon, f.recon_stride = recs[poc].data_ptr() + sp_.h.pad * sp_.h.stride + sp_.h.pad, sp_.h.stride
+            f.picture_number, f.max_width, f.max_height, f.usable = poc, W, H, 1
+    tj.me_mv_array, tj.me_candidate_array = o["me_mv_array"].data_ptr(), o["me_candidate_array"].data_ptr()
+    tj.total_me_candidate_index = o["total_me_candidate_index"].data_ptr()
+    tj.max_cand, tj.max_refs, tj.max_l0 = prm_c.max_cand, prm_c.max_refs, prm_c.max_l0
+    tj.enable_me_16x16, tj.stored_pus = prm_c.enable_me_16x16, prm_c.stored_pus()
+    tj.pf_shape, tj.disable_intra_pred, tj.is_ref, tj.store_src_stats, tj.synth_blk_size = 2, 0, 1, 1, 16
+    q60 = np.load(os.path.join(ROOT, "tests", "golden", "tpl_frame.npz"))["quant_60"]   # the reference's 8-bit tables at qindex 60
+    for i in range(2):
+        tj.round_fp[i], tj.quant_fp[i], tj.dequant[i] = int(q60[i]), int(q60[2 + i]), int(q60[4 + i])
+    a16, rows16 = (W + 15) >> 4, (H + 15) >> 4
+    stats = torch.zeros(a16 * rows16 * C.sizeof(abi.TplStats), dtype=torch.uint8, device=dev)
+    sst = torch.zeros(a16 * rows16 * C.sizeof(abi.TplSrcStats), dtype=torch.uint8, device=dev)
+    lib.svt_hip_tpl_workspace_bytes.restype = C.c_uint64
+    twb = int(lib.svt_hip_tpl_workspace_bytes(W, H))
+    tws = torch.zeros(twb, dtype=torch.uint8, device=dev)
+    tj.stats, tj.src_stats, tj.workspace, tj.workspace_bytes = stats.data_ptr(), sst.data_ptr(), tws.data_ptr(), twb
+
+    def run_tpl():
+        check(lib, lib.svt_hip_tpl_dispenser_frame(C.byref(tj), sp))
+    ms = timed_launches(stream, 5, 2, run_tpl)
+    nblk = a16 * rows16
+    out.append(roof("tpl_kernel (svt_hip_tpl_dispenser_frame, 16x16 blocks, 3+2 references)", nblk * (256 * (1 + 5) + 2 * 256 + 64 + 40), ms,
+                    unit_of_work=f"one 4K picture, {nblk} blocks"))
+    return out
+
+
 def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffic_note):
     W, H, F = 3840, 2160, args.frames
     mw = MeWorkload(lib, dev, W, H, F, "m8_4k_tl2", (-1, -2, -3), (1, 2), seed=7 + rank)
@@ -617,6 +712,7 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
     tx_alg = sum(tw.launches[s]["alg_bytes"] for s in sizes)
     if not args.no_lf:
         rl_all += lf_stage_rooflines(lib, dev, args, sp, stream, rank)
+        rl_all += tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw)
     step_ms = elapsed / K * 1e3
     line = {
         "metric": METRIC,

@@ -146,14 +146,16 @@ __device__ int64_t quantize_error(const TplArgs &a, const uint8_t *src, uint32_t
     d.flags = (uint8_t)(SVT_HIP_TX_FWD | SVT_HIP_TX_SRC_PRED | (inv ? SVT_HIP_TX_INV : 0));
     SvtHipTxfmResult res;
     txfm_block<16, 16>((uint8_t *)nullptr, d, &res, lane < 16, lane & 15, lds_tile + (lane >> 4) * (16 * 17));
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the coefficient arrays (and the reconstruction) are in memory and visible
+    // the coefficient arrays were written by this wave: a workgroup-scope fence (wait for the stores, same CU) makes them
+    // readable by its other lanes — no agent-scope cache write-back / invalidate here
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
     int64_t err = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int     i = lane + 64 * k;
-        const int64_t e = (int64_t)__hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-            (int64_t)__hip_atomic_load(scratch + 256 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t e = (int64_t)__hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
+            (int64_t)__hip_atomic_load(scratch + 256 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         err += e * e;
     }
     err = wave_sum64(err) >> 2;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
         uint8_t       *o  = dst + (size_t)lr * rs + lc;
         o[0] = o[1] = o[2] = o[3] = (uint8_t)dc;
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the prediction is in memory before the transform block reads it back
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the prediction (this wave's stores) is in memory before the transform block reads it back
     __syncthreads();
     const bool inv = !j.disable_intra_pred || j.is_ref;
     recon_error = quantize_error(a, src, ss, dst, rs, dst, rs, inv, scratch, tile);  // (its fence also publishes the reconstruction)
@@ -293,6 +295,10 @@ __global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
             SvtHipTplStats *d = &j.stats[(size_t)(y >> 3) * stride + (x >> 3)];
             d[0] = st, d[1] = st, d[stride] = st, d[stride + 1] = st;
         }
+    }
+    // publish: every lane's reconstruction stores are complete (the fence inside quantize_error waited for them, then the barrier),
+    // one agent-scope release makes them visible to other CUs / XCDs, then the flag
+    if (lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(&a.flags[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
