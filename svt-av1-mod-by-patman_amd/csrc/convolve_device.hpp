@@ -1,0 +1,142 @@
+// convolve_device.hpp — one 64 x 64 tile of one predicted block (the body of convolve_sr_kernel, inter_convolve.hip) as a device
+// function, shared with the temporal filter's prediction kernel (tf_picture.hip).  All 256 threads of the workgroup call it;
+// `in` / `im` are the workgroup's LDS buffers ((TILE + 7) * IP uint16 and (TILE + 7) * TILE int16).
+#pragma once
+#include <cstdint>
+
+#include "../../include/svt_hip_inter.h"
+
+namespace svthip {
+namespace conv {
+
+
+constexpr int FILTER_BITS = 7, TILE = 64, IP = TILE + 8;
+
+__device__ __forceinline__ int32_t ldpx(const void *p, ptrdiff_t idx, int is16) {
+    return is16 ? ((const __attribute__((address_space(1))) uint16_t *)p)[idx] : ((const __attribute__((address_space(1))) uint8_t *)p)[idx];  // pictures are global memory: no flat loads
+}
+__device__ __forceinline__ int32_t rnd(int32_t v, int n) { return (v + ((1 << n) >> 1)) >> n; }
+__device__ __forceinline__ void stpx(void *p, size_t idx, int is16, int32_t v, int bd) {
+    const int32_t hi = (1 << bd) - 1;
+    v                = v < 0 ? 0 : (v > hi ? hi : v);
+    if (is16)
+        ((__attribute__((address_space(1))) uint16_t *)p)[idx] = (uint16_t)v;
+    else
+        ((__attribute__((address_space(1))) uint8_t *)p)[idx] = (uint8_t)v;
+}
+
+// compound epilogue (inter_prediction.c:531-543 and its siblings): store the offset intermediate, or average with the stored
+// one and write the pixel
+__device__ __forceinline__ void comp_out(const SvtHipConvolveDesc &d, int y, int x, int32_t res, int32_t round_offset, int round_bits) {
+    uint16_t *cb = d.cbuf + (size_t)y * d.cbuf_stride + x;
+    if (d.compound == 1) {
+        *cb = (uint16_t)res;
+    } else {
+        int32_t tmp = *cb;
+        tmp         = d.compound == 3 ? (tmp * (int32_t)d.fwd_offset + res * (int32_t)d.bck_offset) >> 4 : (tmp + res) >> 1;
+        tmp -= round_offset;
+        stpx(d.dst, (size_t)y * d.dst_stride + x, d.is_16bit, rnd(tmp, round_bits), d.bit_depth);
+    }
+}
+
+// tile: index of the 64 x 64 tile inside the block (row-major); a tile beyond the block returns at once
+__device__ __forceinline__ void convolve_tile(const SvtHipConvolveDesc &d, const int tile, uint16_t *__restrict__ in, int16_t *__restrict__ im) {
+    if (d.w == 0 || d.h == 0)  // an unused slot of a fixed-size descriptor array (tf_picture.hip)
+        return;
+    const int tiles_x = (d.w + TILE - 1) / TILE;
+    const int x0 = (tile % tiles_x) * TILE, y0 = (tile / tiles_x) * TILE;
+    if (y0 >= d.h)
+        return;
+    const int tw = min(TILE, d.w - x0), th = min(TILE, d.h - y0);
+    const int tx = d.taps_x, ty = d.taps_y, is16 = d.is_16bit, bd = d.bit_depth, r0 = d.round_0, r1 = d.round_1;
+    const int fo_h = tx ? tx / 2 - 1 : 0, fo_v = ty ? ty / 2 - 1 : 0;
+    const int ew = tw + (tx ? tx - 1 : 0), eh = th + (ty ? ty - 1 : 0);  // staged extent
+    for (int idx = threadIdx.x; idx < eh * ew; idx += 256) {
+        const int r = idx / ew, c = idx - r * ew;
+        in[r * IP + c] = (uint16_t)ldpx(d.src, (ptrdiff_t)(y0 + r - fo_v) * d.src_stride + (x0 + c - fo_h), is16);
+    }
+    __syncthreads();
+    if (d.compound) {  // jnt_convolve_{2d_copy, x, y, 2d}
+        const int     offset_bits = bd + 2 * FILTER_BITS - r0, round_bits = 2 * FILTER_BITS - r0 - r1;
+        const int32_t round_offset = (1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1));
+        if (tx && ty) {
+            for (int idx = threadIdx.x; idx < eh * tw; idx += 256) {
+                const int r = idx / tw, c = idx - r * tw;
+                int32_t   sum = 1 << (bd + FILTER_BITS - 1);
+                for (int k = 0; k < tx; k++) sum += d.filter_x[k] * (int32_t)in[r * IP + c + k];
+                im[r * TILE + c] = (int16_t)(uint16_t)rnd(sum, r0);
+            }
+            __syncthreads();
+        }
+        for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+            const int r = idx / tw, c = idx - r * tw;
+            int32_t   res;
+            if (tx && ty) {
+                int32_t sum = 1 << offset_bits;
+                for (int k = 0; k < ty; k++) sum += d.filter_y[k] * (int32_t)im[(r + k) * TILE + c];
+                res = (uint16_t)rnd(sum, r1);
+            } else if (ty) {
+                res = 0;
+                for (int k = 0; k < ty; k++) res += d.filter_y[k] * (int32_t)in[(r + k) * IP + c];
+                res *= 1 << (FILTER_BITS - r0);
+                res = rnd(res, r1) + round_offset;
+            } else if (tx) {
+                res = 0;
+                for (int k = 0; k < tx; k++) res += d.filter_x[k] * (int32_t)in[r * IP + c + k];
+                res = (1 << (FILTER_BITS - r1)) * rnd(res, r0) + round_offset;
+            } else {
+                res = (uint16_t)((uint16_t)((int32_t)in[r * IP + c] << round_bits) + (uint16_t)round_offset);
+            }
+            comp_out(d, y0 + r, x0 + c, res, round_offset, round_bits);
+        }
+        return;
+    }
+    if (!tx && !ty) {  // 2d_copy_sr
+        for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+            const int r = idx / tw, c = idx - r * tw;
+            stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, in[r * IP + c], 16);
+        }
+        return;
+    }
+    if (!ty) {  // x_sr
+        const int bits = FILTER_BITS - r0;
+        for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+            const int r = idx / tw, c = idx - r * tw;
+            int32_t   res = 0;
+            for (int k = 0; k < tx; k++) res += d.filter_x[k] * (int32_t)in[r * IP + c + k];
+            stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(rnd(res, r0), bits), bd);
+        }
+        return;
+    }
+    if (!tx) {  // y_sr
+        for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+            const int r = idx / tw, c = idx - r * tw;
+            int32_t   res = 0;
+            for (int k = 0; k < ty; k++) res += d.filter_y[k] * (int32_t)in[(r + k) * IP + c];
+            stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(res, FILTER_BITS), bd);
+        }
+        return;
+    }
+    // 2d_sr
+    for (int idx = threadIdx.x; idx < eh * tw; idx += 256) {
+        const int r = idx / tw, c = idx - r * tw;
+        int32_t   sum = 1 << (bd + FILTER_BITS - 1);
+        for (int k = 0; k < tx; k++) sum += d.filter_x[k] * (int32_t)in[r * IP + c + k];
+        im[r * TILE + c] = (int16_t)(uint16_t)rnd(sum, r0);
+    }
+    __syncthreads();
+    const int bits = 2 * FILTER_BITS - r0 - r1, offset_bits = bd + 2 * FILTER_BITS - r0;
+    for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+        const int r = idx / tw, c = idx - r * tw;
+        int32_t   sum = 1 << offset_bits;
+        for (int k = 0; k < ty; k++) sum += d.filter_y[k] * (int32_t)im[(r + k) * TILE + c];
+        int32_t res = rnd(sum, r1) - ((1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1)));
+        if (!is16)
+            res = (int16_t)res;  // the 8-bit function narrows to int16 first (inter_prediction.c:343-345)
+        stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(res, bits), bd);
+    }
+
+}
+
+}  // namespace conv
+}  // namespace svthip
