@@ -99,3 +99,28 @@ def test_argument_checks(hip, orc):
     job.n_refs, job.bit_depth = n_refs, 12
     assert hip.svt_hip_tf_filter_picture(C.byref(job), None) == abi.SVT_HIP_ERR_BAD_PARAMETER
     assert hip.svt_hip_tf_filter_picture(None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+
+
+def test_filter_picture_4k(hip, orc):
+    """BASELINE size: one 3840x2160 8-bit picture against one neighbour (tf level 6 controls, luma + chroma), GPU == oracle on
+    every plane and every (b64) refinement state; and the size-independent property that a window of identical pictures
+    leaves the centre picture unchanged (every prediction is the picture itself, (sum w * x + sum w / 2) / sum w == x)."""
+    case = ("pan_4k", "pan", 3840, 2160, 1, 8, "m8_4k_tl2", tpc.LVL6)
+    decay = (2247286, 6156426, 6156426)
+    got, states, tot = run_gpu(hip, tpc.case_window(orc, case), case, decay)
+    pics = tpc.case_window(orc, case)
+    ostates, otot = tpc.run_oracle(orc, pics, case, decay)
+    assert tot == otot
+    assert np.array_equal(tpc.states_to_array(ostates), states)
+    for k, v in pics[0].arrays().items():
+        assert np.array_equal(got[k], v), (k, int((got[k] != v).sum()))
+    # identical pictures
+    same = tpc.case_window(orc, case)
+    for k, v in same[1].arrays().items():
+        v[...] = same[0].arrays()[k]
+    d = same[1].pyr.desc()
+    orc.orc_pyramid_frame(C.byref(d.full), C.byref(d.quarter), C.byref(d.sixteenth), 1)
+    before = {k: v.copy() for k, v in same[0].arrays().items()}
+    got, _, _ = run_gpu(hip, same, case, decay)
+    for k, v in before.items():
+        assert np.array_equal(got[k], v), k

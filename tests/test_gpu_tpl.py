@@ -80,6 +80,18 @@ def test_all_intra_wavefront_1080p(hip, orc):
         assert np.array_equal(got[k], v), (k, int((got[k] != v).sum()))
 
 
+def test_dispenser_frame_4k(hip, orc):
+    """BASELINE size: a 3840x2160 picture with 2+2 references (preset-8 tpl level), GPU == oracle."""
+    case = ("pan_4k", "pan", 3840, 2160, 120, dict(T.BASE))
+    a, b = T.TplScene(orc, case, key="m8_4k_tl2"), T.TplScene(orc, case, key="m8_4k_tl2")
+    got = run_gpu(hip, a)
+    assert orc.orc_tpl_dispenser_frame(C.byref(b.job())) == 0
+    for k, v in b.results().items():
+        assert np.array_equal(got[k], v), (k, int((got[k] != v).sum()))
+    modes = b.src_stats["best_mode"]
+    assert (modes == 16).sum() > 1000
+
+
 def test_argument_checks(hip, orc):
     s = T.TplScene(orc, T.CASES[0])
     dm = DevMap(hip)

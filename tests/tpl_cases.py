@@ -25,7 +25,7 @@ QUANT = {}
 
 
 class TplScene:
-    def __init__(self, orc, case):
+    def __init__(self, orc, case, key="m8_360p_tl0"):
         name, kind, w, h, qindex, opt = case
         self.case, self.w, self.h = case, w, h
         seed = sum(map(ord, name))
@@ -33,7 +33,7 @@ class TplScene:
         clip = me_cases.make_clip(kind, w, h, 5, seed=seed)
         self.pyrs = me_cases.build_pyramids(orc, clip)
         self.cur, l0, l1 = 2, [1, 0], [3, 4]
-        self.prm = me_cases.scenario_params("m8_360p_tl0", self.cur, l0, l1, 0, 1)
+        self.prm = me_cases.scenario_params(key, self.cur, l0, l1, 0, 1)
         self.me = me_cases.run_cpu(orc.orc_me_frame_range, self.prm, self.pyrs, self.cur, l0, l1, w, h)
         self.ref_pocs = [l0, l1]
         # 'reconstructions' of the reference pictures that are inside the sliding window: the source + coding noise
