@@ -52,3 +52,21 @@ def test_asm_hip_bitstream_md5(hip, case):
     assert int(m.group(1)) == int(m.group(2)) >= 170
     g = E.golden()[case]
     assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the HIP leaves installed\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,lp", [("p12_8bit", 1), ("p8_8bit", 4), ("p8_10bit", 2)])
+def test_batched_me_bitstream_md5(hip, case, lp):
+    """GPU, Tier B inside the real encoder: with SVTAV1_HIP_TIERB_ME=1 the b64 loop of me_process.c hands
+    every picture's open-loop ME to ONE svt_hip_me_frames call (tools/e2e/svt_hip_bind_me.c) instead of calling
+    svt_aom_motion_estimation_b64 per block; several ME threads (--lp) share the picture's results.  Same bitstream."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_ME": "1"})
+    m = re.search(r"svt_hip_bind_me: (\d+) pictures / (\d+) blocks", log)
+    assert m, "the batched ME path did not run:\n" + log[-2000:]
+    w, h, n, bd, preset = E.CASES[case]
+    assert int(m.group(1)) >= n - 2 and int(m.group(2)) == int(m.group(1)) * ((w + 63) // 64) * ((h + 63) // 64)
+    assert "falls back to the CPU search" not in log
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched ME\n{log[-1500:]}"

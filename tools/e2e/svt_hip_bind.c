@@ -55,6 +55,9 @@ static void *open_library(void) {
     return dlopen("libsvtav1_hip.so", RTLD_NOW | RTLD_GLOBAL);
 }
 
+static void *g_lib;
+static void *lib_sym(const char *name) { return g_lib ? dlsym(g_lib, name) : NULL; }
+
 int svt_hip_bind_install(char *msg, unsigned msg_len) {
     void *h = open_library();
     if (!h) {
@@ -90,6 +93,8 @@ int svt_hip_bind_install(char *msg, unsigned msg_len) {
         snprintf(msg, msg_len, "%s", p_err());
         return -1;
     }
+    g_lib = h;
+    svt_hip_bind_me_setup(lib_sym); /* Step 2b: batched open-loop ME (SVTAV1_HIP_TIERB_ME=1) */
     snprintf(msg, msg_len, "%u of %u RTCD pointers now point at HIP leaves", done, n_all);
     return (int)done;
 }

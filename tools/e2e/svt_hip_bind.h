@@ -20,4 +20,14 @@
  * Env SVTAV1_HIP_ONLY / SVTAV1_HIP_SKIP: comma-separated name prefixes to restrict the set (bisecting aid). */
 int svt_hip_bind_install(char *msg, unsigned msg_len);
 
+/* Step 2b (svt_hip_bind_me.c): whole-picture open-loop ME through svt_hip_me_frames.  Called from the b64 loop of
+ * me_process.c in front of svt_aom_motion_estimation_b64; returns 0 when the block's results have been filled in from the
+ * GPU, 1 when the caller must run the reference's own call (feature off, or a picture the batched path does not cover). */
+struct PictureParentControlSet;
+struct MeContext;
+struct EbPictureBufferDesc;
+int  svt_hip_bind_me_b64(struct PictureParentControlSet *pcs, uint32_t b64_index, struct MeContext *me_ctx, struct EbPictureBufferDesc *full,
+                         struct EbPictureBufferDesc *quarter, struct EbPictureBufferDesc *sixteenth);
+void svt_hip_bind_me_setup(void *(*sym)(const char *));
+
 #endif
