@@ -89,7 +89,7 @@ int svt_hip_bind_install(char *msg, unsigned msg_len) {
         sel[n++] = hip_bindings[i];
     }
     uint32_t done = 0;
-    if (p_install(sel, n, &done) != SVT_HIP_OK) {
+    if (n && p_install(sel, n, &done) != SVT_HIP_OK) { /* n == 0: SVTAV1_HIP_ONLY matched nothing — batched entry points only */
         snprintf(msg, msg_len, "%s", p_err());
         return -1;
     }
