@@ -70,3 +70,19 @@ def test_batched_me_bitstream_md5(hip, case, lp):
     assert "falls back to the CPU search" not in log
     g = E.golden()[case]
     assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched ME\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,lp", [("p8_8bit", 1), ("p8_8bit", 4), ("p8_10bit", 2), ("p12_8bit", 2)])
+def test_batched_tf_bitstream_md5(hip, case, lp):
+    """GPU, Tier B inside the real encoder: with SVTAV1_HIP_TIERB_TF=1 produce_temporally_filtered_pic hands the
+    whole picture to ONE svt_hip_tf_filter_picture call (tools/e2e/svt_hip_bind_tf.c) instead of running its block loop; together
+    with the batched open-loop ME.  Same bitstream."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_ME": "1"})
+    m = re.search(r"svt_hip_bind_tf: (\d+) pictures", log)
+    assert m and int(m.group(1)) >= 1, "the batched temporal filter did not run:\n" + log[-2000:]
+    assert "stays on the CPU" not in log
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched temporal filter\n{log[-1500:]}"

@@ -81,7 +81,8 @@ static void entry_release(PicEntry *e) {
 }
 
 #define SA(dst, srcv) (dst).width = (uint16_t)(srcv).width, (dst).height = (uint16_t)(srcv).height
-static void params_of(SvtHipMeParams *out, const PictureParentControlSet *pcs, const MeContext *me) {
+void svt_hip_bind_me_params(SvtHipMeParams *out, const PictureParentControlSet *pcs, const MeContext *me); /* also used by svt_hip_bind_tf.c */
+void svt_hip_bind_me_params(SvtHipMeParams *out, const PictureParentControlSet *pcs, const MeContext *me) {
     const SequenceControlSet *scs = pcs->scs;
     memset(out, 0, sizeof(*out));
     out->hme_search_method      = me->hme_search_method == FULL_SAD_SEARCH;
@@ -134,7 +135,8 @@ static void params_of(SvtHipMeParams *out, const PictureParentControlSet *pcs, c
     out->similar_brightness_refs = pcs->similar_brightness_refs;
     out->enable_me_8x8 = pcs->enable_me_8x8, out->enable_me_16x16 = pcs->enable_me_16x16;
     out->max_number_of_pus_per_sb = pcs->max_number_of_pus_per_sb;
-    out->max_cand = pcs->pa_me_data->max_cand, out->max_refs = pcs->pa_me_data->max_refs, out->max_l0 = pcs->pa_me_data->max_l0;
+    if (pcs->pa_me_data) /* not attached yet when the temporal filter runs (svt_hip_bind_tf.c): ME_MCTF does not store candidates */
+        out->max_cand = pcs->pa_me_data->max_cand, out->max_refs = pcs->pa_me_data->max_refs, out->max_l0 = pcs->pa_me_data->max_l0;
     out->only_l_bwd               = scs->mrp_ctrls.only_l_bwd;
     out->input_resolution_le_480p = scs->input_resolution <= INPUT_SIZE_480p_RANGE;
     out->picture_number           = pcs->picture_number;
@@ -158,7 +160,7 @@ static int compute_picture(PicEntry *e, PictureParentControlSet *pcs, MeContext 
     SvtHipMeFrameJob *job = (SvtHipMeFrameJob *)calloc(1, sizeof(*job));
     if (!job)
         return -1;
-    params_of(&job->prm, pcs, me);
+    svt_hip_bind_me_params(&job->prm, pcs, me);
     const SvtHipMeParams *p = &job->prm;
     const uint32_t nb = pcs->b64_total_count, stored = svt_hip_me_stored_pus(p);
     e->total = nb, e->stored = stored, e->max_refs = p->max_refs, e->max_cand = p->max_cand;

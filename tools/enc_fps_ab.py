@@ -1,3 +1,5 @@
+"""Encoder-level A/B on the GPU box: the patched reference encoder (oracle/_ref/e2e/SvtAv1EncApp) on a 33-frame 1080p clip with
+`--asm c`, with its open-loop ME on the GPU, and with ME + temporal filter on the GPU (tools/reference_hip.patch steps 2b / 6b)."""
 import os, re, subprocess, sys, tempfile, time
 sys.path.insert(0, "svt-av1-mod-by-patman_amd"); sys.path.insert(0, "tests")
 import numpy as np
@@ -13,11 +15,13 @@ with open(path, "wb") as f:
     for y in clip:
         f.write(y.tobytes()); f.write(np.full((H // 2) * (W // 2) * 2, 128, np.uint8).tobytes())
 for lp in (16, 4):
-    for name, asm, env in (("c", "c", {}), ("batched_me", "hip", {"SVTAV1_HIP_LIB": lib, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_ONLY": "__none__"})):
+    for name, asm, env in (("c", "c", {}), ("batched_me", "hip", {"SVTAV1_HIP_LIB": lib, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_ONLY": "__none__"}),
+                           ("batched_me_tf", "hip", {"SVTAV1_HIP_LIB": lib, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_ONLY": "__none__"})):
         t = time.time()
         r = subprocess.run([app, "-i", path, "-w", str(W), "-h", str(H), "--fps", "30", "-n", str(N), "--preset", "8", "--lp", str(lp), "--asm", asm,
                             "-b", os.path.join(tmp, name + ".ivf")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **env))
         m = re.search(r"Average Speed:\s+([0-9.]+) fps", r.stdout)
-        g = re.search(r"svt_hip_bind_me: .*", r.stdout)
-        print(lp, name, m.group(1) if m else r.stdout[-300:], "wall", round(time.time() - t, 1), g.group(0) if g else "")
-    print("identical", open(os.path.join(tmp, "c.ivf"), "rb").read() == open(os.path.join(tmp, "batched_me.ivf"), "rb").read())
+        g = re.findall(r"svt_hip_bind_(?:me|tf): .*", r.stdout)
+        print(lp, name, m.group(1) if m else r.stdout[-300:], "wall", round(time.time() - t, 1), " | ".join(g))
+    ref = open(os.path.join(tmp, "c.ivf"), "rb").read()
+    print("identical", [open(os.path.join(tmp, n + ".ivf"), "rb").read() == ref for n in ("batched_me", "batched_me_tf")])
