@@ -465,22 +465,25 @@ def encoder_level_fps(cores, frames_n=5, timeout_s=240):
         # the same encoder with its open-loop ME handed to svt_hip_me_frames picture by picture (tools/reference_hip.patch step 2b:
         # SVTAV1_HIP_TIERB_ME=1; SVTAV1_HIP_ONLY=<nothing>: every other kernel stays on the C table) — only with a GPU
         lib_so = os.path.join(ROOT, "svt-av1-mod-by-patman_amd", "csrc", "libsvtav1_hip.so")
-        gpu_env = {"SVTAV1_HIP_LIB": lib_so, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_ONLY": "__none__"}
+        gpu_env = {"SVTAV1_HIP_LIB": lib_so, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_TPL": "1", "SVTAV1_HIP_ONLY": "__none__"}
         if torch.cuda.is_available() and os.path.exists(lib_so):
             fps_h, r2 = run("hip", gpu_env, "h.ivf")
             m = re.search(r"svt_hip_bind_me: (\d+) pictures / (\d+) blocks", r2.stdout)
             mt = re.search(r"svt_hip_bind_tf: (\d+) pictures", r2.stdout)
+            mp = re.search(r"svt_hip_bind_tpl: (\d+) pictures", r2.stdout)
             same = None
             try:
                 same = open(os.path.join(tmp, "c.ivf"), "rb").read() == open(os.path.join(tmp, "h.ivf"), "rb").read()
             except OSError:
                 pass
-            res["with_gpu_me_and_temporal_filter"] = {
+            res["with_gpu_me_tf_tpl"] = {
                 "value": fps_h, "unit": "fps", "me_pictures_on_gpu": int(m.group(1)) if m else 0,
-                "tf_pictures_on_gpu": int(mt.group(1)) if mt else 0, "bitstream_identical_to_asm_c": same,
-                "sample": "the same binary with `--asm hip`, SVTAV1_HIP_TIERB_ME=1 SVTAV1_HIP_TIERB_TF=1, no Tier A leaves: me_process.c calls "
-                          "svt_hip_me_frames once per picture and produce_temporally_filtered_pic calls svt_hip_tf_filter_picture once per "
-                          "picture (planes uploaded and results downloaded per call over PCIe); every other kernel on the C table"}
+                "tf_pictures_on_gpu": int(mt.group(1)) if mt else 0, "tpl_pictures_on_gpu": int(mp.group(1)) if mp else 0,
+                "bitstream_identical_to_asm_c": same,
+                "sample": "the same binary with `--asm hip`, SVTAV1_HIP_TIERB_ME=1 SVTAV1_HIP_TIERB_TF=1 SVTAV1_HIP_TIERB_TPL=1, no Tier A leaves: "
+                          "me_process.c calls svt_hip_me_frames, produce_temporally_filtered_pic calls svt_hip_tf_filter_picture and the TPL "
+                          "dispenser kernel calls svt_hip_tpl_dispenser_frame, each once per picture (planes uploaded and results downloaded "
+                          "per call over PCIe); every other kernel on the C table"}
             # a clip long enough for the steady state (two mini-GOPs) at a size the C-only encoder finishes in seconds
             W2, H2, N2 = 1920, 1080, 33
             path2 = os.path.join(tmp, "clip1080.yuv")
@@ -501,7 +504,7 @@ def encoder_level_fps(cores, frames_n=5, timeout_s=240):
                 same2 = open(os.path.join(tmp, "c2.ivf"), "rb").read() == open(os.path.join(tmp, "h2.ivf"), "rb").read()
             except OSError:
                 same2 = None
-            res["gpu_me_and_temporal_filter_1080p_33_frames"] = {"asm_c_fps": a, "with_gpu_me_and_tf_fps": b, "bitstream_identical": same2,
+            res["gpu_me_tf_tpl_1080p_33_frames"] = {"asm_c_fps": a, "with_gpu_me_tf_tpl_fps": b, "bitstream_identical": same2,
                                                       "sample": f"same binary, 1920x1080 8-bit, 33 frames, --preset 8 --lp {cores}"}
         return res
     except subprocess.TimeoutExpired:

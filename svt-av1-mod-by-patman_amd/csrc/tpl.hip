@@ -321,8 +321,8 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     const SvtHipPlane8 &s = job->src, &r = job->recon;
     if (!s.buf || !r.buf || s.width < 16 || s.height < 16 || r.width != s.width || r.height != s.height)
         return bad("source / reconstruction planes missing or of different size");
-    if (s.org_x < TPL_PAD + 16 || s.org_y < TPL_PAD + 16 || r.org_x < TPL_PAD + 16 || r.org_y < TPL_PAD + 16)
-        return bad("planes need >= 48 samples of padding (TPL_PADX + one block)");
+    if (s.org_x < TPL_PAD || s.org_y < TPL_PAD || r.org_x < TPL_PAD || r.org_y < TPL_PAD)
+        return bad("planes need >= 32 samples of padding (TPL_PADX / TPL_PADY: the clipped vectors reach that far, reference_object.c:439-442)");
     if (s.stride < s.width + 2u * s.org_x || r.stride < r.width + 2u * r.org_x)
         return bad("stride smaller than the padded width");
     if (job->synth_blk_size != 16 && job->synth_blk_size != 8)
@@ -344,8 +344,8 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
             if (!f.recon || f.src_stride < s.width + 2u * TPL_PAD || f.recon_stride < s.width + 2u * TPL_PAD)
                 return bad("reference picture: reconstruction missing or stride too small");
             // the clipped vector keeps a block inside max_width + TPL_PAD: that must be inside the padded plane
-            if (f.max_width > s.width + (uint32_t)(s.org_x - TPL_PAD) || f.max_height > s.height + (uint32_t)(s.org_y - TPL_PAD))
-                return bad("reference picture: max_width / max_height reach beyond the padding");
+            if (f.max_width > s.width || f.max_height > s.height)
+                return bad("reference picture: max_width / max_height beyond the picture (its planes must be padded by >= 32 samples around them)");
         }
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;

@@ -86,3 +86,23 @@ def test_batched_tf_bitstream_md5(hip, case, lp):
     assert "stays on the CPU" not in log
     g = E.golden()[case]
     assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched temporal filter\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,lp", [("p8_8bit", 1), ("p8_8bit", 4), ("p8_10bit", 2), ("p12_8bit", 2)])
+def test_batched_tpl_bitstream_md5(hip, case, lp):
+    """GPU, Tier B inside the real encoder: with SVTAV1_HIP_TIERB_TPL=1 svt_aom_tpl_disp_kernel hands every
+    picture's TPL dispenser to ONE svt_hip_tpl_dispenser_frame call (tools/e2e/svt_hip_bind_tpl.c); here together with the batched
+    ME and the batched temporal filter: all three whole-picture entry points inside the running encoder.  Same bitstream."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_TPL": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_ME": "1"})
+    m = re.search(r"svt_hip_bind_tpl: (\d+) pictures", log)
+    assert m, log[-2000:]
+    if E.CASES[case][4] <= 10:   # presets M7 ... M10 run the tpl level the batched dispenser covers
+        assert int(m.group(1)) >= 1, "the batched TPL dispenser did not run:\n" + log[-2000:]
+    else:                        # preset 12: 32x32 dispenser blocks with sub-sampled transforms -> every picture declined, the reference's loop runs
+        assert int(m.group(1)) == 0
+    assert "stays on the CPU" not in log
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched TPL dispenser\n{log[-1500:]}"

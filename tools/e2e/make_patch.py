@@ -66,12 +66,22 @@ def patch_temporal_filtering(t):
     return t[:i] + "    if (svt_hip_bind_tf_picture(pcs_list, list_input_picture_ptr, index_center, ctx, is_highbd))\n" + t[i:]
 
 
+def patch_src_ops_process(t):
+    """Step 3c: the whole-picture TPL dispenser in front of the per-block call of the segment loop (no-tiles path)."""
+    t = edit(t, '#include "src_ops_process.h"\n', '#include "src_ops_process.h"\n#include "svt_hip_bind.h"\n')
+    old = ("                        tpl_mc_flow_dispenser_sb_generic(pcs->scs->enc_ctx,\n"
+           "                                                         scs,\n")
+    new = ("                        if (svt_hip_bind_tpl_sb(pcs, frame_idx, context_ptr->sb_index, in_results_ptr->qIndex))\n" + old)
+    return edit(t, old, new)
+
+
 def main():
     pieces = []
     for rel, fn in (("Source/Lib/Globals/enc_settings.c", patch_enc_settings),
                     ("Source/Lib/Globals/enc_handle.c", patch_enc_handle),
                     ("Source/Lib/Codec/me_process.c", patch_me_process),
-                    ("Source/Lib/Codec/temporal_filtering.c", patch_temporal_filtering)):
+                    ("Source/Lib/Codec/temporal_filtering.c", patch_temporal_filtering),
+                    ("Source/Lib/Codec/src_ops_process.c", patch_src_ops_process)):
         with open(os.path.join(REF, rel), encoding="utf-8", errors="surrogateescape") as f:
             a = f.read()
         b = fn(a)

@@ -96,6 +96,7 @@ int svt_hip_bind_install(char *msg, unsigned msg_len) {
     g_lib = h;
     svt_hip_bind_me_setup(lib_sym); /* Step 2b: batched open-loop ME (SVTAV1_HIP_TIERB_ME=1) */
     svt_hip_bind_tf_setup(lib_sym); /* Step 6b: whole-picture temporal filter (SVTAV1_HIP_TIERB_TF=1) */
+    svt_hip_bind_tpl_setup(lib_sym); /* Step 3c: whole-picture TPL dispenser (SVTAV1_HIP_TIERB_TPL=1) */
     snprintf(msg, msg_len, "%u of %u RTCD pointers now point at HIP leaves", done, n_all);
     return (int)done;
 }

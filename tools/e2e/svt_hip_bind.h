@@ -36,4 +36,9 @@ int  svt_hip_bind_tf_picture(struct PictureParentControlSet **pcs_list, struct E
                              struct MeContext *ctx, int is_highbd);
 void svt_hip_bind_tf_setup(void *(*sym)(const char *));
 
+/* Step 3c (svt_hip_bind_tpl.c): the TPL dispenser of a picture through svt_hip_tpl_dispenser_frame.  Called in front of
+ * tpl_mc_flow_dispenser_sb_generic in svt_aom_tpl_disp_kernel; 0 = the picture ran on the GPU, 1 = the caller runs its own call. */
+int  svt_hip_bind_tpl_sb(struct PictureParentControlSet *pcs, int32_t frame_idx, uint32_t sb_index, int32_t qindex);
+void svt_hip_bind_tpl_setup(void *(*sym)(const char *));
+
 #endif

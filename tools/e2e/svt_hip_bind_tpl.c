@@ -1,0 +1,260 @@
+/*
+ * svt_hip_bind_tpl.c — OUR glue compiled into the reference encoder by tools/reference_hip.patch (Step 3c of INTEGRATION.md):
+ * the TPL dispenser of a whole picture through svt_hip_tpl_dispenser_frame instead of one tpl_mc_flow_dispenser_sb_generic call
+ * per 64x64 block (Source/Lib/Codec/src_ops_process.c:519-1207, called from svt_aom_tpl_disp_kernel :1964).
+ * The patch puts `if (svt_hip_bind_tpl_sb(pcs, frame_idx, sb_index, qIndex))` in front of the reference's per-block call: the
+ * first block of a picture that arrives runs the whole picture on the GPU (source, the references' source and TPL
+ * reconstruction pictures and the picture's ME results uploaded; the TPL reconstruction, TplStats and TplSrcStats downloaded and
+ * stored where the reference's loop stores them, result_model_store's grids included); the other blocks wait and return.
+ * Covered: the configuration of include/svt_hip_tpl.h (tpl levels of presets M7 ... M10); anything else returns 1 for every block
+ * of the picture and the reference's own loop runs.  Active with `--asm hip` and SVTAV1_HIP_TIERB_TPL=1.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "definitions.h"
+#include "encode_context.h"
+#include "pcs.h"
+#include "sequence_control_set.h"
+
+#include "svt_hip.h"
+#include "svt_hip_tpl.h"
+#include "svt_hip_bind.h"
+
+typedef struct TplApi {
+    int32_t (*malloc_)(void **, size_t);
+    int32_t (*free_)(void *);
+    int32_t (*upload)(void *, const void *, size_t, void *);
+    int32_t (*download)(void *, const void *, size_t, void *);
+    int32_t (*memset_)(void *, int32_t, size_t, void *);
+    int32_t (*sync)(void *);
+    int32_t (*tpl_frame)(const SvtHipTplFrameJob *, void *);
+    uint64_t (*ws_bytes)(uint32_t, uint32_t);
+    const char *(*last_error)(void);
+} TplApi;
+static TplApi        g_api;
+static int           g_active;
+static unsigned long g_pictures;
+
+static void report(void) { fprintf(stderr, "svt_hip_bind_tpl: %lu pictures through svt_hip_tpl_dispenser_frame\n", g_pictures); }
+
+void svt_hip_bind_tpl_setup(void *(*sym)(const char *)) {
+    g_api.malloc_    = (int32_t(*)(void **, size_t))sym("svt_hip_malloc");
+    g_api.free_      = (int32_t(*)(void *))sym("svt_hip_free");
+    g_api.upload     = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_upload");
+    g_api.download   = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_download");
+    g_api.memset_    = (int32_t(*)(void *, int32_t, size_t, void *))sym("svt_hip_memset");
+    g_api.sync       = (int32_t(*)(void *))sym("svt_hip_stream_sync");
+    g_api.tpl_frame  = (int32_t(*)(const SvtHipTplFrameJob *, void *))sym("svt_hip_tpl_dispenser_frame");
+    g_api.ws_bytes   = (uint64_t(*)(uint32_t, uint32_t))sym("svt_hip_tpl_workspace_bytes");
+    g_api.last_error = (const char *(*)(void))sym("svt_hip_last_error");
+    const char *env  = getenv("SVTAV1_HIP_TIERB_TPL");
+    g_active = env && atoi(env) && g_api.malloc_ && g_api.free_ && g_api.upload && g_api.download && g_api.memset_ && g_api.sync &&
+        g_api.tpl_frame && g_api.ws_bytes;
+    if (g_active)
+        atexit(report);
+}
+
+typedef struct TplEntry {
+    PictureParentControlSet *pcs;
+    uint64_t                 picture_number;
+    int32_t                  frame_idx;
+    int                      state; /* 0 free, 1 being computed, 2 done on the GPU, 3 not covered / failed */
+    uint32_t                 seen, total;
+} TplEntry;
+#define N_TPL 16
+static TplEntry        g_tab[N_TPL];
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t  g_cv = PTHREAD_COND_INITIALIZER;
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t luma_bytes(const EbPictureBufferDesc *d) { return (size_t)d->stride_y * (d->height + 2u * d->org_y); }
+static int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t qindex) {
+    SequenceControlSet *scs = pcs->scs;
+    EncodeContext      *enc = scs->enc_ctx;
+    const TplControls  *tc  = &pcs->tpl_ctrls;
+    EbPictureBufferDesc *src = pcs->enhanced_pic, *recon = enc->mc_flow_rec_picture_buffer[frame_idx];
+    if (tc->dispenser_search_level != 0 || tc->intra_mode_end != DC_PRED || !tc->use_sad_in_src_search || tc->subsample_tx != 0 ||
+        tc->subpel_depth != FULL_PEL || tc->compute_rate || !scs->in_loop_ois || src->org_x < 32 || src->org_y < 32 || recon->org_x < 32 ||
+        recon->org_y < 32 || (tc->synth_blk_size != 8 && tc->synth_blk_size != 16 && tc->synth_blk_size != 32) ||
+        scs->static_config.tile_rows || scs->static_config.tile_columns)
+        return 1;
+    SvtHipTplFrameJob *job = (SvtHipTplFrameJob *)calloc(1, sizeof(*job));
+    if (!job)
+        return 1;
+    const uint32_t W = src->width, H = src->height, aw = pcs->aligned_width, ah = pcs->aligned_height;
+    const uint32_t a16 = (aw + 15) >> 4, rows16 = (ah + 15) >> 4, nb = pcs->b64_total_count;
+    MotionEstimationData *med = pcs->pa_me_data;
+    const uint32_t stored = pcs->enable_me_16x16 ? (pcs->enable_me_8x8 ? 85u : 21u) : 5u;
+    const size_t   n_mv = (size_t)nb * stored * med->max_refs * 4, n_cand = (size_t)nb * stored * med->max_cand, n_cnt = (size_t)nb * stored;
+    const size_t   n_stats = (size_t)a16 * rows16 * sizeof(SvtHipTplStats), n_sst = (size_t)a16 * rows16 * sizeof(SvtHipTplSrcStats);
+    const uint64_t wsb = g_api.ws_bytes(W, H);
+    size_t         need = al256(luma_bytes(src) + 64) + al256(luma_bytes(recon) + 64) + al256(n_mv) + al256(n_cand) + al256(n_cnt) + al256(n_stats) +
+        al256(n_sst) + al256(wsb);
+    EbPictureBufferDesc *rsrc[2][4] = {{0}}, *rrec[2][4] = {{0}};
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 4; r++) {
+            EbPictureBufferDesc *p = (EbPictureBufferDesc *)pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_ptr;
+            if (!p || !p->buffer_y)
+                continue;
+            rsrc[l][r] = p, need += al256(luma_bytes(p) + 64);
+            if (pcs->tpl_data.ref_in_slide_window[l][r]) {
+                const uint64_t poc = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
+                uint32_t       k = 0;
+                while (k < MAX_TPL_LA_SW && enc->poc_map_idx[k] != poc) k++;
+                if (k < MAX_TPL_LA_SW && enc->mc_flow_rec_picture_buffer[k])
+                    rrec[l][r] = enc->mc_flow_rec_picture_buffer[k], need += al256(luma_bytes(rrec[l][r]) + 64);
+            }
+        }
+    /* host-side staging of the scattered inputs: the ME results live in one MeSbResults per block */
+    uint8_t *h_mv = (uint8_t *)malloc(n_mv), *h_cand = (uint8_t *)malloc(n_cand), *h_cnt = (uint8_t *)malloc(n_cnt);
+    SvtHipTplSrcStats *h_sst = (SvtHipTplSrcStats *)calloc((size_t)a16 * rows16, sizeof(*h_sst));
+    SvtHipTplStats    *h_st  = (SvtHipTplStats *)calloc((size_t)a16 * rows16, sizeof(*h_st));
+    for (uint32_t i = 0; i < nb; i++) {
+        const MeSbResults *res = med->me_results[i];
+        memcpy(h_mv + (size_t)i * stored * med->max_refs * 4, res->me_mv_array, (size_t)stored * med->max_refs * 4);
+        memcpy(h_cand + (size_t)i * stored * med->max_cand, res->me_candidate_array, (size_t)stored * med->max_cand);
+        memcpy(h_cnt + (size_t)i * stored, res->total_me_candidate_index, stored);
+    }
+    for (size_t i = 0; i < (size_t)a16 * rows16; i++) {
+        const TplSrcStats *q = &med->tpl_src_stats_buffer[i];
+        h_sst[i].srcrf_dist = q->srcrf_dist, h_sst[i].srcrf_rate = q->srcrf_rate, h_sst[i].ref_frame_poc = q->ref_frame_poc;
+        h_sst[i].mv_row = q->mv.row, h_sst[i].mv_col = q->mv.col, h_sst[i].best_rf_idx = q->best_rf_idx, h_sst[i].best_mode = q->best_mode;
+        h_sst[i].best_intra_mode = (uint8_t)q->best_intra_mode;
+    }
+    uint8_t *dev = NULL;
+    int      rc  = g_api.malloc_((void **)&dev, need);
+    size_t   off = 0;
+#define PUT(dst, hostp, n) (dst = dev + off, off += al256((n) + 64), g_api.upload(dst, hostp, n, NULL))
+    uint8_t *d_src = NULL, *d_rec = NULL, *d_mv = NULL, *d_cand = NULL, *d_cnt = NULL, *d_st = NULL, *d_sst = NULL, *d_p = NULL;
+    if (rc == 0)
+        rc = PUT(d_src, src->buffer_y, luma_bytes(src)) | PUT(d_rec, recon->buffer_y, luma_bytes(recon)) | PUT(d_mv, h_mv, n_mv) |
+            PUT(d_cand, h_cand, n_cand) | PUT(d_cnt, h_cnt, n_cnt) | PUT(d_sst, h_sst, n_sst);
+    if (rc == 0) {
+        d_st = dev + off, off += al256(n_stats);
+        rc   = g_api.memset_(d_st, 0, n_stats, NULL);
+    }
+    job->src.buf = d_src, job->src.stride = src->stride_y, job->src.org_x = src->org_x, job->src.org_y = src->org_y, job->src.width = (uint16_t)W,
+    job->src.height = (uint16_t)H;
+    job->recon = job->src, job->recon.buf = d_rec, job->recon.stride = recon->stride_y, job->recon.org_x = recon->org_x, job->recon.org_y = recon->org_y;
+    for (int l = 0; rc == 0 && l < 2; l++)
+        for (int r = 0; rc == 0 && r < 4; r++) {
+            if (!rsrc[l][r])
+                continue;
+            SvtHipTplRef        *f = &job->ref[l][r];
+            EbPictureBufferDesc *p = rsrc[l][r];
+            rc                     = PUT(d_p, p->buffer_y, luma_bytes(p));
+            f->src = d_p + (size_t)p->org_y * p->stride_y + p->org_x, f->src_stride = p->stride_y;
+            f->recon = f->src, f->recon_stride = f->src_stride;
+            if (rc == 0 && rrec[l][r]) {
+                EbPictureBufferDesc *q = rrec[l][r];
+                rc                     = PUT(d_p, q->buffer_y, luma_bytes(q));
+                f->recon = d_p + (size_t)q->org_y * q->stride_y + q->org_x, f->recon_stride = q->stride_y;
+            }
+            f->picture_number = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
+            f->max_width = p->max_width, f->max_height = p->max_height;
+            const int32_t grp = pcs->tpl_data.ref_tpl_group_idx[l][r];
+            f->usable = !(grp > 0 && pcs->tpl_data.base_pcs->tpl_valid_pic[grp] == 0);
+        }
+    if (rc == 0) {
+        job->me_mv_array = (const uint32_t *)d_mv, job->me_candidate_array = d_cand, job->total_me_candidate_index = d_cnt;
+        job->max_cand = med->max_cand, job->max_refs = med->max_refs, job->max_l0 = med->max_l0;
+        job->enable_me_16x16 = pcs->enable_me_16x16, job->stored_pus = (uint8_t)stored;
+        job->pf_shape = (uint8_t)tc->pf_shape;
+        job->disable_intra_pred = tc->disable_intra_pred_nref && (pcs->temporal_layer_index == pcs->hierarchical_levels);
+        job->is_ref = pcs->tpl_data.is_ref, job->i_slice = pcs->slice_type == I_SLICE, job->tpl_i_slice = pcs->tpl_data.tpl_slice_type == I_SLICE;
+        job->src_data_ready = pcs->tpl_src_data_ready, job->store_src_stats = scs->tpl_lad_mg > 0, job->synth_blk_size = 16;
+        for (int i = 0; i < 2; i++) {
+            job->round_fp[i] = enc->quants_8bit.y_round_fp[qindex][i], job->quant_fp[i] = enc->quants_8bit.y_quant_fp[qindex][i];
+            job->dequant[i] = enc->deq_8bit.y_dequant_qtx[qindex][i];
+        }
+        job->stats = (SvtHipTplStats *)d_st, job->src_stats = (SvtHipTplSrcStats *)d_sst;
+        job->workspace = dev + off, job->workspace_bytes = wsb;
+        rc = g_api.tpl_frame(job, NULL);
+    }
+    if (rc == 0) {
+        rc = g_api.download(recon->buffer_y, d_rec, luma_bytes(recon), NULL) | g_api.download(h_st, d_st, n_stats, NULL) |
+            g_api.download(h_sst, d_sst, n_sst, NULL) | g_api.sync(NULL);
+    }
+    if (rc == 0) {
+        /* result_model_store (src_ops_process.c:266-340) from the 16x16 grid, and the source-based statistics, block by block in
+         * the reference's order (64x64 blocks raster, 16x16 blocks in z-order inside: a 32x32 synthesizer cell keeps its last block) */
+        const uint32_t bw64 = (aw + 63) / 64;
+        for (uint32_t sb = 0; sb < nb; sb++)
+            for (uint32_t z = 0; z < 16; z++) {
+                const uint32_t bx = (z & 1) | ((z >> 2) & 1) << 1, by = ((z >> 1) & 1) | ((z >> 3) & 1) << 1;
+                const uint32_t x = (sb % bw64) * 64 + bx * 16, y = (sb / bw64) * 64 + by * 16;
+                if (x + 8 > W || y + 8 > H)
+                    continue;
+                const SvtHipTplStats *s = &h_st[(size_t)(y >> 4) * a16 + (x >> 4)];
+                TplStats              t;
+                memset(&t, 0, sizeof(t));
+                t.srcrf_dist = s->srcrf_dist, t.recrf_dist = s->recrf_dist, t.srcrf_rate = s->srcrf_rate, t.recrf_rate = s->recrf_rate;
+                t.mv.row = s->mv_row, t.mv.col = s->mv_col, t.ref_frame_poc = s->ref_frame_poc;
+                if (tc->synth_blk_size == 32) {
+                    *med->tpl_stats[(size_t)(y >> 5) * ((aw + 31) / 32) + (x >> 5)] = t;
+                } else if (tc->synth_blk_size == 16) {
+                    *med->tpl_stats[(size_t)(y >> 4) * a16 + (x >> 4)] = t;
+                } else {
+                    const uint32_t stride = a16 << 1;
+                    t.srcrf_dist = max64(1, t.srcrf_dist / 4), t.recrf_dist = max64(1, t.recrf_dist / 4);
+                    t.srcrf_rate = max64(1, t.srcrf_rate / 4), t.recrf_rate = max64(1, t.recrf_rate / 4);
+                    TplStats **d = &med->tpl_stats[(size_t)(y >> 3) * stride + (x >> 3)];
+                    *d[0] = t, *d[1] = t, *d[stride] = t, *d[stride + 1] = t;
+                }
+                if (!job->src_data_ready && job->store_src_stats) {
+                    const SvtHipTplSrcStats *q = &h_sst[(size_t)(y >> 4) * a16 + (x >> 4)];
+                    TplSrcStats             *o = &med->tpl_src_stats_buffer[(size_t)(y >> 4) * a16 + (x >> 4)];
+                    o->srcrf_dist = q->srcrf_dist, o->srcrf_rate = q->srcrf_rate, o->ref_frame_poc = q->ref_frame_poc;
+                    o->mv.row = q->mv_row, o->mv.col = q->mv_col, o->best_rf_idx = q->best_rf_idx, o->best_mode = q->best_mode;
+                    o->best_intra_mode = (PredictionMode)q->best_intra_mode;
+                }
+            }
+    }
+    if (rc != 0)
+        fprintf(stderr, "svt_hip_bind_tpl: picture %llu stays on the CPU (%s)\n", (unsigned long long)pcs->picture_number,
+                g_api.last_error ? g_api.last_error() : "?");
+    if (dev)
+        g_api.free_(dev);
+    free(h_mv), free(h_cand), free(h_cnt), free(h_sst), free(h_st), free(job);
+    return rc != 0;
+}
+
+/* Returns 0 when the picture's dispenser ran on the GPU (the caller skips its per-block call), 1 when the caller must run it. */
+int svt_hip_bind_tpl_sb(PictureParentControlSet *pcs, int32_t frame_idx, uint32_t sb_index, int32_t qindex) {
+    (void)sb_index;
+    if (!g_active)
+        return 1;
+    pthread_mutex_lock(&g_mu);
+    TplEntry *e = NULL, *fr = NULL;
+    for (int i = 0; i < N_TPL; i++) {
+        if (g_tab[i].state && g_tab[i].pcs == pcs && g_tab[i].picture_number == pcs->picture_number && g_tab[i].frame_idx == frame_idx)
+            e = &g_tab[i];
+        else if (!g_tab[i].state && !fr)
+            fr = &g_tab[i];
+    }
+    if (!e) {
+        if (!fr) {
+            pthread_mutex_unlock(&g_mu);
+            return 1;
+        }
+        e = fr;
+        e->pcs = pcs, e->picture_number = pcs->picture_number, e->frame_idx = frame_idx, e->state = 1, e->seen = 0, e->total = pcs->b64_total_count;
+        pthread_mutex_unlock(&g_mu);
+        const int rc = run_picture(pcs, frame_idx, qindex);
+        pthread_mutex_lock(&g_mu);
+        e->state = rc == 0 ? 2 : 3;
+        g_pictures += rc == 0;
+        pthread_cond_broadcast(&g_cv);
+    }
+    while (e->state == 1) pthread_cond_wait(&g_cv, &g_mu);
+    const int on_gpu = e->state == 2;
+    if (++e->seen >= e->total)
+        memset(e, 0, sizeof(*e));
+    pthread_mutex_unlock(&g_mu);
+    return on_gpu ? 0 : 1;
+}

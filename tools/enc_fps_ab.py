@@ -16,12 +16,14 @@ with open(path, "wb") as f:
         f.write(y.tobytes()); f.write(np.full((H // 2) * (W // 2) * 2, 128, np.uint8).tobytes())
 for lp in (16, 4):
     for name, asm, env in (("c", "c", {}), ("batched_me", "hip", {"SVTAV1_HIP_LIB": lib, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_ONLY": "__none__"}),
-                           ("batched_me_tf", "hip", {"SVTAV1_HIP_LIB": lib, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_ONLY": "__none__"})):
+                           ("batched_me_tf", "hip", {"SVTAV1_HIP_LIB": lib, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_ONLY": "__none__"}),
+                           ("batched_me_tf_tpl", "hip", {"SVTAV1_HIP_LIB": lib, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_TF": "1",
+                                                         "SVTAV1_HIP_TIERB_TPL": "1", "SVTAV1_HIP_ONLY": "__none__"})):
         t = time.time()
         r = subprocess.run([app, "-i", path, "-w", str(W), "-h", str(H), "--fps", "30", "-n", str(N), "--preset", "8", "--lp", str(lp), "--asm", asm,
                             "-b", os.path.join(tmp, name + ".ivf")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **env))
         m = re.search(r"Average Speed:\s+([0-9.]+) fps", r.stdout)
-        g = re.findall(r"svt_hip_bind_(?:me|tf): .*", r.stdout)
+        g = re.findall(r"svt_hip_bind_(?:me|tf|tpl): \d+ pictures", r.stdout)
         print(lp, name, m.group(1) if m else r.stdout[-300:], "wall", round(time.time() - t, 1), " | ".join(g))
     ref = open(os.path.join(tmp, "c.ivf"), "rb").read()
-    print("identical", [open(os.path.join(tmp, n + ".ivf"), "rb").read() == ref for n in ("batched_me", "batched_me_tf")])
+    print("identical", [open(os.path.join(tmp, n + ".ivf"), "rb").read() == ref for n in ("batched_me", "batched_me_tf", "batched_me_tf_tpl")])
