@@ -4,7 +4,7 @@
  * Reference interface replaced (paths relative to /root/reference):
  *   Source/Lib/Codec/src_ops_process.c:519-1207   tpl_mc_flow_dispenser_sb_generic, called per 64x64 block from
  *                                                 tpl_mc_flow_dispenser (:1348-1410) / svt_aom_tpl_disp_kernel (:1964)
- * for the configuration the reference runs at presets M7 ... M10 (tpl level 4 of set_tpl_params, initial_rc_process.c:359-370,
+ * for the configuration the reference runs at presets M7 ... M9 (and M10 with VBR: tpl level 4 of set_tpl_params, initial_rc_process.c:284-296, 359-370;
  * and level 3 without its sub-pel refinement): 16x16 blocks (dispenser_search_level 0), DC intra prediction only
  * (intra_mode_end == DC_PRED), SAD in the source-based search, full-pel vectors straight from the open-loop ME results,
  * no transform sub-sampling, no rate estimate (compute_rate 0), any coefficient shape (pf_shape).  Per block:

@@ -23,6 +23,16 @@ CASES = {
 }
 
 
+# larger clips with ragged sizes (neither dimension a multiple of 64 or 16: partial 64x64 / 16x16 blocks at the right and bottom
+# edges, several ME / TF / TPL segments) — for the batched (Tier B) paths only: one PCIe round trip per leaf call makes the
+# Tier A run of such a clip take minutes
+TIER_B_CASES = {
+    "p8_8bit_ragged": (424, 232, 17, 8, 8),
+    "p10_10bit_ragged": (360, 200, 10, 10, 10),
+}
+ALL_CASES = dict(CASES, **TIER_B_CASES)
+
+
 def have_app():
     return os.path.exists(APP)
 
@@ -46,7 +56,7 @@ def write_clip(path, w, h, n, bd, seed=7):
 
 def encode(case, workdir, asm, lp=1, env_extra=None, timeout=900):
     """Runs the encoder; returns ({'ivf': md5, 'recon': md5}, log text)."""
-    w, h, n, bd, preset = CASES[case]
+    w, h, n, bd, preset = ALL_CASES[case]
     clip = os.path.join(workdir, f"{case}.yuv")
     if not os.path.exists(clip):
         write_clip(clip, w, h, n, bd)

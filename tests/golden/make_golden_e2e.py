@@ -18,11 +18,11 @@ import e2e_cases as E  # noqa: E402
 def main():
     out = {}
     with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None) as d:
-        for case in E.CASES:
+        for case in E.ALL_CASES:
             m1, _ = E.encode(case, d, "c", lp=1)
             m4, _ = E.encode(case, d, "c", lp=4)
             assert m1 == m4, f"{case}: --lp 1 and --lp 4 differ"
-            out[case] = dict(zip(("width", "height", "frames", "bit_depth", "preset"), E.CASES[case]), **m1)
+            out[case] = dict(zip(("width", "height", "frames", "bit_depth", "preset"), E.ALL_CASES[case]), **m1)
             print(case, m1)
     with open(E.GOLDEN, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
