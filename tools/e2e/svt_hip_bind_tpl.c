@@ -6,7 +6,7 @@
  * first block of a picture that arrives runs the whole picture on the GPU (source, the references' source and TPL
  * reconstruction pictures and the picture's ME results uploaded; the TPL reconstruction, TplStats and TplSrcStats downloaded and
  * stored where the reference's loop stores them, result_model_store's grids included); the other blocks wait and return.
- * Covered: the configuration of include/svt_hip_tpl.h (tpl levels of presets M7 ... M10); anything else returns 1 for every block
+ * Covered: the configuration of include/svt_hip_tpl.h (the tpl level of presets M7 ... M9); anything else returns 1 for every block
  * of the picture and the reference's own loop runs.  Active with `--asm hip` and SVTAV1_HIP_TIERB_TPL=1.
  */
 #include <pthread.h>
