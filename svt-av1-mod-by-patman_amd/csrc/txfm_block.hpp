@@ -214,7 +214,9 @@ __device__ __forceinline__ void coop_store_tile(const int32_t *__restrict__ lds,
                 const int e = 4 * q, r = e / IW, c = e % IW;
                 int4      v;
                 v.x = lds[r * PW + c], v.y = lds[r * PW + c + 1], v.z = lds[r * PW + c + 2], v.w = lds[r * PW + c + 3];
-                ((int4 *)g)[q] = v;
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i nv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nv, (v4i *)g + q);  // written once, never read by this kernel: keep it out of the caches
             }
         }
     } else {
@@ -250,7 +252,7 @@ __device__ __forceinline__ void txfm_block(uint8_t *__restrict__ base, const Svt
                 if (!(d.flags & SVT_HIP_TX_SRC_PRED)) {
                     const int16_t *rp = (const int16_t *)(base + d.residual_off) + row0;
 #pragma unroll
-                    for (int r = 0; r < H; r++, rp += step) v[r] = (int32_t)((uint32_t)(int32_t)*rp << sh0);
+                    for (int r = 0; r < H; r++, rp += step) v[r] = (int32_t)((uint32_t)(int32_t)__builtin_nontemporal_load(rp) << sh0);  // read once
                 } else {  // residual = source - prediction (svt_aom_[highbd_]subtract_block), never materialised
                     const ptrdiff_t pstep = ud ? -(ptrdiff_t)d.pred_stride : (ptrdiff_t)d.pred_stride;
                     const ptrdiff_t prow0 = (ud ? (ptrdiff_t)(H - 1) * d.pred_stride : 0) + t;
@@ -472,7 +474,7 @@ __device__ __forceinline__ void txfm_block(uint8_t *__restrict__ base, const Svt
             if (d.flags & SVT_HIP_TX_PIXEL16) {
                 const uint16_t *pr = (const uint16_t *)(base + d.pred_off) + r0 * (ptrdiff_t)d.pred_stride + t;
 #pragma unroll
-                for (int r = 0; r < H; r += 2) predv[r / 2] = (uint32_t)pr[(ptrdiff_t)r * ps] | ((uint32_t)pr[(ptrdiff_t)(r + 1) * ps] << 16);
+                for (int r = 0; r < H; r += 2) predv[r / 2] = (uint32_t)__builtin_nontemporal_load(pr + (ptrdiff_t)r * ps) | ((uint32_t)__builtin_nontemporal_load(pr + (ptrdiff_t)(r + 1) * ps) << 16);
             } else {
                 const uint8_t *pr = base + d.pred_off + r0 * (ptrdiff_t)d.pred_stride + t;
 #pragma unroll
@@ -482,7 +484,7 @@ __device__ __forceinline__ void txfm_block(uint8_t *__restrict__ base, const Svt
         if (d.flags & SVT_HIP_TX_PIXEL16) {
             uint16_t *rc = (uint16_t *)(base + d.recon_off) + r0 * (ptrdiff_t)d.recon_stride + t;
 #pragma unroll
-            for (int r = 0; r < H; r++, rc += rs) *rc = clip_pixel_add((uint16_t)(predv[r / 2] >> (16 * (r & 1))), v[r], bd);
+            for (int r = 0; r < H; r++, rc += rs) __builtin_nontemporal_store(clip_pixel_add((uint16_t)(predv[r / 2] >> (16 * (r & 1))), v[r], bd), rc);
         } else {
             uint8_t *rc = base + d.recon_off + r0 * (ptrdiff_t)d.recon_stride + t;
 #pragma unroll
