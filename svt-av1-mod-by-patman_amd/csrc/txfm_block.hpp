@@ -191,14 +191,17 @@ __device__ __forceinline__ uint64_t group_sum64(uint64_t v) {
 }
 
 // highbd_clip_pixel_add with the check_range clamp of the residual (inv_transforms.c:2490-2520); everything fits 32 bits
-// for bit depths up to 12
-__device__ __forceinline__ uint16_t clip_pixel_add(uint32_t dest, int32_t trans, int bd) {
-    const int32_t mx = (1 << (7 + bd)) - 1 + (914 << (bd - 7)), mn = -mx - 1;
-    const int32_t t  = trans > mx ? mx : (trans < mn ? mn : trans);
-    const int32_t v  = (int32_t)dest + t;
-    const int32_t hi = (1 << bd) - 1;
-    return (uint16_t)(v < 0 ? 0 : (v > hi ? hi : v));
-}
+// for bit depths up to 12.  Both clamps are one v_med3_i32 (the compiler only forms it for constant bounds).
+struct PixelClip {
+    int32_t mn, mx, hi;
+    __device__ __forceinline__ explicit PixelClip(int bd) : mx((1 << (7 + bd)) - 1 + (914 << (bd - 7))), hi((1 << bd) - 1) { mn = -mx - 1; }
+    __device__ __forceinline__ static int32_t med3(int32_t v, int32_t lo, int32_t up) {
+        int32_t r;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(up));
+        return r;
+    }
+    __device__ __forceinline__ uint16_t add(uint32_t dest, int32_t trans) const { return (uint16_t)med3((int32_t)dest + med3(trans, mn, mx), 0, hi); }
+};
 
 // Store the IW x IH coefficient tile held in LDS (row pitch PW) to a dense global array with all L lanes of the
 // transform block: consecutive lanes write consecutive 16-byte chunks, so every wave-level store covers whole cache
@@ -453,7 +456,7 @@ __device__ __forceinline__ void txfm_block(uint8_t *__restrict__ base, const Svt
         const int range_col = bd == 12 ? 18 : 16, col_clamp = bd + 6 > 16 ? bd + 6 : 16;
         const int cc = lr ? W - 1 - t : t;
 #pragma unroll
-        for (int r = 0; r < H; r++) v[r] = clampv<true>(lds[r * PW + cc], col_clamp);
+        for (int r = 0; r < H; r++) v[r] = r < IH ? clampv<true>(lds[r * PW + cc], col_clamp) : 0;  // rows >= IH of a 64-point column are zero: the network below folds
         if (__all(bdi >= 0 && INV_FAST_OK[bdi < 0 ? 0 : bdi][1][G::HI][kind_index(vk)] != 0)) {
             inv1d<Fast, H>(v, vk, range_col);
 #pragma unroll
@@ -481,14 +484,15 @@ __device__ __forceinline__ void txfm_block(uint8_t *__restrict__ base, const Svt
                 for (int r = 0; r < H; r += 2) predv[r / 2] = (uint32_t)pr[(ptrdiff_t)r * ps] | ((uint32_t)pr[(ptrdiff_t)(r + 1) * ps] << 16);
             }
         }
+        const PixelClip clip((d.flags & SVT_HIP_TX_PIXEL16) ? bd : 8);
         if (d.flags & SVT_HIP_TX_PIXEL16) {
             uint16_t *rc = (uint16_t *)(base + d.recon_off) + r0 * (ptrdiff_t)d.recon_stride + t;
 #pragma unroll
-            for (int r = 0; r < H; r++, rc += rs) __builtin_nontemporal_store(clip_pixel_add((uint16_t)(predv[r / 2] >> (16 * (r & 1))), v[r], bd), rc);
+            for (int r = 0; r < H; r++, rc += rs) __builtin_nontemporal_store(clip.add((uint16_t)(predv[r / 2] >> (16 * (r & 1))), v[r]), rc);
         } else {
             uint8_t *rc = base + d.recon_off + r0 * (ptrdiff_t)d.recon_stride + t;
 #pragma unroll
-            for (int r = 0; r < H; r++, rc += rs) *rc = (uint8_t)clip_pixel_add((uint16_t)(predv[r / 2] >> (16 * (r & 1))), v[r], 8);
+            for (int r = 0; r < H; r++, rc += rs) *rc = (uint8_t)clip.add((uint16_t)(predv[r / 2] >> (16 * (r & 1))), v[r]);
         }
     }
 }
