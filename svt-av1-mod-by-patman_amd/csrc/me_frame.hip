@@ -1399,7 +1399,9 @@ __global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFra
 #ifdef SVT_HIP_ME_ABLATE
 extern "C" __attribute__((visibility("default"))) int32_t svt_hip_debug_me_stop(int32_t k) {
     SVT_HIP_CHECK(hipDeviceSynchronize());
-    SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_me_stop), &k, sizeof(k)));
+    const int32_t stop = k & 0xff, skip = k >> 8;  // bits 8.. = what wg_multi_search leaves out (see g_ms_skip)
+    SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_me_stop), &stop, sizeof(stop)));
+    SVT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ms_skip), &skip, sizeof(skip)));
     return SVT_HIP_OK;
 }
 #endif

@@ -33,10 +33,11 @@ struct SearchDesc {
     uint32_t k;         // ref_stride / raw_stride
     uint32_t fast;      // LDS fast path usable
     uint32_t nq;        // quads per search row
+    uint32_t no;        // work items per search row: pairs of quads (8 adjacent positions), the last one may be half
     uint32_t n_srows;   // searched rows
     uint32_t pitch_dw;  // LDS row pitch of the staged window (dwords)
     uint32_t rows_per_pos;  // raw rows spanned by one search position: (bh-1)*k + 1
-    uint32_t inv_pitch, inv_nq;  // ceil(2^32 / x): exact quotients for the small dividends used here
+    uint32_t inv_pitch, inv_no;  // ceil(2^32 / x): exact quotients for the small dividends used here
     // --- caller's per-descriptor state that has to survive the search (kept here rather than in registers: live values
     // across the inlined search are what the register allocator spills) ---
     int16_t  aux_x, aux_y;
@@ -64,6 +65,9 @@ template <int NS> struct SearchSharedT {
 };
 using SearchShared = SearchSharedT<MAX_SEARCH>;
 
+#ifdef SVT_HIP_ME_ABLATE
+static __device__ int g_ms_skip;  // ABLATE=1 builds: bit 0 = no window staging loads, bit 1 = no SAD arithmetic (instruction accounting)
+#endif
 #ifdef SVT_HIP_ME_PROFILE
 static __device__ unsigned long long g_ms_prof[16];  // [call site][plan, stage, search, -] (per translation unit)
 #define MS_PHASE(i)                                                 \
@@ -215,15 +219,56 @@ __device__ __forceinline__ void quad_sad_fixed(const uint32_t *__restrict__ w, u
     out[0] = a0, out[1] = a1, out[2] = a2, out[3] = a3;
 }
 
+// Two horizontally adjacent quads (8 positions, window dword `w` onwards) in one walk over the block: the window dwords of a
+// row are read once for both (NF + 2 instead of 2 NF + 2), the 64-bit operand (d[j], d[j+1]) serves quad A against source
+// dword j and quad B against source dword j - 1, and the source row is read once.  out[0..3] = quad A, out[4..7] = quad B.
+template <uint32_t BW>
+__device__ __forceinline__ void oct_sad_fixed(const uint32_t *__restrict__ w, uint32_t w_row_dw, const uint32_t *__restrict__ s,
+                                              uint32_t s_row_dw, uint32_t bh, uint32_t out[8]) {
+    constexpr uint32_t NF = BW / 4, FLUSH = 64 / NF;
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t r0 = 0; r0 < bh; r0 += FLUSH) {
+        uint64_t       acc_a = 0, acc_b = 0;
+        const uint32_t r1    = r0 + FLUSH < bh ? r0 + FLUSH : bh;
+#pragma unroll 1
+        for (uint32_t r = r0; r < r1; r++) {
+            const uint32_t *wr = w + r * w_row_dw;
+            const uint32_t *sr = s + r * s_row_dw;
+            uint32_t        d[NF + 2];
+#pragma unroll
+            for (uint32_t i = 0; i <= NF + 1; i++) d[i] = wr[i];
+#pragma unroll
+            for (uint32_t i = 0; i < NF; i += 4) {
+                const uint4 sv = *(const uint4 *)&sr[i];
+                acc_a = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i], d[i + 1]), sv.x, acc_a);
+                acc_b = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 1], d[i + 2]), sv.x, acc_b);
+                acc_a = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 1], d[i + 2]), sv.y, acc_a);
+                acc_b = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 2], d[i + 3]), sv.y, acc_b);
+                acc_a = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 2], d[i + 3]), sv.z, acc_a);
+                acc_b = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 3], d[i + 4]), sv.z, acc_b);
+                acc_a = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 3], d[i + 4]), sv.w, acc_a);
+                acc_b = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d[i + 4], d[i + 5]), sv.w, acc_b);
+            }
+        }
+        a[0] += (uint32_t)(acc_a & 0xffff), a[1] += (uint32_t)((acc_a >> 16) & 0xffff);
+        a[2] += (uint32_t)((acc_a >> 32) & 0xffff), a[3] += (uint32_t)(acc_a >> 48);
+        a[4] += (uint32_t)(acc_b & 0xffff), a[5] += (uint32_t)((acc_b >> 16) & 0xffff);
+        a[6] += (uint32_t)((acc_b >> 32) & 0xffff), a[7] += (uint32_t)(acc_b >> 48);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = a[i];
+}
+
 __device__ __forceinline__ void search_plan_desc(SearchDesc &d, uint32_t bw, uint32_t bh, uint32_t win_cap_dw) {
     d.fast = 0;
     d.k    = 0;
     if (d.sa_w <= 0 || d.sa_h <= 0) {
-        d.n_srows = 0, d.nq = 0;
+        d.n_srows = 0, d.nq = 0, d.no = 0;
         return;
     }
     d.n_srows = d.skip ? (uint32_t)d.sa_h / 2u : (uint32_t)d.sa_h;
     d.nq      = ((uint32_t)d.sa_w + 3u) >> 2;
+    d.no      = (d.nq + 1u) >> 1;
     if (d.raw_stride != 0 && bw <= 256) {
         // the two strides the reference passes are either equal or 2:1 (sub-sampled SAD); anything else: slow path
         d.k = d.ref_stride == d.raw_stride ? 1u : (d.ref_stride == 2 * d.raw_stride ? 2u : (d.ref_stride % d.raw_stride == 0 ? d.ref_stride / d.raw_stride : 0u));
@@ -232,7 +277,7 @@ __device__ __forceinline__ void search_plan_desc(SearchDesc &d, uint32_t bw, uin
             d.pitch_dw     = (d.nq + ((bw + 3) >> 2) + 1) | 1u;  // odd pitch: rows land on different banks
             d.fast         = (uint64_t)d.pitch_dw * d.rows_per_pos <= win_cap_dw && win_cap_dw <= 65536u;
             d.inv_pitch    = make_inv(d.pitch_dw);
-            d.inv_nq       = make_inv(d.nq);
+            d.inv_no       = make_inv(d.no);
         }
     }
 }
@@ -297,7 +342,7 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
                         part   = true;
                     }
                     need  = (nstage * ds.pitch_dw + SEG_ALIGN - 1) & ~(SEG_ALIGN - 1);
-                    items = nj * ds.nq;
+                    items = nj * ds.no;
                 }
             }
             const bool split = __shfl((int)part, (int)(d0 & 63u), 64) != 0;
@@ -344,40 +389,58 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
                 const SearchSeg   sg = sh.seg[s];
                 const SearchDesc &ds = sh.desc[sg.d];
                 const uint32_t    rstride = ds.raw_stride;
+#ifdef SVT_HIP_ME_ABLATE
+                if (g_ms_skip & 1)
+                    continue;
+#endif
                 stage_rows16(win + sg.lds_dw, ds.pitch_dw, ds.ref + (size_t)(ds.skip ? 2 * sg.j0 + 1 : sg.j0) * rstride, rstride,
                              sg.nstage, lanes, lid);
             }
         }
         __syncthreads();
         MS_PHASE(1);
-        // search: one work item = four horizontally adjacent positions (a quad) of one searched row
+        // search: one work item = eight horizontally adjacent positions (two quads) of one searched row
         const uint32_t nitems = sh.nitems;
         for (uint32_t item = tid; item < nitems; item += blockDim.x) {
             const uint32_t   s  = find_seg<true, SH>(sh, nseg, item);
             const SearchSeg  sg = sh.seg[s];
             const SearchDesc &ds = sh.desc[sg.d];
             const uint32_t   li = item - sg.item_base;
-            const uint32_t   jl = fast_div(li, ds.inv_nq), q = li - jl * ds.nq;
+            const uint32_t   jl = fast_div(li, ds.inv_no), q = 2u * (li - jl * ds.no);  // q: first quad of the pair
             const uint32_t   step = ds.skip ? 2u : 1u;
             const uint32_t  *w    = win + sg.lds_dw + (jl * step) * ds.pitch_dw + q;
-            uint32_t         sad[4];
+            uint32_t         sad[8];
+            // a half pair (odd quad count) still walks both quads: the second reads at most one dword past its row (staged
+            // data or the next LDS object, never used: its positions fail the sa_w test below)
+#ifdef SVT_HIP_ME_ABLATE
+            if (g_ms_skip & 2) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) sad[i] = item + i;
+            } else
+#endif
 #ifndef SVT_HIP_NO_QSAD
             if (src_aligned && bw == 16)
-                quad_sad_fixed<16>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+                oct_sad_fixed<16>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
             else if (src_aligned && bw == 32)
-                quad_sad_fixed<32>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+                oct_sad_fixed<32>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
             else if (src_aligned && bw == 64)
-                quad_sad_fixed<64>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+                oct_sad_fixed<64>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
             else
 #endif
+            {
                 quad_sad(w, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad);
+                if (q + 1 < ds.nq)
+                    quad_sad(w + 1, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad + 4);
+                else
+                    sad[4] = sad[5] = sad[6] = sad[7] = ~0u;
+            }
             const uint32_t sy = ds.skip ? 2 * (sg.j0 + jl) + 1 : (sg.j0 + jl);
             const uint32_t saw = (uint32_t)ds.sa_w;
-            // the four positions of a quad are in raster order: a strict '<' on the SAD keeps the first minimum, and the
+            // the eight positions are in raster order: a strict '<' on the SAD keeps the first minimum, and the
             // 64-bit (sad, raster index) key is built once
             uint32_t best = ~0u, bpos = 0;
 #pragma unroll
-            for (uint32_t p = 0; p < 4; p++)
+            for (uint32_t p = 0; p < 8; p++)
                 if (4 * q + p < saw && sad[p] < best)
                     best = sad[p], bpos = p;
             if (best != ~0u)
