@@ -66,7 +66,7 @@ template <int NS> struct SearchSharedT {
 using SearchShared = SearchSharedT<MAX_SEARCH>;
 
 #ifdef SVT_HIP_ME_ABLATE
-static __device__ int g_ms_skip;  // ABLATE=1 builds: bit 0 = no window staging loads, bit 1 = no SAD arithmetic (instruction accounting)
+static __device__ int g_ms_skip;  // ABLATE=1 builds: bit 0 = no window staging loads, bit 1 = no SAD arithmetic, bit 2 = no work items (instruction accounting)
 #endif
 #ifdef SVT_HIP_ME_PROFILE
 static __device__ unsigned long long g_ms_prof[16];  // [call site][plan, stage, search, -] (per translation unit)
@@ -140,7 +140,8 @@ __device__ __forceinline__ void stage_rows16(uint32_t *__restrict__ w0, uint32_t
 
 // n / d for n * d < 2^32 with inv = ceil(2^32 / d) (d >= 2; d == 1 is handled by the caller passing inv = 0)
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
-__device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? (uint32_t)((0x100000000ull + d - 1) / d) : 0u; }
+// ceil(2^32 / d) == floor((2^32 - 1) / d) + 1 for every d >= 1: a 32-bit division (a 64-bit one is ~100 instructions here)
+__device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
 
 // SAD of 4 adjacent positions (window dword `w` onwards) against one block.  src rows are dwords in LDS.
 __device__ __forceinline__ void quad_sad(const uint32_t *__restrict__ w, uint32_t w_row_dw,
@@ -400,7 +401,11 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
         __syncthreads();
         MS_PHASE(1);
         // search: one work item = eight horizontally adjacent positions (two quads) of one searched row
+#ifdef SVT_HIP_ME_ABLATE
+        const uint32_t nitems = (g_ms_skip & 4) ? 0u : sh.nitems;  // bit 2: no work items at all
+#else
         const uint32_t nitems = sh.nitems;
+#endif
         for (uint32_t item = tid; item < nitems; item += blockDim.x) {
             const uint32_t   s  = find_seg<true, SH>(sh, nseg, item);
             const SearchSeg  sg = sh.seg[s];

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "svt-av1-mod-by-patman_amd"))
 STOPS = [1, 2, 3, 4, 99]
-MASKS = [0, 1, 2, 3]
+MASKS = [0, 1, 2, 3, 7]
 
 
 def main():

@@ -18,7 +18,7 @@ for f in glob.glob("/tmp/abl_skip/**/*counter_collection.csv", recursive=True):
         if "me_b64_kernel" in r["Kernel_Name"]:
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
-keys = [f"stop{s}_mask{m}" for s in (1, 2, 3, 4, 99) for m in (0, 1, 2, 3)]
+keys = [f"stop{s}_mask{m}" for s in (1, 2, 3, 4, 99) for m in (0, 1, 2, 3, 7)]
 per = len(ids) // len(keys)
 out = {}
 for k, n in enumerate(keys):
