@@ -4,22 +4,24 @@
  * Reference interface replaced (paths relative to /root/reference):
  *   Source/Lib/Codec/src_ops_process.c:519-1207   tpl_mc_flow_dispenser_sb_generic, called per 64x64 block from
  *                                                 tpl_mc_flow_dispenser (:1348-1410) / svt_aom_tpl_disp_kernel (:1964)
- * for the configuration the reference runs at presets M7 ... M9 (and M10 with VBR: tpl level 4 of set_tpl_params, initial_rc_process.c:284-296, 359-370;
- * and level 3 without its sub-pel refinement): 16x16 blocks (dispenser_search_level 0), DC intra prediction only
- * (intra_mode_end == DC_PRED), SAD in the source-based search, full-pel vectors straight from the open-loop ME results,
- * no transform sub-sampling, no rate estimate (compute_rate 0), any coefficient shape (pf_shape).  Per block:
+ * for the configurations the reference runs at presets M7 and faster (tpl levels 4 and 5 of set_tpl_params,
+ * initial_rc_process.c:284-296, 359-382; and level 3 without its sub-pel refinement): 16x16 blocks (dispenser_search_level 0)
+ * or 32x32 blocks whose transform runs on every 4th row (level 5: dispenser_search_level 1, subsample_tx 2, TX_32X8), DC intra
+ * prediction only (intra_mode_end == DC_PRED), SAD in the source-based search, full-pel vectors straight from the open-loop
+ * ME results, no rate estimate (compute_rate 0), any coefficient shape (pf_shape).  Per block:
  *   source-based path  DC prediction from the SOURCE neighbours and its sub-sampled SAD; every single-reference ME candidate,
  *                      vector clipped to the TPL padding, sub-sampled SAD against the reference's source picture; for an
- *                      inter winner residual -> DCT 16x16 -> svt_av1_quantize_fp -> svt_av1_block_error  (srcrf_dist)
+ *                      inter winner residual -> DCT 16x16 (32x8) -> svt_av1_quantize_fp -> svt_av1_block_error  (srcrf_dist)
  *   reconstruction     inter: the block of the reference's RECONSTRUCTION at that vector; intra: DC prediction from the
  *                      reconstructed neighbours of this picture; residual -> DCT -> quantise -> error (recrf_dist) ->
- *                      inverse transform + reconstruction into the TPL reconstruction picture
- *   result_model_store TplStats on the 16x16 (or 8x8) grid, TplSrcStats
+ *                      inverse transform + reconstruction into the TPL reconstruction picture (sub-sampled: the rows left out
+ *                      repeat the row above them)
+ *   result_model_store TplStats on the synthesizer's 32x32 / 16x16 / 8x8 grid (cells beyond the grid are dropped), TplSrcStats
  * The intra blocks depend on the reconstruction of their left / top / top-left neighbours: the kernel runs the source-based
  * path of every block in parallel and orders only the reconstruction of intra blocks behind their neighbours' (flags in
  * device memory; block indices are handed out by a ticket counter, so no dispatch order is assumed).  The caller orders pictures (a reference picture's reconstruction must be complete before this call).
  * Not provided: the other intra modes and the SATD source search (tpl levels 1, 2), sub-pel refinement (levels 1-3),
- * 32x32 / 64x64 dispenser blocks with transform sub-sampling (level 5), the rate estimate.
+ * 64x64 dispenser blocks, subsample_tx 1, the rate estimate.
  */
 #ifndef SVT_HIP_TPL_H
 #define SVT_HIP_TPL_H
@@ -75,12 +77,14 @@ typedef struct SvtHipTplFrameJob {
     uint8_t  tpl_i_slice;        /* pcs->tpl_data.tpl_slice_type == I_SLICE */
     uint8_t  src_data_ready;     /* pcs->tpl_src_data_ready: the source-based results are READ from src_stats */
     uint8_t  store_src_stats;    /* scs->tpl_lad_mg > 0 */
-    uint8_t  synth_blk_size;     /* 16 or 8 (tpl_ctrls.synth_blk_size): grid of `stats` */
-    uint8_t  pad_[3];
+    uint8_t  synth_blk_size;     /* 16 or 8 (tpl_ctrls.synth_blk_size; 32 too with 32x32 blocks): grid of `stats` */
+    uint8_t  blk_size;           /* 0 / 16: 16x16 blocks (dispenser_search_level 0); 32: 32x32 blocks (level 1) */
+    uint8_t  subsample_tx;       /* tpl_ctrls.subsample_tx: 0 with 16x16 blocks; 0 or 2 (transform TX_32X8 on every 4th row) with 32x32 */
+    uint8_t  pad_;
     /* quants_8bit / deq_8bit of the picture's qindex: [0] DC, [1] AC */
     int16_t  round_fp[2], quant_fp[2], dequant[2];
     uint16_t pad2_;
-    SvtHipTplStats    *stats;     /* [(aligned_h / blk)][stride]: stride = (aligned_width + 15) / 16 for 16, twice that for 8 */
+    SvtHipTplStats    *stats;     /* [rows][stride]: stride = (aligned_width + 15) / 16 for synth_blk_size 16, twice that for 8, (aligned_width + 31) / 32 for 32 */
     SvtHipTplSrcStats *src_stats; /* [..][(aligned_width + 15) >> 4] */
     void              *workspace; /* device scratch of svt_hip_tpl_workspace_bytes(): the done-flags of the blocks, one status word
                                    * (first uint32 behind the flags: non-zero if a dependency wait ran into its bound — the

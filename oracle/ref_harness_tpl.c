@@ -77,7 +77,7 @@ __attribute__((visibility("default"))) int ref_tpl_dispenser_frame(const SvtHipT
     pcs->temporal_layer_index = 3, pcs->hierarchical_levels = 3;
     TplControls *c = &pcs->tpl_ctrls;
     c->enable = 1, c->compute_rate = 0, c->disable_intra_pred_nref = job->disable_intra_pred, c->intra_mode_end = DC_PRED;
-    c->pf_shape = (EB_TRANS_COEFF_SHAPE)job->pf_shape, c->use_sad_in_src_search = 1, c->dispenser_search_level = 0, c->subsample_tx = 0;
+    c->pf_shape = (EB_TRANS_COEFF_SHAPE)job->pf_shape, c->use_sad_in_src_search = 1, c->dispenser_search_level = job->blk_size == 32 ? 1 : 0, c->subsample_tx = job->subsample_tx;
     c->synth_blk_size = job->synth_blk_size, c->subpel_depth = FULL_PEL;
     pcs->tpl_data.base_pcs = base, pcs->tpl_data.is_ref = job->is_ref;
     pcs->tpl_data.tpl_slice_type = job->tpl_i_slice ? I_SLICE : B_SLICE;
@@ -114,20 +114,26 @@ __attribute__((visibility("default"))) int ref_tpl_dispenser_frame(const SvtHipT
         res[i].me_candidate_array       = (MeCandidate *)(job->me_candidate_array + (size_t)i * job->stored_pus * job->max_cand);
         res[i].total_me_candidate_index = (uint8_t *)job->total_me_candidate_index + (size_t)i * job->stored_pus;
     }
-    const uint32_t a16 = (aw + 15) >> 4, grid = job->synth_blk_size == 16 ? 1 : 2, rows16 = (ah + 15) >> 4;
-    const size_t   n_stats = (size_t)a16 * grid * rows16 * grid;
+    const uint32_t a16 = (aw + 15) >> 4, rows16 = (ah + 15) >> 4;
+    const uint32_t gstride = job->synth_blk_size == 32 ? (aw + 31) / 32 : (job->synth_blk_size == 16 ? a16 : a16 << 1);
+    const uint32_t grows   = job->synth_blk_size == 32 ? (ah + 31) / 32 : (job->synth_blk_size == 16 ? rows16 : rows16 << 1);
+    const size_t   n_stats = (size_t)gstride * grows;
+    /* a 32x32 block half outside the picture stores cells past the last row of the grid (result_model_store has no bound):
+     * room behind the array for them; they are not part of the result */
+    const size_t   n_alloc = n_stats + (size_t)gstride * 4 + 8;
     TplSrcStats   *ss = calloc((size_t)a16 * rows16, sizeof(*ss));
-    TplStats      *ts = calloc(n_stats, sizeof(*ts));
+    TplStats      *ts = calloc(n_alloc, sizeof(*ts));
     med->tpl_src_stats_buffer = ss;
-    med->tpl_stats            = calloc(n_stats, sizeof(TplStats *));
-    for (size_t i = 0; i < n_stats; i++) med->tpl_stats[i] = &ts[i];
+    med->tpl_stats            = calloc(n_alloc, sizeof(TplStats *));
+    for (size_t i = 0; i < n_alloc; i++) med->tpl_stats[i] = &ts[i];
     for (size_t i = 0; i < (size_t)a16 * rows16; i++) { /* in: previously computed source-based data (src_data_ready) */
         const SvtHipTplSrcStats *q = &job->src_stats[i];
         ss[i].srcrf_dist = q->srcrf_dist, ss[i].srcrf_rate = q->srcrf_rate, ss[i].ref_frame_poc = q->ref_frame_poc;
         ss[i].mv.row = q->mv_row, ss[i].mv.col = q->mv_col, ss[i].best_mode = q->best_mode, ss[i].best_rf_idx = q->best_rf_idx;
         ss[i].best_intra_mode = q->best_intra_mode;
     }
-    for (uint32_t i = 0; i < nb; i++) tpl_mc_flow_dispenser_sb_generic(enc, scs, pcs, 0, i, qindex, 0);
+    for (uint32_t i = 0; i < nb; i++) /* as svt_aom_tpl_disp_kernel calls it (:2043-2051): an incomplete 64x64 block is always dispensed at level 0 */
+        tpl_mc_flow_dispenser_sb_generic(enc, scs, pcs, 0, i, qindex, (geom[i].width == 64 && geom[i].height == 64 && job->blk_size == 32) ? 1 : 0);
     for (size_t i = 0; i < (size_t)a16 * rows16; i++) {
         SvtHipTplSrcStats *q = &job->src_stats[i];
         memset(q, 0, sizeof(*q));

@@ -1,7 +1,8 @@
 /*
  * oracle/src/orc_tpl.c — TEST INFRASTRUCTURE, not product code.
  * CPU restatement of the TPL dispenser of one picture for the configuration of include/svt_hip_tpl.h
- * (16x16 blocks, DC intra prediction, SAD source search, full-pel vectors, no transform sub-sampling, no rate estimate):
+ * (16x16 blocks, or 32x32 blocks with the transform on every 4th row = tpl level 5; DC intra prediction, SAD source search,
+ * full-pel vectors, no rate estimate):
  *   tpl_mc_flow_dispenser_sb_generic                                   src_ops_process.c:519-1207
  *   get_neighbor_samples_dc                                            :360-373
  *   svt_aom_update_neighbor_samples_array_open_loop_mb / _mb_recon     enc_intra_prediction.c:1127-1300
@@ -10,7 +11,7 @@
  * built on the pinned pieces orc_nxm_sad, orc_fwd_txfm2d, orc_quantize_fp, orc_inv_txfm2d_add_8bit.
  * Pinned against the REAL function through oracle/ref_harness_tpl.c (tests/test_tpl_oracle.py) and tests/golden/tpl_frame.npz.
  * Every pointer inside the job is a HOST pointer here; `workspace` is not used.  Blocks run in the reference's order (64x64 blocks
- * in raster order, 16x16 blocks in z-order inside).
+ * in raster order, 16x16 / 32x32 blocks in z-order inside).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -62,52 +63,52 @@ static void neighbours(uint8_t *above_ref, uint8_t *left_ref, const uint8_t *pic
     }
 }
 
-/* svt_aom_dc_pred[x > 0][y > 0][TX_16X16] */
-static uint8_t dc_value(const uint8_t *above, const uint8_t *left, uint32_t x, uint32_t y) {
+/* svt_aom_dc_pred[x > 0][y > 0][TX_16X16 / TX_32X32] */
+static uint8_t dc_value(const uint8_t *above, const uint8_t *left, uint32_t x, uint32_t y, int bs) {
     int32_t sa = 0, sl = 0;
-    for (int i = 0; i < 16; i++) sa += above[i], sl += left[i];
+    for (int i = 0; i < bs; i++) sa += above[i], sl += left[i];
     if (x > 0 && y > 0)
-        return (uint8_t)((sa + sl + 16) / 32);
+        return (uint8_t)((sa + sl + bs) / (2 * bs));
     if (x > 0)
-        return (uint8_t)((sl + 8) / 16);
+        return (uint8_t)((sl + bs / 2) / bs);
     if (y > 0)
-        return (uint8_t)((sa + 8) / 16);
+        return (uint8_t)((sa + bs / 2) / bs);
     return 128;
 }
 
-static void dc_predict(const uint8_t *pic0, uint32_t stride, uint32_t x, uint32_t y, uint32_t width, uint32_t height, uint8_t *dst, uint32_t dst_stride) {
-    uint8_t above_data[8 + 64 + 8], left_data[8 + 64 + 8];
+static void dc_predict(const uint8_t *pic0, uint32_t stride, uint32_t x, uint32_t y, uint32_t width, uint32_t height, uint8_t *dst, uint32_t dst_stride,
+                       uint32_t bs) {
+    uint8_t above_data[8 + 128 + 8], left_data[8 + 128 + 8];
     uint8_t *above = above_data + 8, *left = left_data + 8;
-    const int inside = x + 16 <= width && y + 16 <= height;
+    const int inside = x + bs <= width && y + bs <= height;
     if (x > 0 && y > 0 && inside) { /* get_neighbor_samples_dc */
         const uint8_t *src = pic0 + (size_t)y * stride + x;
-        memcpy(above, src - stride, 16);
-        for (int i = 0; i < 16; i++) left[i] = src[(ptrdiff_t)i * stride - 1];
+        memcpy(above, src - stride, bs);
+        for (uint32_t i = 0; i < bs; i++) left[i] = src[(ptrdiff_t)i * stride - 1];
     } else {
-        neighbours(above - 1, left - 1, pic0, stride, x, y, 16, 16, width, height);
+        neighbours(above - 1, left - 1, pic0, stride, x, y, bs, bs, width, height);
     }
-    const uint8_t v = dc_value(above, left, x, y);
-    for (int r = 0; r < 16; r++) memset(dst + (size_t)r * dst_stride, v, 16);
+    const uint8_t v = dc_value(above, left, x, y, (int)bs);
+    for (uint32_t r = 0; r < bs; r++) memset(dst + (size_t)r * dst_stride, v, bs);
 }
 
-/* subtract -> svt_av1_wht_fwd_txfm (DCT_DCT 16x16, pf_shape) -> get_quantize_error; dqcoeff out */
+/* subtract -> svt_av1_wht_fwd_txfm (DCT_DCT bs x (bs >> sub) on every (1 << sub)-th row, pf_shape) -> get_quantize_error; dqcoeff out */
 static int64_t quantize_error(const SvtHipTplFrameJob *job, const uint8_t *src, uint32_t src_stride, const uint8_t *pred, uint32_t pred_stride,
-                              int32_t *dqcoeff, uint16_t *eob) {
-    static const int16_t identity_scan[256] = {0};
-    int16_t diff[256], scan[256];
-    int32_t coeff[256], qcoeff[256];
-    (void)identity_scan;
-    for (int i = 0; i < 256; i++) scan[i] = (int16_t)i; /* the scan only orders the end-of-block position, which nothing here depends on */
-    orc_subtract_block(16, 16, diff, 16, src, src_stride, pred, pred_stride);
+                              int32_t *dqcoeff, uint16_t *eob, int bs, int sub) {
+    int16_t   diff[1024], scan[1024];
+    int32_t   coeff[1024], qcoeff[1024];
+    const int th = bs >> sub, n = bs * th;
+    for (int i = 0; i < n; i++) scan[i] = (int16_t)i; /* the scan only orders the end-of-block position, of which only "non-zero" is used */
+    orc_subtract_block(th, bs, diff, bs, src, (ptrdiff_t)src_stride << sub, pred, (ptrdiff_t)pred_stride << sub);
     memset(coeff, 0, sizeof(coeff));
-    orc_fwd_txfm2d(diff, coeff, 16, 16, 16, 0, 8, job->pf_shape);
-    orc_quantize_fp(coeff, 256, job->round_fp, job->quant_fp, qcoeff, dqcoeff, job->dequant, eob, scan, NULL, NULL, 0);
+    orc_fwd_txfm2d(diff, coeff, (uint32_t)bs, bs, th, 0, 8, job->pf_shape);
+    orc_quantize_fp(coeff, n, job->round_fp, job->quant_fp, qcoeff, dqcoeff, job->dequant, eob, scan, NULL, NULL, 0);
     int64_t err = 0;
-    for (int i = 0; i < 256; i++) {
+    for (int i = 0; i < n; i++) {
         const int64_t d = (int64_t)coeff[i] - dqcoeff[i];
         err += d * d;
     }
-    err >>= 2;
+    err >>= (bs == 32 && th == 32) ? 0 : 2; /* shift = tx_size == TX_32X32 ? 0 : 2 (:229) */
     return err > 1 ? err : 1;
 }
 
@@ -115,17 +116,26 @@ static inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 
 ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
     const uint32_t W = job->src.width, H = job->src.height, aw = (W + 7) & ~7u, ah = (H + 7) & ~7u;
-    const uint32_t bw64 = (aw + 63) / 64, bh64 = (ah + 63) / 64, a16 = (aw + 15) >> 4;
+    const uint32_t bw64 = (aw + 63) / 64, bh64 = (ah + 63) / 64, a16 = (aw + 15) >> 4, rows16 = (ah + 15) >> 4;
     const uint8_t *src0 = job->src.buf + (size_t)job->src.org_y * job->src.stride + job->src.org_x;
     uint8_t       *rec0 = job->recon.buf + (size_t)job->recon.org_y * job->recon.stride + job->recon.org_x;
     const uint32_t ss = job->src.stride, rs = job->recon.stride;
-    if (job->synth_blk_size != 16 && job->synth_blk_size != 8)
+    const int      sub = job->subsample_tx;
+    if (job->synth_blk_size != 16 && job->synth_blk_size != 8 && !(job->synth_blk_size == 32 && job->blk_size == 32))
         return -1;
-    for (uint32_t sb = 0; sb < bw64 * bh64; sb++)
-        for (uint32_t z = 0; z < 16; z++) {
-            const uint32_t bx = (z & 1) | ((z >> 2) & 1) << 1, by = ((z >> 1) & 1) | ((z >> 3) & 1) << 1; /* z-order inside the b64 */
-            const uint32_t x = (sb % bw64) * 64 + bx * 16, y = (sb / bw64) * 64 + by * 16;
-            if (x + 8 > W || y + 8 > H) /* at least half of the block inside */
+    if ((job->blk_size != 0 && job->blk_size != 16 && job->blk_size != 32) || (sub != 0 && sub != 2) || (job->blk_size != 32 && sub != 0))
+        return -1;
+    for (uint32_t sb = 0; sb < bw64 * bh64; sb++) {
+        /* the caller dispenses an incomplete 64x64 block (right / bottom picture edge) with 16x16 blocks whatever the level
+         * (svt_aom_tpl_disp_kernel, :2043-2051); the transform sub-sampling stays: TX_16X4 there */
+        const int      full = aw - (sb % bw64) * 64 >= 64 && ah - (sb / bw64) * 64 >= 64;
+        const uint32_t bs = (job->blk_size == 32 && full) ? 32 : 16; /* size_array[dispenser_search_level] */
+        const uint32_t nz = bs == 32 ? 4 : 16;
+        for (uint32_t z = 0; z < nz; z++) {
+            /* z-order inside the b64 (tpl_blk_idx_tab[0][blk_start .. blk_end]) */
+            const uint32_t bx = bs == 32 ? (z & 1) : ((z & 1) | ((z >> 2) & 1) << 1), by = bs == 32 ? (z >> 1) : (((z >> 1) & 1) | ((z >> 3) & 1) << 1);
+            const uint32_t x = (sb % bw64) * 64 + bx * bs, y = (sb / bw64) * 64 + by * bs;
+            if (x + (bs >> 1) > W || y + (bs >> 1) > H) /* at least half of the block inside */
                 continue;
             const uint8_t *src = src0 + (size_t)y * ss + x;
             uint8_t       *dst = rec0 + (size_t)y * rs + x;
@@ -137,16 +147,16 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
             int32_t  best_rf_idx = -1;
             int16_t  mv_row = 0, mv_col = 0;
             uint8_t  best_mode = 0;
-            uint8_t  pred[256];
-            int32_t  dq[256];
+            uint8_t  pred[1024];
+            int32_t  dq[1024];
             uint16_t eob;
             if (!job->src_data_ready) {
                 int64_t best_inter = INT64_MAX, best_intra = INT64_MAX;
                 if (!job->disable_intra_pred) {
-                    dc_predict(src0, ss, x, y, W, H, pred, 16);
-                    best_intra = orc_nxm_sad(src, ss, pred, 16, 16, 16);
+                    dc_predict(src0, ss, x, y, W, H, pred, bs, bs);
+                    best_intra = orc_nxm_sad(src, ss, pred, bs, bs, bs);
                 }
-                uint32_t me_off = 5 + by * 4 + bx; /* tpl_blk_idx_tab[1] */
+                uint32_t me_off = bs == 32 ? 1 + by * 2 + bx : 5 + by * 4 + bx; /* tpl_blk_idx_tab[1] */
                 if (!job->enable_me_16x16)
                     me_off = (me_off - 1) / 4;
                 const size_t   pu = (size_t)sb * job->stored_pus + me_off;
@@ -164,14 +174,14 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
                     int16_t mx = (int16_t)((int16_t)(mv & 0xffff) << 3), my = (int16_t)((int16_t)(mv >> 16) << 3);
                     if ((int)x + (mx >> 3) < -TPL_PAD)
                         mx = (int16_t)((-TPL_PAD - (int)x) << 3);
-                    if ((int)x + 16 + (mx >> 3) > TPL_PAD + (int)rf->max_width - 1)
-                        mx = (int16_t)(((TPL_PAD + (int)rf->max_width - 1) - ((int)x + 16)) << 3);
+                    if ((int)x + (int)bs + (mx >> 3) > TPL_PAD + (int)rf->max_width - 1)
+                        mx = (int16_t)(((TPL_PAD + (int)rf->max_width - 1) - ((int)x + (int)bs)) << 3);
                     if ((int)y + (my >> 3) < -TPL_PAD)
                         my = (int16_t)((-TPL_PAD - (int)y) << 3);
-                    if ((int)y + 16 + (my >> 3) > TPL_PAD + (int)rf->max_height - 1)
-                        my = (int16_t)(((TPL_PAD + (int)rf->max_height - 1) - ((int)y + 16)) << 3);
+                    if ((int)y + (int)bs + (my >> 3) > TPL_PAD + (int)rf->max_height - 1)
+                        my = (int16_t)(((TPL_PAD + (int)rf->max_height - 1) - ((int)y + (int)bs)) << 3);
                     const uint8_t *rp = rf->src + ((ptrdiff_t)y + my / 8) * (ptrdiff_t)rf->src_stride + (ptrdiff_t)x + mx / 8;
-                    const int64_t  cost = orc_nxm_sad(src, ss, rp, rf->src_stride, 16, 16);
+                    const int64_t  cost = orc_nxm_sad(src, ss, rp, rf->src_stride, bs, bs);
                     if (cost < best_inter)
                         best_inter = cost, best_ref_poc = rf->picture_number, best_rf_idx = (int32_t)(dir * 4 + ri), mv_row = my, mv_col = mx;
                 }
@@ -180,8 +190,8 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
                 if (best_mode == NEWMV_MODE) {
                     const SvtHipTplRef *rf = &job->ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
                     const uint8_t      *rp = rf->src + ((ptrdiff_t)y + (mv_row >> 3)) * (ptrdiff_t)rf->src_stride + (ptrdiff_t)x + (mv_col >> 3);
-                    recon_error = quantize_error(job, src, ss, rp, rf->src_stride, dq, &eob);
-                    st.srcrf_rate = 0, st.srcrf_dist = recon_error << 4;
+                    recon_error = quantize_error(job, src, ss, rp, rf->src_stride, dq, &eob, (int)bs, sub);
+                    st.srcrf_rate = 0, st.srcrf_dist = (recon_error << 4) << sub;
                 }
                 if (job->store_src_stats) {
                     memset(sst, 0, sizeof(*sst));
@@ -196,33 +206,44 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
             if (best_mode == NEWMV_MODE) {
                 const SvtHipTplRef *rf = &job->ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
                 const uint8_t      *rp = rf->recon + ((ptrdiff_t)y + (mv_row >> 3)) * (ptrdiff_t)rf->recon_stride + (ptrdiff_t)x + (mv_col >> 3);
-                for (int r = 0; r < 16; r++) memcpy(dst + (size_t)r * rs, rp + (ptrdiff_t)r * rf->recon_stride, 16);
+                for (uint32_t r = 0; r < bs; r++) memcpy(dst + (size_t)r * rs, rp + (ptrdiff_t)r * rf->recon_stride, bs);
             } else {
-                dc_predict(rec0, rs, x, y, W, H, dst, rs);
+                dc_predict(rec0, rs, x, y, W, H, dst, rs, bs);
             }
-            recon_error = quantize_error(job, src, ss, dst, rs, dq, &eob);
+            recon_error = quantize_error(job, src, ss, dst, rs, dq, &eob, (int)bs, sub);
             if (!job->disable_intra_pred || job->is_ref)
-                if (eob)
-                    orc_inv_txfm2d_add_8bit(dq, dst, (int32_t)rs, dst, (int32_t)rs, 16, 16, 0);
-            st.recrf_dist = recon_error << 4, st.recrf_rate = 0;
+                if (eob) {
+                    orc_inv_txfm2d_add_8bit(dq, dst, (int32_t)(rs << sub), dst, (int32_t)(rs << sub), (int)bs, (int)(bs >> sub), 0);
+                    /* the rows the sub-sampled transform left out repeat the row above them (:1162-1180) */
+                    for (uint32_t i = 0; sub && i < bs; i += 1u << sub)
+                        for (uint32_t k = 1; k < (1u << sub); k++) memcpy(dst + (size_t)(i + k) * rs, dst + (size_t)i * rs, bs);
+                }
+            st.recrf_dist = (recon_error << 4) << sub, st.recrf_rate = 0;
             if (best_mode != NEWMV_MODE)
-                st.srcrf_dist = recon_error << 4, st.srcrf_rate = 0;
+                st.srcrf_dist = (recon_error << 4) << sub, st.srcrf_rate = 0;
             st.recrf_dist = max64(st.srcrf_dist, st.recrf_dist), st.recrf_rate = max64(st.srcrf_rate, st.recrf_rate);
             if (!job->tpl_i_slice && best_rf_idx != -1)
                 st.mv_row = mv_row, st.mv_col = mv_col, st.ref_frame_poc = best_ref_poc;
-            /* result_model_store */
+            /* result_model_store: the block's statistics on the synthesizer's grid, normalised to the grid's cell size; cells
+             * beyond the grid (a 32x32 block half outside the picture) are dropped — the reference writes them past the row end */
             st.srcrf_dist = max64(1, st.srcrf_dist), st.recrf_dist = max64(1, st.recrf_dist);
             st.srcrf_rate = max64(1, st.srcrf_rate), st.recrf_rate = max64(1, st.recrf_rate);
-            if (job->synth_blk_size == 16) {
-                job->stats[(size_t)(y >> 4) * a16 + (x >> 4)] = st;
-            } else {
-                const uint32_t stride = a16 << 1;
-                st.srcrf_dist = max64(1, st.srcrf_dist / 4), st.recrf_dist = max64(1, st.recrf_dist / 4);
-                st.srcrf_rate = max64(1, st.srcrf_rate / 4), st.recrf_rate = max64(1, st.recrf_rate / 4);
-                SvtHipTplStats *d = &job->stats[(size_t)(y >> 3) * stride + (x >> 3)];
-                d[0] = d[1] = d[stride] = d[stride + 1] = st;
+            const uint32_t cell = job->synth_blk_size, per = bs / cell; /* cells per block side: 1, 2 or 4; 0: a 16x16 block on the 32x32 grid overwrites its cell */
+            const uint32_t gstride = cell == 32 ? (aw + 31) / 32 : (cell == 16 ? a16 : a16 << 1);
+            const uint32_t grows = cell == 32 ? (ah + 31) / 32 : (cell == 16 ? rows16 : rows16 << 1);
+            if (per > 1) {
+                const int64_t div = (int64_t)per * per;
+                st.srcrf_dist = max64(1, st.srcrf_dist / div), st.recrf_dist = max64(1, st.recrf_dist / div);
+                st.srcrf_rate = max64(1, st.srcrf_rate / div), st.recrf_rate = max64(1, st.recrf_rate / div);
             }
+            for (uint32_t cy = 0; cy < (per ? per : 1); cy++)
+                for (uint32_t cx = 0; cx < (per ? per : 1); cx++) {
+                    const uint32_t gx = x / cell + cx, gy = y / cell + cy;
+                    if (gx < gstride && gy < grows)
+                        job->stats[(size_t)gy * gstride + gx] = st;
+                }
         }
+    }
     return 0;
 }
 

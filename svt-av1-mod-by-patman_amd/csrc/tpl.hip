@@ -1,8 +1,9 @@
 // tpl.hip — the TPL dispenser of one picture on gfx950: tpl_mc_flow_dispenser_sb_generic
-// (src_ops_process.c:519-1207) for the 16x16 / DC / SAD / full-pel configuration described in include/svt_hip_tpl.h.
+// (src_ops_process.c:519-1207) for the DC / SAD / full-pel configurations described in include/svt_hip_tpl.h: 16x16 blocks, or 32x32
+// blocks whose transform is TX_32X8 on every 4th row (tpl level 5).
 //
-// One wavefront per 16x16 block, all blocks of the picture in ONE launch:
-//   source-based path (no dependencies): the block's 256 source samples stay in registers (one dword per lane); DC prediction
+// One wavefront per block, all blocks of the picture in ONE launch:
+//   source-based path (no dependencies): the block's source samples stay in registers (one or four dwords per lane); DC prediction
 //     from the source neighbours, `v_sad_u8` against it and against every single-reference ME candidate; the inter winner's
 //     residual goes through the fused transform block of txfm_block.hpp (DCT 16x16 with the pf_shape zero-out, quantize_fp)
 //     and svt_av1_block_error is summed from the coefficient arrays it wrote;
@@ -56,11 +57,12 @@ __device__ __forceinline__ int64_t wave_sum64(int64_t v) {
     return v;
 }
 
-// svt_aom_update_neighbor_samples_array_open_loop_mb[_recon] (enc_intra_prediction.c:1127-1300) for a 16x16 block with
+// svt_aom_update_neighbor_samples_array_open_loop_mb[_recon] (enc_intra_prediction.c:1127-1300) for a BS x BS block with
 // use_top_right_bottom_left = update_top_neighbor = 1; above_ref / left_ref point at the [-1] entries.  One lane.
+template <uint32_t BS>
 __device__ void neighbours(uint8_t *above_ref, uint8_t *left_ref, const uint8_t *pic0, uint32_t stride, uint32_t x, uint32_t y, uint32_t width,
                            uint32_t height) {
-    const uint32_t bw = 16, bh = 16, n = 32;
+    const uint32_t bw = BS, bh = BS, n = 2 * BS;
     const uint8_t *src = pic0 + (size_t)y * stride + x;
     for (uint32_t i = 0; i <= n; i++) above_ref[i] = 127, left_ref[i] = 129;
     uint8_t *a = above_ref, *l = left_ref;
@@ -98,46 +100,52 @@ __device__ void neighbours(uint8_t *above_ref, uint8_t *left_ref, const uint8_t 
     }
 }
 
-// DC_PRED value of the block at (x, y) of plane pic0 (svt_aom_dc_pred[x > 0][y > 0][TX_16X16]); uniform over the wave
+// DC_PRED value of the block at (x, y) of plane pic0 (svt_aom_dc_pred[x > 0][y > 0][TX_16X16 / TX_32X32]); uniform over the wave
+constexpr int NB_LEFT = 8 + 88;  // offsets of the neighbour arrays in their LDS buffer: above[-1 .. 64], left[-1 .. 64]
+template <uint32_t BS>
 __device__ uint32_t dc_value(const uint8_t *pic0, uint32_t stride, uint32_t x, uint32_t y, uint32_t W, uint32_t H, uint8_t *lds_nb) {
-    const int  lane = threadIdx.x;
-    const bool inside = x + 16 <= W && y + 16 <= H;
-    uint32_t   sa, sl;
+    const uint32_t lane = threadIdx.x;
+    const bool     inside = x + BS <= W && y + BS <= H;
+    uint32_t       sa, sl;
     if (x > 0 && y > 0 && inside) {  // get_neighbor_samples_dc
         const uint8_t *src = pic0 + (size_t)y * stride + x;
         uint32_t       v = 0;
-        if (lane < 16)
+        if (lane < BS)
             v = ld8(src - stride + lane);
-        else if (lane < 32)
-            v = ld8(src + (size_t)(lane - 16) * stride - 1);
-        sa = wave_sum(lane < 16 ? v : 0), sl = wave_sum(lane >= 16 && lane < 32 ? v : 0);
+        else if (lane < 2 * BS)
+            v = ld8(src + (size_t)(lane - BS) * stride - 1);
+        sa = wave_sum(lane < BS ? v : 0), sl = wave_sum(lane >= BS && lane < 2 * BS ? v : 0);
     } else {
-        uint8_t *above = lds_nb + 8, *left = lds_nb + 8 + 48;
+        uint8_t *above = lds_nb + 8, *left = lds_nb + NB_LEFT;
         if (lane == 0)
-            neighbours(above - 1, left - 1, pic0, stride, x, y, W, H);
+            neighbours<BS>(above - 1, left - 1, pic0, stride, x, y, W, H);
         __syncthreads();
-        sa = wave_sum(lane < 16 ? above[lane] : 0), sl = wave_sum(lane < 16 ? left[lane] : 0);
+        sa = wave_sum(lane < BS ? above[lane] : 0), sl = wave_sum(lane < BS ? left[lane] : 0);
         __syncthreads();
     }
     if (x > 0 && y > 0)
-        return (sa + sl + 16) / 32;
+        return (sa + sl + BS) / (2 * BS);
     if (x > 0)
-        return (sl + 8) / 16;
+        return (sl + BS / 2) / BS;
     if (y > 0)
-        return (sa + 8) / 16;
+        return (sa + BS / 2) / BS;
     return 128;
 }
 
-// residual (source - prediction) -> DCT 16x16 (pf_shape) -> quantize_fp -> svt_av1_block_error >> 2, max 1 (get_quantize_error);
-// with `inv` the inverse transform reconstructs onto recon (prediction and reconstruction may be the same samples)
+// residual (source - prediction) -> DCT BS x (BS >> SUB) on every (1 << SUB)-th row (pf_shape) -> quantize_fp -> svt_av1_block_error >> 2,
+// max 1 (get_quantize_error: neither transform size here is TX_32X32); with `inv` the inverse transform reconstructs onto recon
+// (prediction and reconstruction may be the same samples).  *nonzero = the block has a non-zero quantised coefficient (eob != 0).
+template <int BS, int SUB>
 __device__ int64_t quantize_error(const TplArgs &a, const uint8_t *src, uint32_t src_stride, const uint8_t *pred, uint32_t pred_stride,
-                                  uint8_t *recon, uint32_t recon_stride, bool inv, int32_t *scratch, int32_t *lds_tile) {
+                                  uint8_t *recon, uint32_t recon_stride, bool inv, int32_t *scratch, int32_t *lds_tile, bool *nonzero) {
+    constexpr int  TH = BS >> SUB, N = BS * TH;
+    static_assert(N <= 256 && N % 64 == 0, "the coefficient scratch of a block holds 2 x 256 values");
     const int      lane = threadIdx.x;
     SvtHipTxfmDesc d;
     memset(&d, 0, sizeof(d));
-    d.residual_off = (uint64_t)(uintptr_t)src, d.residual_stride = src_stride;
-    d.pred_off = (uint64_t)(uintptr_t)pred, d.pred_stride = pred_stride;
-    d.recon_off = (uint64_t)(uintptr_t)recon, d.recon_stride = recon_stride;
+    d.residual_off = (uint64_t)(uintptr_t)src, d.residual_stride = src_stride << SUB;
+    d.pred_off = (uint64_t)(uintptr_t)pred, d.pred_stride = pred_stride << SUB;
+    d.recon_off = (uint64_t)(uintptr_t)recon, d.recon_stride = recon_stride << SUB;
     d.coeff_off = (uint64_t)(uintptr_t)scratch, d.dqcoeff_off = (uint64_t)(uintptr_t)(scratch + 256);
     d.qcoeff_off = SVT_HIP_NO_OFFSET, d.qm_off = d.iqm_off = SVT_HIP_NO_OFFSET;
     d.iscan_off = (uint64_t)(uintptr_t)TPL_ISCAN;
@@ -145,14 +153,16 @@ __device__ int64_t quantize_error(const TplArgs &a, const uint8_t *src, uint32_t
     d.tx_type = 0, d.shape = a.j.pf_shape, d.bit_depth = 8, d.quant_mode = SVT_HIP_QUANT_FP, d.log_scale = 0;
     d.flags = (uint8_t)(SVT_HIP_TX_FWD | SVT_HIP_TX_SRC_PRED | (inv ? SVT_HIP_TX_INV : 0));
     SvtHipTxfmResult res;
-    txfm_block<16, 16>((uint8_t *)nullptr, d, &res, lane < 16, lane & 15, lds_tile + (lane >> 4) * (16 * 17));
+    memset(&res, 0, sizeof(res));
+    txfm_block<BS, TH>((uint8_t *)nullptr, d, &res, lane < BS, lane & (BS - 1), lds_tile + (lane / BS) * (TH * (BS + 1)));
+    *nonzero = __shfl((int)res.eob, 0, 64) != 0;  // lane 0 holds the block's result (the all-zero scan table makes eob 0 / 1)
     // the coefficient arrays were written by this wave: a workgroup-scope fence (wait for the stores, same CU) makes them
     // readable by its other lanes — no agent-scope cache write-back / invalidate here
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
     int64_t err = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < N / 64; k++) {
         const int     i = lane + 64 * k;
         const int64_t e = (int64_t)__hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
             (int64_t)__hip_atomic_load(scratch + 256 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -164,39 +174,45 @@ __device__ int64_t quantize_error(const TplArgs &a, const uint8_t *src, uint32_t
 
 __device__ __forceinline__ int64_t max64(int64_t x, int64_t y) { return x > y ? x : y; }
 
-__global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
-    __shared__ int32_t tile[4 * 16 * 17];
-    __shared__ uint8_t nb[8 + 48 + 48];
+// One block: (x, y) its origin.  Dependency flags live on the 16x16-cell grid (a block of 32x32 covers four cells).
+template <int BS, int SUB>
+__device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, const uint32_t y, int32_t *tile, uint8_t *nb) {
+    constexpr int NDW = BS * BS / 256;     // dwords of the block a lane holds: 1 (16x16) or 4 (32x32)
+    constexpr int LPR = BS / (4 * NDW);    // lanes per block row: 4 or 2
+    static_assert((64 / BS) * (BS >> SUB) * (BS + 1) <= 4 * 16 * 17, "transform tile");
     const SvtHipTplFrameJob &j = a.j;
-    __shared__ uint32_t s_ticket;
     const int      lane = threadIdx.x;
-    if (lane == 0)
-        s_ticket = atomicAdd(a.error + 1, 1u);
-    __syncthreads();
-    const uint32_t blk = s_ticket, bx = blk % a.a16, by = blk / a.a16, x = bx * 16, y = by * 16;
-    if (x + 8 > a.W || y + 8 > a.H)  // at least half of the block inside
+    const uint32_t cx = x >> 4, cy = y >> 4, cell0 = cy * a.a16 + cx;
+    if (x + BS / 2 > a.W || y + BS / 2 > a.H)  // at least half of the block inside
         return;
     const uint32_t ss = j.src.stride, rs = j.recon.stride;
     const uint8_t *src = a.src0 + (size_t)y * ss + x;
     uint8_t       *dst = a.rec0 + (size_t)y * rs + x;
-    int32_t       *scratch = a.scratch + (size_t)blk * 512;
-    SvtHipTplSrcStats *sst = &j.src_stats[(size_t)by * a.a16 + bx];
-    const int      lr = lane >> 2, lc = (lane & 3) * 4;  // this lane's four samples: row lr, columns lc .. lc + 3
-    const uint32_t spx = ld4(src + (size_t)lr * ss + lc);
+    int32_t       *scratch = a.scratch + (size_t)cell0 * 512;
+    SvtHipTplSrcStats *sst = &j.src_stats[cell0];
+    const int      lr = lane / LPR, lc = (lane % LPR) * 4 * NDW;  // this lane's samples: row lr, columns lc .. lc + 4 NDW - 1
+    uint32_t       spx[NDW];
+#pragma unroll
+    for (int k = 0; k < NDW; k++) spx[k] = ld4(src + (size_t)lr * ss + lc + 4 * k);
 
     int64_t  srcrf_dist = 0, recon_error = 1;
     uint64_t best_ref_poc = 0;
     int32_t  best_rf_idx = -1;
     int      mv_row = 0, mv_col = 0;
     uint32_t best_mode = 0;
+    bool     nonzero = false;
     if (!j.src_data_ready) {
         int64_t best_inter = INT64_MAX, best_intra = INT64_MAX;
         if (!j.disable_intra_pred) {
-            const uint32_t dc = dc_value(a.src0, ss, x, y, a.W, a.H, nb);
-            best_intra = wave_sum(__builtin_amdgcn_sad_u8(spx, dc * 0x01010101u, 0));
+            const uint32_t dc = dc_value<BS>(a.src0, ss, x, y, a.W, a.H, nb);
+            uint32_t       sad = 0;
+#pragma unroll
+            for (int k = 0; k < NDW; k++) sad = __builtin_amdgcn_sad_u8(spx[k], dc * 0x01010101u, sad);
+            best_intra = wave_sum(sad);
         }
         const uint32_t sb = (y >> 6) * ((((a.W + 7) & ~7u) + 63) >> 6) + (x >> 6);
-        uint32_t       me_off = 5 + ((y >> 4) & 3) * 4 + ((x >> 4) & 3);  // tpl_blk_idx_tab[1]
+        // tpl_blk_idx_tab[1]: the 16x16 / 32x32 PU of the open-loop ME results
+        uint32_t me_off = BS == 32 ? 1 + ((y >> 5) & 1) * 2 + ((x >> 5) & 1) : 5 + ((y >> 4) & 3) * 4 + ((x >> 4) & 3);
         if (!j.enable_me_16x16)
             me_off = (me_off - 1) / 4;
         const size_t   pu = (size_t)sb * j.stored_pus + me_off;
@@ -214,14 +230,17 @@ __global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
             int            mx = (int16_t)((int16_t)(mv & 0xffff) << 3), my = (int16_t)((int16_t)(mv >> 16) << 3);
             if ((int)x + (mx >> 3) < -TPL_PAD)
                 mx = (int16_t)((-TPL_PAD - (int)x) << 3);
-            if ((int)x + 16 + (mx >> 3) > TPL_PAD + (int)rf.max_width - 1)
-                mx = (int16_t)(((TPL_PAD + (int)rf.max_width - 1) - ((int)x + 16)) << 3);
+            if ((int)x + BS + (mx >> 3) > TPL_PAD + (int)rf.max_width - 1)
+                mx = (int16_t)(((TPL_PAD + (int)rf.max_width - 1) - ((int)x + BS)) << 3);
             if ((int)y + (my >> 3) < -TPL_PAD)
                 my = (int16_t)((-TPL_PAD - (int)y) << 3);
-            if ((int)y + 16 + (my >> 3) > TPL_PAD + (int)rf.max_height - 1)
-                my = (int16_t)(((TPL_PAD + (int)rf.max_height - 1) - ((int)y + 16)) << 3);
+            if ((int)y + BS + (my >> 3) > TPL_PAD + (int)rf.max_height - 1)
+                my = (int16_t)(((TPL_PAD + (int)rf.max_height - 1) - ((int)y + BS)) << 3);
             const uint8_t *rp = rf.src + ((ptrdiff_t)y + my / 8 + lr) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + mx / 8 + lc;
-            const int64_t  cost = wave_sum(__builtin_amdgcn_sad_u8(spx, ld4(rp), 0));
+            uint32_t       sad = 0;
+#pragma unroll
+            for (int k = 0; k < NDW; k++) sad = __builtin_amdgcn_sad_u8(spx[k], ld4(rp + 4 * k), sad);
+            const int64_t  cost = wave_sum(sad);
             if (cost < best_inter)
                 best_inter = cost, best_ref_poc = rf.picture_number, best_rf_idx = (int32_t)(dir * 4 + ri), mv_row = my, mv_col = mx;
         }
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
         if (best_mode == NEWMV_MODE) {
             const SvtHipTplRef &rf = j.ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
             const uint8_t      *rp = rf.src + ((ptrdiff_t)y + (mv_row >> 3)) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + (mv_col >> 3);
-            srcrf_dist = quantize_error(a, src, ss, rp, rf.src_stride, nullptr, 0, false, scratch, tile) << 4;
+            srcrf_dist = (quantize_error<BS, SUB>(a, src, ss, rp, rf.src_stride, nullptr, 0, false, scratch, tile, &nonzero) << 4) << SUB;
         }
         if (j.store_src_stats && lane == 0) {
             SvtHipTplSrcStats s;
@@ -244,19 +263,30 @@ __global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
         best_ref_poc = sst->ref_frame_poc, best_mode = sst->best_mode;
     }
     // ---- reconstruction path
+    uint8_t *o = dst + (size_t)lr * rs + lc;
     if (best_mode == NEWMV_MODE) {
         const SvtHipTplRef &rf = j.ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
         const uint8_t      *rp = rf.recon + ((ptrdiff_t)y + (mv_row >> 3) + lr) * (ptrdiff_t)rf.recon_stride + (ptrdiff_t)x + (mv_col >> 3) + lc;
-        const uint32_t      v = ld4(rp);
-        uint8_t            *o = dst + (size_t)lr * rs + lc;
-        o[0] = (uint8_t)v, o[1] = (uint8_t)(v >> 8), o[2] = (uint8_t)(v >> 16), o[3] = (uint8_t)(v >> 24);
+#pragma unroll
+        for (int k = 0; k < NDW; k++) {
+            const uint32_t v = ld4(rp + 4 * k);
+            o[4 * k] = (uint8_t)v, o[4 * k + 1] = (uint8_t)(v >> 8), o[4 * k + 2] = (uint8_t)(v >> 16), o[4 * k + 3] = (uint8_t)(v >> 24);
+        }
     } else {
         // the DC prediction reads reconstructed samples of the left / top / top-left blocks: wait for them
         if (lane == 0) {
-            const uint32_t deps[3] = {bx ? blk - 1 : ~0u, by ? blk - a.a16 : ~0u, (bx && by) ? blk - a.a16 - 1 : ~0u};
-            for (int k = 0; k < 3; k++) {
-                if (deps[k] == ~0u)
-                    continue;
+            constexpr int NC = BS / 16;  // cells per block side
+            uint32_t deps[2 * NC + 1];
+            int      nd = 0;
+            for (int k = 0; k < NC; k++) {
+                if (cx)
+                    deps[nd++] = cell0 + k * a.a16 - 1;   // left column
+                if (cy)
+                    deps[nd++] = cell0 - a.a16 + k;        // top row
+            }
+            if (cx && cy)
+                deps[nd++] = cell0 - a.a16 - 1;
+            for (int k = 0; k < nd; k++) {
                 uint32_t spins = 0;
                 while (__hip_atomic_load(&a.flags[deps[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                     __builtin_amdgcn_s_sleep(32);
@@ -269,38 +299,115 @@ __global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const uint32_t dc = dc_value(a.rec0, rs, x, y, a.W, a.H, nb);
-        uint8_t       *o  = dst + (size_t)lr * rs + lc;
-        o[0] = o[1] = o[2] = o[3] = (uint8_t)dc;
+        const uint32_t dc = dc_value<BS>(a.rec0, rs, x, y, a.W, a.H, nb);
+#pragma unroll
+        for (int k = 0; k < 4 * NDW; k++) o[k] = (uint8_t)dc;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the prediction (this wave's stores) is in memory before the transform block reads it back
     __syncthreads();
     const bool inv = !j.disable_intra_pred || j.is_ref;
-    recon_error = quantize_error(a, src, ss, dst, rs, dst, rs, inv, scratch, tile);  // (its fence also publishes the reconstruction)
+    recon_error = quantize_error<BS, SUB>(a, src, ss, dst, rs, dst, rs, inv, scratch, tile, &nonzero);  // (its fence also publishes the reconstruction)
+    if (SUB && inv && nonzero) {
+        // the rows the sub-sampled transform left out repeat the reconstructed row above them (:1162-1180; only when the block has
+        // coefficients: otherwise every row keeps its prediction).  Row (lr & ~mask) was stored by other lanes of this wave: the
+        // fence + barrier inside quantize_error completed those stores.
+        constexpr int MASK = (1 << SUB) - 1;
+        if (lr & MASK) {
+            const uint8_t *from = dst + (size_t)(lr & ~MASK) * rs + lc;
+#pragma unroll
+            for (int k = 0; k < NDW; k++) {
+                const uint32_t v = ld4(from + 4 * k);
+                o[4 * k] = (uint8_t)v, o[4 * k + 1] = (uint8_t)(v >> 8), o[4 * k + 2] = (uint8_t)(v >> 16), o[4 * k + 3] = (uint8_t)(v >> 24);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+    }
     if (lane == 0) {
         SvtHipTplStats st;
         memset(&st, 0, sizeof(st));
-        st.srcrf_dist = srcrf_dist, st.recrf_dist = recon_error << 4;
+        st.srcrf_dist = srcrf_dist, st.recrf_dist = (recon_error << 4) << SUB;
         if (best_mode != NEWMV_MODE)
-            st.srcrf_dist = recon_error << 4;
+            st.srcrf_dist = (recon_error << 4) << SUB;
         st.recrf_dist = max64(st.srcrf_dist, st.recrf_dist);
         if (!j.tpl_i_slice && best_rf_idx != -1)
             st.mv_row = (int16_t)mv_row, st.mv_col = (int16_t)mv_col, st.ref_frame_poc = best_ref_poc;
         st.srcrf_dist = max64(1, st.srcrf_dist), st.recrf_dist = max64(1, st.recrf_dist), st.srcrf_rate = 1, st.recrf_rate = 1;
-        if (j.synth_blk_size == 16) {
-            j.stats[(size_t)by * a.a16 + bx] = st;
-        } else {  // the 16x16 data is duplicated on an 8x8 grid
-            const uint32_t stride = a.a16 << 1;
-            st.srcrf_dist = max64(1, st.srcrf_dist / 4), st.recrf_dist = max64(1, st.recrf_dist / 4);
-            SvtHipTplStats *d = &j.stats[(size_t)(y >> 3) * stride + (x >> 3)];
-            d[0] = st, d[1] = st, d[stride] = st, d[stride + 1] = st;
+        // result_model_store: the synthesizer's grid, statistics normalised to its cell size
+        const uint32_t cell = j.synth_blk_size;
+        const uint32_t aw = (a.W + 7) & ~7u, ah = (a.H + 7) & ~7u;
+        const uint32_t gstride = cell == 32 ? (aw + 31) >> 5 : (cell == 16 ? a.a16 : a.a16 << 1);
+        const uint32_t grows = cell == 32 ? (ah + 31) >> 5 : (cell == 16 ? a.rows16 : a.rows16 << 1);
+        if (BS < 32 && cell == 32) {
+            // four 16x16 blocks share the cell and the reference's last one (z-order: right, then below) stays: this block
+            // writes only if no later one is dispensed (at least half inside the picture)
+            const uint32_t x0 = x & ~31u, y0 = y & ~31u, me = ((y >> 4) & 1) * 2 + ((x >> 4) & 1);
+            bool           last = true;
+            for (uint32_t k = me + 1; k < 4; k++) last = last && !(x0 + (k & 1) * 16 + 8 <= a.W && y0 + (k >> 1) * 16 + 8 <= a.H);
+            if (last)
+                j.stats[(size_t)(y >> 5) * gstride + (x >> 5)] = st;
+        } else {
+            const uint32_t per = BS / cell ? BS / cell : 1;
+            if (per > 1) {
+                const int64_t div = (int64_t)per * per;
+                st.srcrf_dist = max64(1, st.srcrf_dist / div), st.recrf_dist = max64(1, st.recrf_dist / div);
+            }
+            for (uint32_t gy = 0; gy < per; gy++)
+                for (uint32_t gx = 0; gx < per; gx++)
+                    if (x / cell + gx < gstride && y / cell + gy < grows)
+                        j.stats[(size_t)(y / cell + gy) * gstride + x / cell + gx] = st;
         }
     }
-    // publish: every lane's reconstruction stores are complete (the fence inside quantize_error waited for them, then the barrier),
-    // one agent-scope release makes them visible to other CUs / XCDs, then the flag
+    // publish: every lane's reconstruction stores are complete (the last workgroup fence waited for them, then the barrier),
+    // one agent-scope release makes them visible to other CUs / XCDs, then the flags of the cells this block covers
     if (lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(&a.flags[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < (BS / 16) * (BS / 16); k++) {
+            const uint32_t fx = cx + (k & (BS / 16 - 1)), fy = cy + k / (BS / 16);
+            if (fx < a.a16 && fy < a.rows16)
+                __hip_atomic_store(&a.flags[fy * a.a16 + fx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// MODE 0: every block 16x16, transform 16x16 (tpl levels 3 / 4).  MODE 1 (level 5): complete 64x64 blocks are dispensed as 32x32
+// blocks, incomplete ones (right / bottom picture edge) as 16x16 blocks (svt_aom_tpl_disp_kernel, :2043-2051), transform on every 4th
+// row in both.  A workgroup takes the next block in raster order of the block origins from the ticket counter: every block a block
+// waits for (left, top, top-left) has a lower ticket, so it is running or done whatever the dispatch order.
+template <int MODE>
+__global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
+    __shared__ int32_t  tile[4 * 16 * 17];
+    __shared__ uint8_t  nb[8 + 88 + 88];
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0)
+        s_ticket = atomicAdd(a.error + 1, 1u);
+    __syncthreads();
+    const uint32_t t = s_ticket;
+    if (MODE == 0) {
+        tpl_block<16, 0>(a, (t % a.a16) * 16, (t / a.a16) * 16, tile, nb);
+        return;
+    }
+    const uint32_t aw = (a.W + 7) & ~7u, ah = (a.H + 7) & ~7u;
+    const uint32_t nfc = aw >> 6, n16c = ((aw & 63) + 15) >> 4, nfr = ah >> 6;  // complete columns, 16-wide columns behind them, complete rows
+    const uint32_t even = 2 * nfc + n16c, per_row = 2 * even + 2 * n16c;        // blocks that start in a 16-row with / of a complete 64-row
+    if (t < nfr * per_row) {
+        uint32_t u = t % per_row, q = 0;
+        if (u >= even) {
+            u -= even, q = 1;
+            if (u >= n16c) {
+                u -= n16c, q = 2;
+                if (u >= even)
+                    u -= even, q = 3;
+            }
+        }
+        const uint32_t y = (t / per_row) * 64 + q * 16;
+        if (!(q & 1) && u < 2 * nfc)
+            tpl_block<32, 2>(a, u * 32, y, tile, nb);
+        else
+            tpl_block<16, 2>(a, nfc * 64 + (u - ((q & 1) ? 0 : 2 * nfc)) * 16, y, tile, nb);
+    } else {
+        const uint32_t v = t - nfr * per_row;
+        tpl_block<16, 2>(a, (v % a.a16) * 16, nfr * 64 + (v / a.a16) * 16, tile, nb);
     }
 }
 
@@ -325,8 +432,13 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
         return bad("planes need >= 32 samples of padding (TPL_PADX / TPL_PADY: the clipped vectors reach that far, reference_object.c:439-442)");
     if (s.stride < s.width + 2u * s.org_x || r.stride < r.width + 2u * r.org_x)
         return bad("stride smaller than the padded width");
-    if (job->synth_blk_size != 16 && job->synth_blk_size != 8)
-        return bad("synth_blk_size must be 16 or 8");
+    const bool b32 = job->blk_size == 32;
+    if (job->blk_size != 0 && job->blk_size != 16 && !b32)
+        return bad("blk_size must be 16 (or 0) or 32");
+    if (b32 ? job->subsample_tx != 2 : job->subsample_tx != 0)
+        return bad("subsample_tx must be 0 with 16x16 blocks and 2 with 32x32 blocks");
+    if (job->synth_blk_size != 16 && job->synth_blk_size != 8 && !(b32 && job->synth_blk_size == 32))
+        return bad("synth_blk_size must be 16 or 8 (or 32 with 32x32 blocks)");
     if (job->pf_shape > 2)
         return bad("pf_shape must be 0, 1 or 2");
     if (!job->stats || !job->src_stats)
@@ -351,7 +463,9 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
         return SVT_HIP_ERR_NO_DEVICE;
     hipStream_t    st = resolve_stream(stream);
     const uint32_t aw = (s.width + 7) & ~7u, ah = (s.height + 7) & ~7u, a16 = (aw + 15) >> 4, rows16 = (ah + 15) >> 4;
-    const size_t   blocks = (size_t)a16 * rows16;
+    // level 5: 32x32 blocks in the complete 64x64 blocks, 16x16 blocks in the incomplete ones (see tpl_kernel)
+    const uint32_t nfc = aw >> 6, n16c = ((aw & 63) + 15) >> 4, nfr = ah >> 6;
+    const size_t   blocks = b32 ? (size_t)nfr * (4 * nfc + 4 * n16c) + (size_t)(rows16 - 4 * nfr) * a16 : (size_t)a16 * rows16;
     uint8_t       *ws = (uint8_t *)job->workspace;
     const size_t   fb = flag_bytes(s.width, s.height);
     SVT_HIP_CHECK(hipMemsetAsync(ws, 0, fb + 256, st));
@@ -359,7 +473,10 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     a.j = *job;
     a.src0 = s.buf + (size_t)s.org_y * s.stride + s.org_x, a.rec0 = r.buf + (size_t)r.org_y * r.stride + r.org_x;
     a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb), a.scratch = (int32_t *)(ws + fb + 256);
-    hipLaunchKernelGGL(tpl_kernel, dim3((uint32_t)blocks), dim3(64), 0, st, a);
+    if (b32)
+        hipLaunchKernelGGL((tpl_kernel<1>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
+    else
+        hipLaunchKernelGGL((tpl_kernel<0>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }

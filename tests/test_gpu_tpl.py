@@ -92,6 +92,21 @@ def test_dispenser_frame_4k(hip, orc):
     assert (modes == 16).sum() > 1000
 
 
+def test_level5_all_intra_and_inter_1080p(hip, orc):
+    """tpl level 5 (32x32 blocks, TX_32X8 on every 4th row, 32x32 synthesizer grid as the reference picks above 720p) at 1920x1080:
+    an I slice (every block waits for its neighbours) and a B picture."""
+    for name, opt in (("l5_islice_1080p", dict(T.BASE, i_slice=1, tpl_i_slice=1, synth_blk_size=32, **T.L5)),
+                      ("l5_pan_1080p", dict(T.BASE, synth_blk_size=32, **T.L5))):
+        case = (name, "pan", 1920, 1080, 120, opt)
+        a, b = T.TplScene(orc, case, key="m8_1080p_tl2"), T.TplScene(orc, case, key="m8_1080p_tl2")
+        assert orc.orc_tpl_dispenser_frame(C.byref(a.job())) == 0
+        got = run_gpu(hip, b)
+        for k, v in a.results().items():
+            assert np.array_equal(got[k], v), (name, k, int((got[k] != v).sum()))
+        if not opt["i_slice"]:
+            assert (a.src_stats["best_mode"] == 16).any() and (a.src_stats["best_mode"] == 0).any()
+
+
 def test_argument_checks(hip, orc):
     s = T.TplScene(orc, T.CASES[0])
     dm = DevMap(hip)

@@ -9,6 +9,7 @@ from svtav1_hip import abi, frames
 
 # (name, clip kind, width, height, qindex, options)
 BASE = dict(pf_shape=2, disable_intra_pred=0, is_ref=1, i_slice=0, tpl_i_slice=0, src_data_ready=0, store_src_stats=1, synth_blk_size=16)
+L5 = dict(blk_size=32, subsample_tx=2)
 CASES = [
     ("pan_n4", "pan", 192, 128, 120, dict(BASE)),
     ("blocks_full", "blocks", 256, 192, 60, dict(BASE, pf_shape=0)),
@@ -18,10 +19,27 @@ CASES = [
     ("pan_islice", "pan", 144, 96, 90, dict(BASE, i_slice=1, tpl_i_slice=1)),
     ("blocks_nointra_ref", "blocks", 192, 192, 20, dict(BASE, disable_intra_pred=1, is_ref=1, pf_shape=1)),
     ("pan_second_pass", "pan", 192, 128, 120, dict(BASE, src_data_ready=1)),
+    # tpl level 5 (presets M10 and faster): 32x32 blocks, transform TX_32X8 on every 4th row
+    ("l5_pan_n4", "pan", 192, 128, 120, dict(BASE, **L5)),
+    ("l5_blocks_full_synth32", "blocks", 256, 192, 60, dict(BASE, pf_shape=0, synth_blk_size=32, **L5)),
+    ("l5_fastpan_n2_ragged_synth8", "fastpan", 200, 136, 180, dict(BASE, pf_shape=1, synth_blk_size=8, **L5)),
+    ("l5_noise_intra_halfrow", "noise", 136, 112, 40, dict(BASE, **L5)),
+    ("l5_static_nointra_nonref", "static", 128, 128, 100, dict(BASE, disable_intra_pred=1, is_ref=0, **L5)),
+    ("l5_pan_islice", "pan", 160, 96, 90, dict(BASE, i_slice=1, tpl_i_slice=1, **L5)),
+    ("l5_pan_second_pass", "pan", 192, 128, 120, dict(BASE, src_data_ready=1, **L5)),
+    ("l5_pan_half_column", "pan", 376, 216, 120, dict(BASE, **L5)),   # the last 32x32 column / row is 24 samples inside the picture
 ]
 # round_fp[2], quant_fp[2], dequant[2] of the reference's 8-bit tables (svt_av1_build_quantizer) at the qindex values above,
 # read from the reference by tests/golden/make_golden_tpl.py and checked against it in test_tpl_oracle.py
 QUANT = {}
+
+
+def stats_cells(w, h, synth):
+    aw, ah = (w + 7) // 8 * 8, (h + 7) // 8 * 8
+    if synth == 32:
+        return ((aw + 31) // 32) * ((ah + 31) // 32)
+    g = 1 if synth == 16 else 2
+    return ((aw + 15) >> 4) * g * ((ah + 15) >> 4) * g
 
 
 class TplScene:
@@ -47,8 +65,7 @@ class TplScene:
         self.out = frames.HostPlane(w, h, frames.FULL_PAD)
         self.out.buf[...] = rng.integers(0, 256, size=self.out.buf.shape, dtype=np.uint8)
         a16, rows16 = ((w + 7) // 8 * 8 + 15) >> 4, ((h + 7) // 8 * 8 + 15) >> 4
-        g = 1 if opt["synth_blk_size"] == 16 else 2
-        self.stats = np.zeros(a16 * g * rows16 * g, dtype=np.dtype(abi.TplStats))
+        self.stats = np.zeros(stats_cells(w, h, opt["synth_blk_size"]), dtype=np.dtype(abi.TplStats))
         self.src_stats = np.zeros(a16 * rows16, dtype=np.dtype(abi.TplSrcStats))
 
     def job(self, ptr=None):

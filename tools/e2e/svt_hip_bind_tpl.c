@@ -78,7 +78,9 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
     EncodeContext      *enc = scs->enc_ctx;
     const TplControls  *tc  = &pcs->tpl_ctrls;
     EbPictureBufferDesc *src = pcs->enhanced_pic, *recon = enc->mc_flow_rec_picture_buffer[frame_idx];
-    if (tc->dispenser_search_level != 0 || tc->intra_mode_end != DC_PRED || !tc->use_sad_in_src_search || tc->subsample_tx != 0 ||
+    /* tpl level 4 (16x16 blocks) or level 5 (32x32 blocks, TX_32X8 on every 4th row) */
+    const int lvl5 = tc->dispenser_search_level == 1 && tc->subsample_tx == 2;
+    if (!(lvl5 || (tc->dispenser_search_level == 0 && tc->subsample_tx == 0)) || tc->intra_mode_end != DC_PRED || !tc->use_sad_in_src_search ||
         tc->subpel_depth != FULL_PEL || tc->compute_rate || !scs->in_loop_ois || src->org_x < 32 || src->org_y < 32 || recon->org_x < 32 ||
         recon->org_y < 32 || (tc->synth_blk_size != 8 && tc->synth_blk_size != 16 && tc->synth_blk_size != 32) ||
         scs->static_config.tile_rows || scs->static_config.tile_columns)
@@ -88,6 +90,10 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
         return 1;
     const uint32_t W = src->width, H = src->height, aw = pcs->aligned_width, ah = pcs->aligned_height;
     const uint32_t a16 = (aw + 15) >> 4, rows16 = (ah + 15) >> 4, nb = pcs->b64_total_count;
+    if (lvl5 && tc->synth_blk_size == 8) { /* (no preset: the synthesizer grid is 16 or 32, initial_rc_process.c:198-232) */
+        free(job);
+        return 1;
+    }
     MotionEstimationData *med = pcs->pa_me_data;
     const uint32_t stored = pcs->enable_me_16x16 ? (pcs->enable_me_8x8 ? 85u : 21u) : 5u;
     const size_t   n_mv = (size_t)nb * stored * med->max_refs * 4, n_cand = (size_t)nb * stored * med->max_cand, n_cnt = (size_t)nb * stored;
@@ -167,7 +173,9 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
         job->pf_shape = (uint8_t)tc->pf_shape;
         job->disable_intra_pred = tc->disable_intra_pred_nref && (pcs->temporal_layer_index == pcs->hierarchical_levels);
         job->is_ref = pcs->tpl_data.is_ref, job->i_slice = pcs->slice_type == I_SLICE, job->tpl_i_slice = pcs->tpl_data.tpl_slice_type == I_SLICE;
-        job->src_data_ready = pcs->tpl_src_data_ready, job->store_src_stats = scs->tpl_lad_mg > 0, job->synth_blk_size = 16;
+        job->src_data_ready = pcs->tpl_src_data_ready, job->store_src_stats = scs->tpl_lad_mg > 0;
+        /* level 4: one cell per 16x16 block, the synthesizer's grid is filled below; level 5: the library writes that grid itself */
+        job->synth_blk_size = lvl5 ? tc->synth_blk_size : 16, job->blk_size = lvl5 ? 32 : 16, job->subsample_tx = lvl5 ? 2 : 0;
         for (int i = 0; i < 2; i++) {
             job->round_fp[i] = enc->quants_8bit.y_round_fp[qindex][i], job->quant_fp[i] = enc->quants_8bit.y_quant_fp[qindex][i];
             job->dequant[i] = enc->deq_8bit.y_dequant_qtx[qindex][i];
@@ -181,22 +189,38 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
             g_api.download(h_sst, d_sst, n_sst, NULL) | g_api.sync(NULL);
     }
     if (rc == 0) {
-        /* result_model_store (src_ops_process.c:266-340) from the 16x16 grid, and the source-based statistics, block by block in
-         * the reference's order (64x64 blocks raster, 16x16 blocks in z-order inside: a 32x32 synthesizer cell keeps its last block) */
-        const uint32_t bw64 = (aw + 63) / 64;
-        for (uint32_t sb = 0; sb < nb; sb++)
-            for (uint32_t z = 0; z < 16; z++) {
-                const uint32_t bx = (z & 1) | ((z >> 2) & 1) << 1, by = ((z >> 1) & 1) | ((z >> 3) & 1) << 1;
-                const uint32_t x = (sb % bw64) * 64 + bx * 16, y = (sb / bw64) * 64 + by * 16;
-                if (x + 8 > W || y + 8 > H)
+        /* result_model_store (src_ops_process.c:266-340) from the one-cell-per-block grid, and the source-based statistics, block by
+         * block in the reference's order (64x64 blocks raster, blocks in z-order inside: with 16x16 blocks a 32x32 synthesizer cell
+         * keeps its last block) */
+        const uint32_t bw64 = (aw + 63) / 64, s32 = (aw + 31) / 32;
+        for (uint32_t sb = 0; sb < nb; sb++) {
+            /* level 5 dispenses complete 64x64 blocks as 32x32 blocks and incomplete ones as 16x16 blocks (:2043-2051) */
+            const B64Geom *g  = &scs->b64_geom[sb];
+            const uint32_t bs = (lvl5 && g->width == 64 && g->height == 64) ? 32 : 16, nz = bs == 32 ? 4 : 16;
+            for (uint32_t z = 0; z < nz; z++) {
+                const uint32_t bx = bs == 32 ? (z & 1) : ((z & 1) | ((z >> 2) & 1) << 1), by = bs == 32 ? (z >> 1) : (((z >> 1) & 1) | ((z >> 3) & 1) << 1);
+                const uint32_t x = (sb % bw64) * 64 + bx * bs, y = (sb / bw64) * 64 + by * bs;
+                if (x + (bs >> 1) > W || y + (bs >> 1) > H)
                     continue;
+                if (lvl5) { /* the cells this block stores, as they are in the library's grid */
+                    const uint32_t cell = tc->synth_blk_size, stride = cell == 32 ? s32 : a16, per = bs / cell ? bs / cell : 1;
+                    for (uint32_t cy = 0; cy < per; cy++)
+                        for (uint32_t cx = 0; cx < per; cx++) {
+                            const size_t          idx = (size_t)(y / cell + cy) * stride + x / cell + cx;
+                            const SvtHipTplStats *s   = &h_st[idx];
+                            TplStats             *t   = med->tpl_stats[idx];
+                            memset(t, 0, sizeof(*t));
+                            t->srcrf_dist = s->srcrf_dist, t->recrf_dist = s->recrf_dist, t->srcrf_rate = s->srcrf_rate, t->recrf_rate = s->recrf_rate;
+                            t->mv.row = s->mv_row, t->mv.col = s->mv_col, t->ref_frame_poc = s->ref_frame_poc;
+                        }
+                } else {
                 const SvtHipTplStats *s = &h_st[(size_t)(y >> 4) * a16 + (x >> 4)];
                 TplStats              t;
                 memset(&t, 0, sizeof(t));
                 t.srcrf_dist = s->srcrf_dist, t.recrf_dist = s->recrf_dist, t.srcrf_rate = s->srcrf_rate, t.recrf_rate = s->recrf_rate;
                 t.mv.row = s->mv_row, t.mv.col = s->mv_col, t.ref_frame_poc = s->ref_frame_poc;
                 if (tc->synth_blk_size == 32) {
-                    *med->tpl_stats[(size_t)(y >> 5) * ((aw + 31) / 32) + (x >> 5)] = t;
+                    *med->tpl_stats[(size_t)(y >> 5) * s32 + (x >> 5)] = t;
                 } else if (tc->synth_blk_size == 16) {
                     *med->tpl_stats[(size_t)(y >> 4) * a16 + (x >> 4)] = t;
                 } else {
@@ -206,6 +230,7 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
                     TplStats **d = &med->tpl_stats[(size_t)(y >> 3) * stride + (x >> 3)];
                     *d[0] = t, *d[1] = t, *d[stride] = t, *d[stride + 1] = t;
                 }
+                }
                 if (!job->src_data_ready && job->store_src_stats) {
                     const SvtHipTplSrcStats *q = &h_sst[(size_t)(y >> 4) * a16 + (x >> 4)];
                     TplSrcStats             *o = &med->tpl_src_stats_buffer[(size_t)(y >> 4) * a16 + (x >> 4)];
@@ -214,6 +239,7 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
                     o->best_intra_mode = (PredictionMode)q->best_intra_mode;
                 }
             }
+        }
     }
     if (rc != 0)
         fprintf(stderr, "svt_hip_bind_tpl: picture %llu stays on the CPU (%s)\n", (unsigned long long)pcs->picture_number,
