@@ -39,103 +39,109 @@ __device__ __forceinline__ void comp_out(const SvtHipConvolveDesc &d, int y, int
     }
 }
 
-// tile: index of the 64 x 64 tile inside the block (row-major); a tile beyond the block returns at once
-__device__ __forceinline__ void convolve_tile(const SvtHipConvolveDesc &d, const int tile, uint16_t *__restrict__ in, int16_t *__restrict__ im) {
+// tile: index of the T x T tile inside the block (row-major); a tile beyond the block returns at once.  NT threads call it together
+// (the whole workgroup); in / im: (T + 7) * P uint16 and (T + 7) * T int16 of LDS.
+template <int NT, int T, int P>
+__device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, const int tile, uint16_t *__restrict__ in, int16_t *__restrict__ im) {
     if (d.w == 0 || d.h == 0)  // an unused slot of a fixed-size descriptor array (tf_picture.hip)
         return;
-    const int tiles_x = (d.w + TILE - 1) / TILE;
-    const int x0 = (tile % tiles_x) * TILE, y0 = (tile / tiles_x) * TILE;
+    const int tiles_x = (d.w + T - 1) / T;
+    const int x0 = (tile % tiles_x) * T, y0 = (tile / tiles_x) * T;
     if (y0 >= d.h)
         return;
-    const int tw = min(TILE, d.w - x0), th = min(TILE, d.h - y0);
+    const int tw = min(T, d.w - x0), th = min(T, d.h - y0);
     const int tx = d.taps_x, ty = d.taps_y, is16 = d.is_16bit, bd = d.bit_depth, r0 = d.round_0, r1 = d.round_1;
     const int fo_h = tx ? tx / 2 - 1 : 0, fo_v = ty ? ty / 2 - 1 : 0;
     const int ew = tw + (tx ? tx - 1 : 0), eh = th + (ty ? ty - 1 : 0);  // staged extent
-    for (int idx = threadIdx.x; idx < eh * ew; idx += 256) {
+    for (int idx = threadIdx.x; idx < eh * ew; idx += NT) {
         const int r = idx / ew, c = idx - r * ew;
-        in[r * IP + c] = (uint16_t)ldpx(d.src, (ptrdiff_t)(y0 + r - fo_v) * d.src_stride + (x0 + c - fo_h), is16);
+        in[r * P + c] = (uint16_t)ldpx(d.src, (ptrdiff_t)(y0 + r - fo_v) * d.src_stride + (x0 + c - fo_h), is16);
     }
     __syncthreads();
     if (d.compound) {  // jnt_convolve_{2d_copy, x, y, 2d}
         const int     offset_bits = bd + 2 * FILTER_BITS - r0, round_bits = 2 * FILTER_BITS - r0 - r1;
         const int32_t round_offset = (1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1));
         if (tx && ty) {
-            for (int idx = threadIdx.x; idx < eh * tw; idx += 256) {
+            for (int idx = threadIdx.x; idx < eh * tw; idx += NT) {
                 const int r = idx / tw, c = idx - r * tw;
                 int32_t   sum = 1 << (bd + FILTER_BITS - 1);
-                for (int k = 0; k < tx; k++) sum += d.filter_x[k] * (int32_t)in[r * IP + c + k];
-                im[r * TILE + c] = (int16_t)(uint16_t)rnd(sum, r0);
+                for (int k = 0; k < tx; k++) sum += d.filter_x[k] * (int32_t)in[r * P + c + k];
+                im[r * T + c] = (int16_t)(uint16_t)rnd(sum, r0);
             }
             __syncthreads();
         }
-        for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+        for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
             const int r = idx / tw, c = idx - r * tw;
             int32_t   res;
             if (tx && ty) {
                 int32_t sum = 1 << offset_bits;
-                for (int k = 0; k < ty; k++) sum += d.filter_y[k] * (int32_t)im[(r + k) * TILE + c];
+                for (int k = 0; k < ty; k++) sum += d.filter_y[k] * (int32_t)im[(r + k) * T + c];
                 res = (uint16_t)rnd(sum, r1);
             } else if (ty) {
                 res = 0;
-                for (int k = 0; k < ty; k++) res += d.filter_y[k] * (int32_t)in[(r + k) * IP + c];
+                for (int k = 0; k < ty; k++) res += d.filter_y[k] * (int32_t)in[(r + k) * P + c];
                 res *= 1 << (FILTER_BITS - r0);
                 res = rnd(res, r1) + round_offset;
             } else if (tx) {
                 res = 0;
-                for (int k = 0; k < tx; k++) res += d.filter_x[k] * (int32_t)in[r * IP + c + k];
+                for (int k = 0; k < tx; k++) res += d.filter_x[k] * (int32_t)in[r * P + c + k];
                 res = (1 << (FILTER_BITS - r1)) * rnd(res, r0) + round_offset;
             } else {
-                res = (uint16_t)((uint16_t)((int32_t)in[r * IP + c] << round_bits) + (uint16_t)round_offset);
+                res = (uint16_t)((uint16_t)((int32_t)in[r * P + c] << round_bits) + (uint16_t)round_offset);
             }
             comp_out(d, y0 + r, x0 + c, res, round_offset, round_bits);
         }
         return;
     }
     if (!tx && !ty) {  // 2d_copy_sr
-        for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+        for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
             const int r = idx / tw, c = idx - r * tw;
-            stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, in[r * IP + c], 16);
+            stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, in[r * P + c], 16);
         }
         return;
     }
     if (!ty) {  // x_sr
         const int bits = FILTER_BITS - r0;
-        for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+        for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
             const int r = idx / tw, c = idx - r * tw;
             int32_t   res = 0;
-            for (int k = 0; k < tx; k++) res += d.filter_x[k] * (int32_t)in[r * IP + c + k];
+            for (int k = 0; k < tx; k++) res += d.filter_x[k] * (int32_t)in[r * P + c + k];
             stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(rnd(res, r0), bits), bd);
         }
         return;
     }
     if (!tx) {  // y_sr
-        for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+        for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
             const int r = idx / tw, c = idx - r * tw;
             int32_t   res = 0;
-            for (int k = 0; k < ty; k++) res += d.filter_y[k] * (int32_t)in[(r + k) * IP + c];
+            for (int k = 0; k < ty; k++) res += d.filter_y[k] * (int32_t)in[(r + k) * P + c];
             stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(res, FILTER_BITS), bd);
         }
         return;
     }
     // 2d_sr
-    for (int idx = threadIdx.x; idx < eh * tw; idx += 256) {
+    for (int idx = threadIdx.x; idx < eh * tw; idx += NT) {
         const int r = idx / tw, c = idx - r * tw;
         int32_t   sum = 1 << (bd + FILTER_BITS - 1);
-        for (int k = 0; k < tx; k++) sum += d.filter_x[k] * (int32_t)in[r * IP + c + k];
-        im[r * TILE + c] = (int16_t)(uint16_t)rnd(sum, r0);
+        for (int k = 0; k < tx; k++) sum += d.filter_x[k] * (int32_t)in[r * P + c + k];
+        im[r * T + c] = (int16_t)(uint16_t)rnd(sum, r0);
     }
     __syncthreads();
     const int bits = 2 * FILTER_BITS - r0 - r1, offset_bits = bd + 2 * FILTER_BITS - r0;
-    for (int idx = threadIdx.x; idx < th * tw; idx += 256) {
+    for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
         const int r = idx / tw, c = idx - r * tw;
         int32_t   sum = 1 << offset_bits;
-        for (int k = 0; k < ty; k++) sum += d.filter_y[k] * (int32_t)im[(r + k) * TILE + c];
+        for (int k = 0; k < ty; k++) sum += d.filter_y[k] * (int32_t)im[(r + k) * T + c];
         int32_t res = rnd(sum, r1) - ((1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1)));
         if (!is16)
             res = (int16_t)res;  // the 8-bit function narrows to int16 first (inter_prediction.c:343-345)
         stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(res, bits), bd);
     }
 
+}
+
+__device__ __forceinline__ void convolve_tile(const SvtHipConvolveDesc &d, const int tile, uint16_t *__restrict__ in, int16_t *__restrict__ im) {
+    convolve_tile_t<256, TILE, IP>(d, tile, in, im);
 }
 
 }  // namespace conv

@@ -169,15 +169,15 @@ __device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int bsize, int lx,
     __syncthreads();
     const int64_t  tsum = L.red_sum[0] + L.red_sum[1] + L.red_sum[2] + L.red_sum[3];
     const uint64_t tsse = L.red_sse[0] + L.red_sse[1] + L.red_sse[2] + L.red_sse[3];
-    const int32_t  n    = bsize * rows_out;
+    const int      ln   = 2 * lb - vshift;  // n = bsize * rows_out is a power of two and the squares are not negative: / n is a shift
     uint64_t       var;
     if (!s.is16) {  // svt_aom_variance*_c
         const int32_t s32 = (int32_t)tsum;
-        var = (uint32_t)((uint32_t)tsse - (uint32_t)(((int64_t)s32 * s32) / n));
+        var = (uint32_t)((uint32_t)tsse - (uint32_t)(((int64_t)s32 * s32) >> ln));
     } else {  // svt_aom_highbd_10_variance*_c
         const uint32_t e = (uint32_t)((tsse + 8) >> 4);
         const int32_t  m = (int32_t)((tsum + 2) >> 2);
-        const int64_t  v = (int64_t)e - (((int64_t)m * m) / n);
+        const int64_t  v = (int64_t)e - (((int64_t)m * m) >> ln);
         var = v >= 0 ? (uint32_t)v : 0;
     }
     return var << vshift;
@@ -367,19 +367,43 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
     }
 }
 
-// the final predictions of one (reference picture, 64x64 block): its up to 48 descriptors one after the other, each by the whole
-// workgroup through the tile function of inter_convolve.hip.  (Handing the fixed-slot arrays to svt_hip_convolve_batch works too,
-// but three quarters of its workgroups would find an empty slot: 2.3 ms per reference picture at 4K against 0.1 ms this way.)
+// the final predictions of one (reference picture, 64x64 block): up to 48 descriptors in fixed slots.  The blocks wider than 16
+// samples (at most four per 64x64 block: one 64x64 + its two chroma blocks, or four 32x32) one after the other by a whole workgroup
+// through the tile function of inter_convolve.hip; the small ones (16x16 luma, 16x16 / 8x8 chroma: up to 48) by four one-wave
+// workgroups with a 2 KB tile each, so that a 64x64 block's slots run side by side instead of one after the other.  Both kernels
+// pick their slots from one look at all 48 widths: walking the slots with one dependent descriptor load each cost ~2 us per slot
+// (1.39 -> 0.45 ms at 4K for both together).
+// (Handing the fixed-slot arrays to svt_hip_convolve_batch works too, but three quarters of its 256-thread, 19 KB workgroups
+// would find an empty slot: 2.3 ms per reference picture at 4K.)
+constexpr int SMALL_T = 16, SMALL_P = SMALL_T + 8;
 __global__ __launch_bounds__(256) void tf_predict_kernel(const RefineRef *__restrict__ refs) {
     __shared__ uint16_t in[(conv::TILE + 7) * conv::IP];
     __shared__ int16_t  im[(conv::TILE + 7) * conv::TILE];
     const SvtHipConvolveDesc *descs = refs[blockIdx.y].desc + (size_t)blockIdx.x * DESC_PER_B64;
-    for (int slot = 0; slot < DESC_PER_B64; slot++) {
-        const SvtHipConvolveDesc d = descs[slot];
-        if (d.w == 0)  // uniform over the workgroup
-            continue;
+    // which slots are this kernel's: every wave looks at all 48 widths at once (walking the slots one dependent descriptor load
+    // after the other cost ~2 us per slot, 100 us per workgroup)
+    const int lane = threadIdx.x & 63;
+    uint64_t  todo = __ballot(lane < DESC_PER_B64 && descs[lane < DESC_PER_B64 ? lane : 0].w > SMALL_T);
+    for (; todo; todo &= todo - 1) {
+        const SvtHipConvolveDesc d = descs[__builtin_ctzll(todo)];
         __syncthreads();  // the previous descriptor's readers are done with the LDS buffers
         conv::convolve_tile(d, 0, in, im);
+    }
+}
+constexpr int SMALL_SPLIT = 4;  // one-wave workgroups per 64x64 block: its small slots are dealt round-robin to them
+__global__ __launch_bounds__(64) void tf_predict_small_kernel(const RefineRef *__restrict__ refs) {
+    __shared__ uint16_t in[(SMALL_T + 7) * SMALL_P];
+    __shared__ int16_t  im[(SMALL_T + 7) * SMALL_T];
+    const SvtHipConvolveDesc *descs = refs[blockIdx.y].desc + (size_t)(blockIdx.x / SMALL_SPLIT) * DESC_PER_B64;
+    const int      lane = threadIdx.x, part = blockIdx.x % SMALL_SPLIT;
+    const uint32_t w    = lane < DESC_PER_B64 ? descs[lane].w : 0;
+    int            k    = 0;
+    for (uint64_t todo = __ballot(w != 0 && w <= SMALL_T); todo; todo &= todo - 1, k++) {
+        if (k % SMALL_SPLIT != part)
+            continue;
+        const SvtHipConvolveDesc d = descs[__builtin_ctzll(todo)];
+        __syncthreads();
+        conv::convolve_tile_t<64, SMALL_T, SMALL_P>(d, 0, in, im);
     }
 }
 
@@ -606,6 +630,7 @@ extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void
         hipLaunchKernelGGL(tf_refine_kernel<false>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
     SVT_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(tf_predict_kernel, dim3(nb, job->n_refs), dim3(256), 0, st, d_refs);
+    hipLaunchKernelGGL(tf_predict_small_kernel, dim3(nb * SMALL_SPLIT, job->n_refs), dim3(64), 0, st, d_refs);
     SVT_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(tf_blocks_kernel, dim3(nb, job->n_refs + 1), dim3(256), 0, st, a, d_refs, job->n_refs, static_blocks, outs);
     SVT_HIP_CHECK(hipGetLastError());

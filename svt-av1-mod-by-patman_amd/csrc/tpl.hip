@@ -218,31 +218,46 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
         const size_t   pu = (size_t)sb * j.stored_pus + me_off;
         const uint8_t *cands = j.me_candidate_array + pu * j.max_cand;
         const uint32_t n_cand = j.i_slice ? 0 : j.total_me_candidate_index[pu];
-        for (uint32_t ci = 0; ci < n_cand; ci++) {
-            const uint32_t cb = cands[ci], dir = cb & 3;
-            if (dir > 1)
-                continue;
-            const uint32_t      ri = dir == 0 ? (cb >> 2) & 3 : (cb >> 4) & 3;
-            const SvtHipTplRef &rf = j.ref[dir][ri];
-            if (!rf.usable)
-                continue;
-            const uint32_t mv = j.me_mv_array[pu * j.max_refs + (dir ? j.max_l0 : 0) + ri];
-            int            mx = (int16_t)((int16_t)(mv & 0xffff) << 3), my = (int16_t)((int16_t)(mv >> 16) << 3);
-            if ((int)x + (mx >> 3) < -TPL_PAD)
-                mx = (int16_t)((-TPL_PAD - (int)x) << 3);
-            if ((int)x + BS + (mx >> 3) > TPL_PAD + (int)rf.max_width - 1)
-                mx = (int16_t)(((TPL_PAD + (int)rf.max_width - 1) - ((int)x + BS)) << 3);
-            if ((int)y + (my >> 3) < -TPL_PAD)
-                my = (int16_t)((-TPL_PAD - (int)y) << 3);
-            if ((int)y + BS + (my >> 3) > TPL_PAD + (int)rf.max_height - 1)
-                my = (int16_t)(((TPL_PAD + (int)rf.max_height - 1) - ((int)y + BS)) << 3);
-            const uint8_t *rp = rf.src + ((ptrdiff_t)y + my / 8 + lr) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + mx / 8 + lc;
-            uint32_t       sad = 0;
+        // the candidates are prepared side by side, one per lane (candidate byte -> reference -> vector -> clip: three dependent
+        // loads that cost a round trip each when taken one candidate after the other); only the SADs run in sequence
+        for (uint32_t base = 0; base < n_cand; base += 64) {
+            const uint32_t ci = base + lane;
+            bool           ok = false;
+            int            mx = 0, my = 0;
+            uint32_t       rfi = 0;
+            if (ci < n_cand) {
+                const uint32_t cb = cands[ci], dir = cb & 3;
+                if (dir <= 1) {  // single-reference candidates only
+                    const uint32_t      ri = dir == 0 ? (cb >> 2) & 3 : (cb >> 4) & 3;
+                    const SvtHipTplRef &rf = j.ref[dir][ri];
+                    if (rf.usable) {
+                        const uint32_t mv = j.me_mv_array[pu * j.max_refs + (dir ? j.max_l0 : 0) + ri];
+                        mx = (int16_t)((int16_t)(mv & 0xffff) << 3), my = (int16_t)((int16_t)(mv >> 16) << 3);
+                        if ((int)x + (mx >> 3) < -TPL_PAD)
+                            mx = (int16_t)((-TPL_PAD - (int)x) << 3);
+                        if ((int)x + BS + (mx >> 3) > TPL_PAD + (int)rf.max_width - 1)
+                            mx = (int16_t)(((TPL_PAD + (int)rf.max_width - 1) - ((int)x + BS)) << 3);
+                        if ((int)y + (my >> 3) < -TPL_PAD)
+                            my = (int16_t)((-TPL_PAD - (int)y) << 3);
+                        if ((int)y + BS + (my >> 3) > TPL_PAD + (int)rf.max_height - 1)
+                            my = (int16_t)(((TPL_PAD + (int)rf.max_height - 1) - ((int)y + BS)) << 3);
+                        ok = true, rfi = dir * 4 + ri;
+                    }
+                }
+            }
+            for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
+                const int           src_lane = __builtin_ctzll(todo);
+                const int           cmx = __shfl(mx, src_lane, 64), cmy = __shfl(my, src_lane, 64);
+                const uint32_t      crf = (uint32_t)__shfl((int)rfi, src_lane, 64);
+                const SvtHipTplRef &rf  = j.ref[crf >> 2][crf & 3];
+                const uint8_t *rp = rf.src + ((ptrdiff_t)y + cmy / 8 + lr) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + cmx / 8 + lc;
+                uint32_t       sad = 0;
 #pragma unroll
-            for (int k = 0; k < NDW; k++) sad = __builtin_amdgcn_sad_u8(spx[k], ld4(rp + 4 * k), sad);
-            const int64_t  cost = wave_sum(sad);
-            if (cost < best_inter)
-                best_inter = cost, best_ref_poc = rf.picture_number, best_rf_idx = (int32_t)(dir * 4 + ri), mv_row = my, mv_col = mx;
+                for (int k = 0; k < NDW; k++) sad = __builtin_amdgcn_sad_u8(spx[k], ld4(rp + 4 * k), sad);
+                const int64_t cost = wave_sum(sad);
+                if (cost < best_inter)
+                    best_inter = cost, best_ref_poc = rf.picture_number, best_rf_idx = (int32_t)crf, mv_row = cmy, mv_col = cmx;
+            }
         }
         if (best_inter < best_intra)
             best_mode = NEWMV_MODE;
