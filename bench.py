@@ -642,12 +642,14 @@ def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
         check(lib, lib.svt_hip_tf_filter_picture(C.byref(job), sp))
     ms = timed_launches(stream, 3, 1, run_tf)
     torch.cuda.synchronize()
+    # (the four calls filter the picture in place one after the other: a fixed sequence, so this sum identifies the results)
+    tf_sum = int(mw.dpyr[c].full.t.to(torch.int64).sum().item())
     mw.dpyr[c].full.t.copy_(luma0)
     P = W * H
     # per reference: centre + reference pyramids through ME, sub-pel windows, prediction written + read, accumulators; once: normalise
     alg = 4 * (1.3125 * 2 * P + 2 * P + 1.5 * P * (1 + 1 + 6 + 6)) + 1.5 * P * (6 + 1 + 1)
     out.append(roof("svt_hip_tf_filter_picture (ME_MCTF + sub-pel + predict + accumulate, 4 refs, luma + chroma)", alg, ms,
-                    unit_of_work="one 4K 8-bit 4:2:0 picture against 4 reference pictures"))
+                    unit_of_work="one 4K 8-bit 4:2:0 picture against 4 reference pictures", result_checksum=tf_sum))
     del ws
     # ---- TPL dispenser
     o = mw.outs[c - mw.lead]

@@ -131,8 +131,9 @@ __device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int bsize, int lx,
         }
         __syncthreads();
     }
-    int64_t  sum = 0;
-    uint64_t sse = 0;
+    // a lane sees at most 16 samples (64 x 64 over 256 lanes) of |difference| < 2^10 (8 / 10-bit): the sums of a whole wave fit 32 bits
+    int32_t  sum = 0;
+    uint32_t sse = 0;
     for (int i = tid; i < rows_out << lb; i += 256) {
         const int ro = i >> lb, c = i & (bsize - 1), r = ro << vshift;
         int32_t   p;
@@ -165,7 +166,7 @@ __device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int bsize, int lx,
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64), sse += __shfl_xor(sse, off, 64);
     __syncthreads();  // the previous position's result has been read by everybody
     if ((tid & 63) == 0)
-        L.red_sum[tid >> 6] = sum, L.red_sse[tid >> 6] = sse;
+        L.red_sum[tid >> 6] = (int64_t)sum, L.red_sse[tid >> 6] = (uint64_t)sse;
     __syncthreads();
     const int64_t  tsum = L.red_sum[0] + L.red_sum[1] + L.red_sum[2] + L.red_sum[3];
     const uint64_t tsse = L.red_sse[0] + L.red_sse[1] + L.red_sse[2] + L.red_sse[3];
