@@ -35,6 +35,7 @@ struct TplArgs {
     const uint8_t    *src0;  // sample (0,0)
     uint8_t          *rec0;
     uint32_t          W, H, a16, rows16;
+    uint32_t          coherent_rows;  // reconstruction rows are 4-byte aligned: blocks are published by write-through stores
     uint32_t         *flags;    // [blocks]
     uint32_t         *error;    // [0]: set when a dependency wait ran into SPIN_LIMIT; [1]: the ticket counter
     int32_t          *scratch;  // [blocks][512]: coeff, dqcoeff
@@ -373,10 +374,23 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
                         j.stats[(size_t)(y / cell + gy) * gstride + x / cell + gx] = st;
         }
     }
-    // publish: every lane's reconstruction stores are complete (the last workgroup fence waited for them, then the barrier),
-    // one agent-scope release makes them visible to other CUs / XCDs, then the flags of the cells this block covers
+    // publish the reconstruction to the other CUs / XCDs, then the flags of the cells this block covers.  An agent-scope release
+    // fence writes back EVERY dirty line of this XCD's L2 (buffer_wbl2): one per block made 68 % of the kernel's time.  Instead
+    // every lane stores its samples of the block once more with agent scope (sc1: written through to the device's coherence
+    // point; the values are the ones already there), waits for those stores, and lane 0 sets the flags.  Needs 4-byte aligned
+    // rows (a.coherent_rows); otherwise the fence.
+    if (a.coherent_rows) {
+#pragma unroll
+        for (int k = 0; k < NDW; k++) {
+            uint32_t *q = (uint32_t *)(o + 4 * k);
+            __hip_atomic_store(q, __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // vmcnt(0): the write-through stores are acknowledged
+        __syncthreads();
+    }
     if (lane == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!a.coherent_rows)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         for (int k = 0; k < (BS / 16) * (BS / 16); k++) {
             const uint32_t fx = cx + (k & (BS / 16 - 1)), fy = cy + k / (BS / 16);
             if (fx < a.a16 && fy < a.rows16)
@@ -487,7 +501,7 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     TplArgs a;
     a.j = *job;
     a.src0 = s.buf + (size_t)s.org_y * s.stride + s.org_x, a.rec0 = r.buf + (size_t)r.org_y * r.stride + r.org_x;
-    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb), a.scratch = (int32_t *)(ws + fb + 256);
+    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.coherent_rows = (r.stride % 4 == 0 && ((uintptr_t)(r.buf + (size_t)r.org_y * r.stride + r.org_x) % 4) == 0) ? 1u : 0u, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb), a.scratch = (int32_t *)(ws + fb + 256);
     if (b32)
         hipLaunchKernelGGL((tpl_kernel<1>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
     else
