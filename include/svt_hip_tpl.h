@@ -88,7 +88,7 @@ typedef struct SvtHipTplFrameJob {
     SvtHipTplSrcStats *src_stats; /* [..][(aligned_width + 15) >> 4] */
     void              *workspace; /* device scratch of svt_hip_tpl_workspace_bytes(): the done-flags of the blocks, one status word
                                    * (first uint32 behind the flags: non-zero if a dependency wait ran into its bound — the
-                                   * results are then unreliable; never observed) and the coefficient arrays of the blocks */
+                                   * results are then unreliable; never observed) */
     uint64_t           workspace_bytes;
 } SvtHipTplFrameJob;
 

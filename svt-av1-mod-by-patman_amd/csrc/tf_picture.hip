@@ -112,14 +112,15 @@ __device__ __forceinline__ uint32_t ldg(const void *p, ptrdiff_t i) {
 
 // distortion of ONE candidate vector from the staged window: prediction (svt_inter_predictor semantics, round_0 = 3,
 // round_1 = 11) against the source, fn_ptr->vf / vf_hbd_10 over every (1 << vshift)-th row.  Returns the same value on every lane.
-__device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int bsize, int lx, int ly, int kernel, int col, int row, int wx0, int wy0,
+template <int bsize>
+__device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int lx, int ly, int kernel, int col, int row, int wx0, int wy0,
                                   int tstep_log2, int vshift) {
     const int tid = threadIdx.x, sx = col & 15, sy = row & 15, bd = s.bd;
     const int px = s.ox + lx + (col >> 4) - wx0, py = s.oy + ly + (row >> 4) - wy0;  // block sample (0,0) in window coordinates
     const int tstep = 1 << tstep_log2, rows_out = bsize >> vshift;
     const int16_t *fx = TF_KERNELS[kernel][sx], *fy = TF_KERNELS[kernel][sy];
     const int      k0 = kernel == K_BILINEAR ? 3 : 0, k1 = kernel == K_BILINEAR ? 5 : 8;  // the other bilinear taps are zero
-    const int      lb = 31 - __clz(bsize);
+    constexpr int  lb = bsize == 64 ? 6 : (bsize == 32 ? 5 : 4);  // compile-time block size: index arithmetic and trip counts fold
     if (sx && sy) {  // svt_av1_[highbd_]convolve_2d_sr_c: horizontal pass over rows -3*tstep .. bsize-1 + 4*tstep
         const int im_rows = bsize + 7 * tstep;
         for (int i = tid; i < im_rows << lb; i += 256) {
@@ -185,8 +186,8 @@ __device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int bsize, int lx,
 }
 
 // tf_subpel_search of one square block; best / bx / by are uniform over the workgroup
-template <bool S16>
-__device__ void subpel_search(Lds &L, const SearchCtx &s, int bsize, int lx, int ly, int kernel, uint64_t &best, int &bx, int &by) {
+template <bool S16, int bsize>
+__device__ void subpel_search(Lds &L, const SearchCtx &s, int lx, int ly, int kernel, uint64_t &best, int &bx, int &by) {
     const SvtHipTfCtrls &c = s.a->ctrls;
     const int tid = threadIdx.x;
     // window around the (clamped) starting vector
@@ -223,7 +224,7 @@ __device__ void subpel_search(Lds &L, const SearchCtx &s, int bsize, int lx, int
                 int       col, row;
                 clamp_mv(s.a->mi_rows, s.a->mi_cols, bsize, bsize, mvx, mvy, 0, s.ox + lx, s.oy + ly, bsize, col, row);
                 const int      tl = (xd == 0 && yd == 0) ? c.sub_sampling_shift : 0;
-                const uint64_t d  = eval_position(L, s, bsize, lx, ly, kernel, col, row, wx0, wy0, tl, c.sub_sampling_shift);
+                const uint64_t d  = eval_position<bsize>(L, s, lx, ly, kernel, col, row, wx0, wy0, tl, c.sub_sampling_shift);
                 if (d < best)
                     best = d, bx = mvx, by = mvy;
             }
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
     uint64_t err64 = 0x7fffffff;
     int      mv64x = (int16_t)((use64_th == 255 ? sr.hme_sc_x : mvx_of(best_mv[0])) << 3);
     int      mv64y = (int16_t)((use64_th == 255 ? sr.hme_sc_y : mvy_of(best_mv[0])) << 3);
-    subpel_search<S16>(L, s, 64, 0, 0, k6432, err64, mv64x, mv64y);
+    subpel_search<S16, 64>(L, s, 0, 0, k6432, err64, mv64x, mv64y);
     bool use64 = false;
     if (use64_th) {
         if (use64_th == 255) {
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
         for (int i = 0; i < 4; i++) {
             err32[i] = 0x7fffffff;
             mv32x[i] = (int16_t)(mvx_of(best_mv[1 + i]) << 3), mv32y[i] = (int16_t)(mvy_of(best_mv[1 + i]) << 3);
-            subpel_search<S16>(L, s, 32, (i & 1) * 32, (i >> 1) * 32, k6432, err32[i], mv32x[i], mv32y[i]);
+            subpel_search<S16, 32>(L, s, (i & 1) * 32, (i >> 1) * 32, k6432, err32[i], mv32x[i], mv32y[i]);
             sum32 += err32[i];
         }
         if (err64 * 14 < sum32 * 16 && err64 < (1u << 18))
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
                 const int q  = i * 4 + k;
                 uint64_t  e  = 0x7fffffff;
                 int       mx = (int16_t)(mvx_of(best_mv[5 + q]) << 3), my = (int16_t)(mvy_of(best_mv[5 + q]) << 3);
-                subpel_search<S16>(L, s, 16, lx + (k & 1) * 16, ly + (k >> 1) * 16, K_REGULAR, e, mx, my);
+                subpel_search<S16, 16>(L, s, lx + (k & 1) * 16, ly + (k >> 1) * 16, K_REGULAR, e, mx, my);
                 sum16 += (int)e;
                 if (tid == 0)
                     st.err16[q] = e, st.mv16_x[q] = (int16_t)mx, st.mv16_y[q] = (int16_t)my;

@@ -38,7 +38,6 @@ struct TplArgs {
     uint32_t          coherent_rows;  // reconstruction rows are 4-byte aligned: blocks are published by write-through stores
     uint32_t         *flags;    // [blocks]
     uint32_t         *error;    // [0]: set when a dependency wait ran into SPIN_LIMIT; [1]: the ticket counter
-    int32_t          *scratch;  // [blocks][512]: coeff, dqcoeff
 };
 
 __device__ __forceinline__ uint32_t ld8(const uint8_t *p) { return *(const __attribute__((address_space(1))) uint8_t *)p; }
@@ -138,16 +137,15 @@ __device__ uint32_t dc_value(const uint8_t *pic0, uint32_t stride, uint32_t x, u
 // (prediction and reconstruction may be the same samples).  *nonzero = the block has a non-zero quantised coefficient (eob != 0).
 template <int BS, int SUB>
 __device__ int64_t quantize_error(const TplArgs &a, const uint8_t *src, uint32_t src_stride, const uint8_t *pred, uint32_t pred_stride,
-                                  uint8_t *recon, uint32_t recon_stride, bool inv, int32_t *scratch, int32_t *lds_tile, bool *nonzero) {
-    constexpr int  TH = BS >> SUB, N = BS * TH;
-    static_assert(N <= 256 && N % 64 == 0, "the coefficient scratch of a block holds 2 x 256 values");
+                                  uint8_t *recon, uint32_t recon_stride, bool inv, int32_t *lds_tile, bool *nonzero) {
+    constexpr int  TH = BS >> SUB;
     const int      lane = threadIdx.x;
     SvtHipTxfmDesc d;
     memset(&d, 0, sizeof(d));
     d.residual_off = (uint64_t)(uintptr_t)src, d.residual_stride = src_stride << SUB;
     d.pred_off = (uint64_t)(uintptr_t)pred, d.pred_stride = pred_stride << SUB;
     d.recon_off = (uint64_t)(uintptr_t)recon, d.recon_stride = recon_stride << SUB;
-    d.coeff_off = (uint64_t)(uintptr_t)scratch, d.dqcoeff_off = (uint64_t)(uintptr_t)(scratch + 256);
+    d.coeff_off = d.dqcoeff_off = SVT_HIP_NO_OFFSET;  // the block error comes out of the transform block itself (BLKERR)
     d.qcoeff_off = SVT_HIP_NO_OFFSET, d.qm_off = d.iqm_off = SVT_HIP_NO_OFFSET;
     d.iscan_off = (uint64_t)(uintptr_t)TPL_ISCAN;
     for (int i = 0; i < 2; i++) d.round[i] = a.j.round_fp[i], d.quant[i] = a.j.quant_fp[i], d.dequant[i] = a.j.dequant[i];
@@ -155,21 +153,16 @@ __device__ int64_t quantize_error(const TplArgs &a, const uint8_t *src, uint32_t
     d.flags = (uint8_t)(SVT_HIP_TX_FWD | SVT_HIP_TX_SRC_PRED | (inv ? SVT_HIP_TX_INV : 0));
     SvtHipTxfmResult res;
     memset(&res, 0, sizeof(res));
-    txfm_block<BS, TH>((uint8_t *)nullptr, d, &res, lane < BS, lane & (BS - 1), lds_tile + (lane / BS) * (TH * (BS + 1)));
+    txfm_block<BS, TH, true>((uint8_t *)nullptr, d, &res, lane < BS, lane & (BS - 1), lds_tile + (lane / BS) * (TH * (BS + 1)));
     *nonzero = __shfl((int)res.eob, 0, 64) != 0;  // lane 0 holds the block's result (the all-zero scan table makes eob 0 / 1)
-    // the coefficient arrays were written by this wave: a workgroup-scope fence (wait for the stores, same CU) makes them
-    // readable by its other lanes — no agent-scope cache write-back / invalidate here
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __syncthreads();
-    int64_t err = 0;
-#pragma unroll
-    for (int k = 0; k < N / 64; k++) {
-        const int     i = lane + 64 * k;
-        const int64_t e = (int64_t)__hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
-            (int64_t)__hip_atomic_load(scratch + 256 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        err += e * e;
+    const uint64_t e2 = ((uint64_t)(uint32_t)__shfl((int)(res.three_quad_energy >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)res.three_quad_energy, 0, 64);
+    if (inv) {
+        // the reconstruction was stored by the lanes of the transform block: a workgroup-scope fence (wait for the stores, same
+        // CU) makes it readable by this wave's other lanes — no agent-scope cache write-back / invalidate here
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
     }
-    err = wave_sum64(err) >> 2;
+    const int64_t err = (int64_t)(e2 >> 2);
     return err > 1 ? err : 1;
 }
 
@@ -189,7 +182,6 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
     const uint32_t ss = j.src.stride, rs = j.recon.stride;
     const uint8_t *src = a.src0 + (size_t)y * ss + x;
     uint8_t       *dst = a.rec0 + (size_t)y * rs + x;
-    int32_t       *scratch = a.scratch + (size_t)cell0 * 512;
     SvtHipTplSrcStats *sst = &j.src_stats[cell0];
     const int      lr = lane / LPR, lc = (lane % LPR) * 4 * NDW;  // this lane's samples: row lr, columns lc .. lc + 4 NDW - 1
     uint32_t       spx[NDW];
@@ -265,7 +257,7 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
         if (best_mode == NEWMV_MODE) {
             const SvtHipTplRef &rf = j.ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
             const uint8_t      *rp = rf.src + ((ptrdiff_t)y + (mv_row >> 3)) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + (mv_col >> 3);
-            srcrf_dist = (quantize_error<BS, SUB>(a, src, ss, rp, rf.src_stride, nullptr, 0, false, scratch, tile, &nonzero) << 4) << SUB;
+            srcrf_dist = (quantize_error<BS, SUB>(a, src, ss, rp, rf.src_stride, nullptr, 0, false, tile, &nonzero) << 4) << SUB;
         }
         if (j.store_src_stats && lane == 0) {
             SvtHipTplSrcStats s;
@@ -322,7 +314,7 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the prediction (this wave's stores) is in memory before the transform block reads it back
     __syncthreads();
     const bool inv = !j.disable_intra_pred || j.is_ref;
-    recon_error = quantize_error<BS, SUB>(a, src, ss, dst, rs, dst, rs, inv, scratch, tile, &nonzero);  // (its fence also publishes the reconstruction)
+    recon_error = quantize_error<BS, SUB>(a, src, ss, dst, rs, dst, rs, inv, tile, &nonzero);  // (its fence also publishes the reconstruction)
     if (SUB && inv && nonzero) {
         // the rows the sub-sampled transform left out repeat the reconstructed row above them (:1162-1180; only when the block has
         // coefficients: otherwise every row keeps its prediction).  Row (lr & ~mask) was stored by other lanes of this wave: the
@@ -501,7 +493,7 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     TplArgs a;
     a.j = *job;
     a.src0 = s.buf + (size_t)s.org_y * s.stride + s.org_x, a.rec0 = r.buf + (size_t)r.org_y * r.stride + r.org_x;
-    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.coherent_rows = (r.stride % 4 == 0 && ((uintptr_t)(r.buf + (size_t)r.org_y * r.stride + r.org_x) % 4) == 0) ? 1u : 0u, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb), a.scratch = (int32_t *)(ws + fb + 256);
+    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.coherent_rows = (r.stride % 4 == 0 && ((uintptr_t)(r.buf + (size_t)r.org_y * r.stride + r.org_x) % 4) == 0) ? 1u : 0u, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb);
     if (b32)
         hipLaunchKernelGGL((tpl_kernel<1>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
     else
@@ -511,7 +503,6 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
 }
 
 extern "C" uint64_t svt_hip_tpl_workspace_bytes(uint32_t width, uint32_t height) {
-    const uint32_t aw = (width + 7) & ~7u, ah = (height + 7) & ~7u;
-    return flag_bytes(width, height) + 256 + (uint64_t)((aw + 15) >> 4) * ((ah + 15) >> 4) * 512 * sizeof(int32_t);
+    return flag_bytes(width, height) + 256;
 }
 extern "C" uint64_t svt_hip_tpl_status_offset(uint32_t width, uint32_t height) { return flag_bytes(width, height); }

@@ -230,9 +230,13 @@ __device__ __forceinline__ void coop_store_tile(const int32_t *__restrict__ lds,
 // One transform block: `d` its descriptor, `result` where its SvtHipTxfmResult goes, `live` false for a lane group without a
 // block (it still takes part in the barriers), t = lane index inside the group (0 .. L-1), lds = the group's H x (W+1) int32 tile.
 // Every lane of the workgroup must call this (it contains __syncthreads).
-template <int W, int H>
+// BLKERR (the TPL dispenser's get_quantize_error, src_ops_process.c:225-249; sizes without a 64-point side): result->three_quad_energy
+// = svt_av1_block_error = sum of (coeff - dqcoeff)^2 over the block, taken in the quantiser loop where both values are in registers, so
+// that neither array has to be stored and read back (coeff_off / dqcoeff_off may be SVT_HIP_NO_OFFSET).
+template <int W, int H, bool BLKERR = false>
 __device__ __forceinline__ void txfm_block(uint8_t *__restrict__ base, const SvtHipTxfmDesc &d, SvtHipTxfmResult *__restrict__ result,
                                            const bool live, const int t, int32_t *__restrict__ lds) {
+    static_assert(!BLKERR || (W != 64 && H != 64), "three_quad_energy is the 64-point energy for those sizes");
     using G = Geo<W, H>;
     constexpr int L = G::L, PW = G::PW, IW = G::IW, IH = G::IH;
     const int vk = VTX_D[d.tx_type & 15], hk = HTX_D[d.tx_type & 15];
@@ -386,6 +390,10 @@ __device__ __forceinline__ void txfm_block(uint8_t *__restrict__ base, const Svt
                 const uint32_t pos = qc ? ((iscv[c / 2] >> (16 * (c & 1))) & 0xffffu) + 1u : 0u;
                 eob                = pos > eob ? pos : eob;
                 lds[t * PW + c] = qc;  // staged for the coalesced store below
+                if constexpr (BLKERR) {
+                    const int64_t e = (int64_t)row[c] - (int64_t)dqc;
+                    energy += (uint64_t)(e * e);
+                }
                 row[c]          = dqc;
             }
         } else if (do_inv && !do_fwd) {
@@ -395,6 +403,8 @@ __device__ __forceinline__ void txfm_block(uint8_t *__restrict__ base, const Svt
         }
     }
     eob = group_max<L>(eob);
+    if constexpr (BLKERR)
+        energy = group_sum64<L>(energy);
     {   // qcoeff / dqcoeff leave through LDS so that the stores are line-coalesced (all L lanes of the block take part)
         const bool quant = live && d.quant_mode != SVT_HIP_QUANT_NONE;
         __syncthreads();

@@ -99,8 +99,9 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
     const size_t   n_mv = (size_t)nb * stored * med->max_refs * 4, n_cand = (size_t)nb * stored * med->max_cand, n_cnt = (size_t)nb * stored;
     const size_t   n_stats = (size_t)a16 * rows16 * sizeof(SvtHipTplStats), n_sst = (size_t)a16 * rows16 * sizeof(SvtHipTplSrcStats);
     const uint64_t wsb = g_api.ws_bytes(W, H);
-    size_t         need = al256(luma_bytes(src) + 64) + al256(luma_bytes(recon) + 64) + al256(n_mv) + al256(n_cand) + al256(n_cnt) + al256(n_stats) +
-        al256(n_sst) + al256(wsb);
+    /* every uploaded array takes al256(bytes + 64) (PUT below); the statistics grid and the workspace al256(bytes) */
+    size_t         need = al256(luma_bytes(src) + 64) + al256(luma_bytes(recon) + 64) + al256(n_mv + 64) + al256(n_cand + 64) + al256(n_cnt + 64) +
+        al256(n_stats) + al256(n_sst + 64) + al256(wsb);
     EbPictureBufferDesc *rsrc[2][4] = {{0}}, *rrec[2][4] = {{0}};
     for (int l = 0; l < 2; l++)
         for (int r = 0; r < 4; r++) {
