@@ -112,22 +112,30 @@ __device__ __forceinline__ uint32_t ldg(const void *p, ptrdiff_t i) {
 
 // distortion of ONE candidate vector from the staged window: prediction (svt_inter_predictor semantics, round_0 = 3,
 // round_1 = 11) against the source, fn_ptr->vf / vf_hbd_10 over every (1 << vshift)-th row.  Returns the same value on every lane.
-template <int bsize>
-__device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int lx, int ly, int kernel, int col, int row, int wx0, int wy0,
-                                  int tstep_log2, int vshift) {
+template <int bsize, int NT>
+__device__ uint64_t eval_position_t(Lds &L, const SearchCtx &s, int lx, int ly, int kernel, int col, int row, int wx0, int wy0,
+                                    int tstep_log2, int vshift) {
+    constexpr int K0 = NT == 2 ? 3 : 0;  // the taps that can be non-zero: 3, 4 of the bilinear kernel, all 8 otherwise
     const int tid = threadIdx.x, sx = col & 15, sy = row & 15, bd = s.bd;
     const int px = s.ox + lx + (col >> 4) - wx0, py = s.oy + ly + (row >> 4) - wy0;  // block sample (0,0) in window coordinates
     const int tstep = 1 << tstep_log2, rows_out = bsize >> vshift;
-    const int16_t *fx = TF_KERNELS[kernel][sx], *fy = TF_KERNELS[kernel][sy];
-    const int      k0 = kernel == K_BILINEAR ? 3 : 0, k1 = kernel == K_BILINEAR ? 5 : 8;  // the other bilinear taps are zero
+    // the taps are uniform: read them once into scalar registers (a tap loop with a run-time range re-read the table from global
+    // memory for every tap of every sample and waited for it)
+    int32_t fx[NT], fy[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        fx[k] = __builtin_amdgcn_readfirstlane((int)TF_KERNELS[kernel][sx][K0 + k]);
+        fy[k] = __builtin_amdgcn_readfirstlane((int)TF_KERNELS[kernel][sy][K0 + k]);
+    }
     constexpr int  lb = bsize == 64 ? 6 : (bsize == 32 ? 5 : 4);  // compile-time block size: index arithmetic and trip counts fold
     if (sx && sy) {  // svt_av1_[highbd_]convolve_2d_sr_c: horizontal pass over rows -3*tstep .. bsize-1 + 4*tstep
         const int im_rows = bsize + 7 * tstep;
         for (int i = tid; i < im_rows << lb; i += 256) {
             const int r = i >> lb, c = i & (bsize - 1);
             int32_t   sum = 1 << (bd + 7 - 1);
-            const uint16_t *w = &L.win[(py + r - 3 * tstep) * WP + px + c - 3];
-            for (int k = k0; k < k1; k++) sum += fx[k] * (int32_t)w[k];
+            const uint16_t *w = &L.win[(py + r - 3 * tstep) * WP + px + c - 3 + K0];
+#pragma unroll
+            for (int k = 0; k < NT; k++) sum += fx[k] * (int32_t)w[k];
             L.im[(r << lb) + c] = (int16_t)(uint16_t)rnd(sum, 3);
         }
         __syncthreads();
@@ -141,19 +149,22 @@ __device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int lx, int ly, in
         if (sx && sy) {
             const int offset_bits = bd + 2 * 7 - 3;
             int32_t   v = 1 << offset_bits;
-            for (int k = k0; k < k1; k++) v += fy[k] * (int32_t)L.im[((r + k * tstep) << lb) + c];
+#pragma unroll
+            for (int k = 0; k < NT; k++) v += fy[k] * (int32_t)L.im[((r + (K0 + k) * tstep) << lb) + c];
             int32_t res = rnd(v, 11) - ((1 << (offset_bits - 11)) + (1 << (offset_bits - 11 - 1)));
             if (!s.is16)
                 res = (int16_t)res;
             p = res;
         } else if (sx) {  // x_sr
             int32_t v = 0;
-            const uint16_t *w = &L.win[(py + r) * WP + px + c - 3];
-            for (int k = k0; k < k1; k++) v += fx[k] * (int32_t)w[k];
+            const uint16_t *w = &L.win[(py + r) * WP + px + c - 3 + K0];
+#pragma unroll
+            for (int k = 0; k < NT; k++) v += fx[k] * (int32_t)w[k];
             p = rnd(rnd(v, 3), 4);
         } else if (sy) {  // y_sr
             int32_t v = 0;
-            for (int k = k0; k < k1; k++) v += fy[k] * (int32_t)L.win[(py + r + (k - 3) * tstep) * WP + px + c];
+#pragma unroll
+            for (int k = 0; k < NT; k++) v += fy[k] * (int32_t)L.win[(py + r + (K0 + k - 3) * tstep) * WP + px + c];
             p = rnd(v, 7);
         } else {
             p = L.win[(py + r) * WP + px + c];
@@ -183,6 +194,13 @@ __device__ uint64_t eval_position(Lds &L, const SearchCtx &s, int lx, int ly, in
         var = v >= 0 ? (uint32_t)v : 0;
     }
     return var << vshift;
+}
+
+template <int bsize>
+__device__ __forceinline__ uint64_t eval_position(Lds &L, const SearchCtx &s, int lx, int ly, int kernel, int col, int row, int wx0, int wy0,
+                                                  int tstep_log2, int vshift) {
+    return kernel == K_BILINEAR ? eval_position_t<bsize, 2>(L, s, lx, ly, kernel, col, row, wx0, wy0, tstep_log2, vshift)
+                                : eval_position_t<bsize, 8>(L, s, lx, ly, kernel, col, row, wx0, wy0, tstep_log2, vshift);
 }
 
 // tf_subpel_search of one square block; best / bx / by are uniform over the workgroup
