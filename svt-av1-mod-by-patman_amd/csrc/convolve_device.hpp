@@ -52,6 +52,15 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
     const int tw = min(T, d.w - x0), th = min(T, d.h - y0);
     const int tx = d.taps_x, ty = d.taps_y, is16 = d.is_16bit, bd = d.bit_depth, r0 = d.round_0, r1 = d.round_1;
     const int fo_h = tx ? tx / 2 - 1 : 0, fo_v = ty ? ty / 2 - 1 : 0;
+    // the taps are uniform: once into scalar registers, padded with zeros to eight so that the tap loops unroll (indexing the
+    // descriptor's arrays with a run-time tap counter put them in scratch memory: a memory access per tap and sample); the samples
+    // a zero tap multiplies lie inside the LDS buffers (rows of T + 8, T + 7 rows)
+    int32_t fx[8], fy[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        fx[k] = __builtin_amdgcn_readfirstlane(k < tx ? (int)d.filter_x[k] : 0);
+        fy[k] = __builtin_amdgcn_readfirstlane(k < ty ? (int)d.filter_y[k] : 0);
+    }
     const int ew = tw + (tx ? tx - 1 : 0), eh = th + (ty ? ty - 1 : 0);  // staged extent
     for (int idx = threadIdx.x; idx < eh * ew; idx += NT) {
         const int r = idx / ew, c = idx - r * ew;
@@ -65,7 +74,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
             for (int idx = threadIdx.x; idx < eh * tw; idx += NT) {
                 const int r = idx / tw, c = idx - r * tw;
                 int32_t   sum = 1 << (bd + FILTER_BITS - 1);
-                for (int k = 0; k < tx; k++) sum += d.filter_x[k] * (int32_t)in[r * P + c + k];
+                _Pragma("unroll") for (int k = 0; k < 8; k++) sum += fx[k] * (int32_t)in[r * P + c + k];
                 im[r * T + c] = (int16_t)(uint16_t)rnd(sum, r0);
             }
             __syncthreads();
@@ -75,16 +84,16 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
             int32_t   res;
             if (tx && ty) {
                 int32_t sum = 1 << offset_bits;
-                for (int k = 0; k < ty; k++) sum += d.filter_y[k] * (int32_t)im[(r + k) * T + c];
+                _Pragma("unroll") for (int k = 0; k < 8; k++) sum += fy[k] * (int32_t)im[(r + k) * T + c];
                 res = (uint16_t)rnd(sum, r1);
             } else if (ty) {
                 res = 0;
-                for (int k = 0; k < ty; k++) res += d.filter_y[k] * (int32_t)in[(r + k) * P + c];
+                _Pragma("unroll") for (int k = 0; k < 8; k++) res += fy[k] * (int32_t)in[(r + k) * P + c];
                 res *= 1 << (FILTER_BITS - r0);
                 res = rnd(res, r1) + round_offset;
             } else if (tx) {
                 res = 0;
-                for (int k = 0; k < tx; k++) res += d.filter_x[k] * (int32_t)in[r * P + c + k];
+                _Pragma("unroll") for (int k = 0; k < 8; k++) res += fx[k] * (int32_t)in[r * P + c + k];
                 res = (1 << (FILTER_BITS - r1)) * rnd(res, r0) + round_offset;
             } else {
                 res = (uint16_t)((uint16_t)((int32_t)in[r * P + c] << round_bits) + (uint16_t)round_offset);
@@ -105,7 +114,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
         for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
             const int r = idx / tw, c = idx - r * tw;
             int32_t   res = 0;
-            for (int k = 0; k < tx; k++) res += d.filter_x[k] * (int32_t)in[r * P + c + k];
+            _Pragma("unroll") for (int k = 0; k < 8; k++) res += fx[k] * (int32_t)in[r * P + c + k];
             stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(rnd(res, r0), bits), bd);
         }
         return;
@@ -114,7 +123,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
         for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
             const int r = idx / tw, c = idx - r * tw;
             int32_t   res = 0;
-            for (int k = 0; k < ty; k++) res += d.filter_y[k] * (int32_t)in[(r + k) * P + c];
+            _Pragma("unroll") for (int k = 0; k < 8; k++) res += fy[k] * (int32_t)in[(r + k) * P + c];
             stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(res, FILTER_BITS), bd);
         }
         return;
@@ -123,7 +132,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
     for (int idx = threadIdx.x; idx < eh * tw; idx += NT) {
         const int r = idx / tw, c = idx - r * tw;
         int32_t   sum = 1 << (bd + FILTER_BITS - 1);
-        for (int k = 0; k < tx; k++) sum += d.filter_x[k] * (int32_t)in[r * P + c + k];
+        _Pragma("unroll") for (int k = 0; k < 8; k++) sum += fx[k] * (int32_t)in[r * P + c + k];
         im[r * T + c] = (int16_t)(uint16_t)rnd(sum, r0);
     }
     __syncthreads();
@@ -131,7 +140,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
     for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
         const int r = idx / tw, c = idx - r * tw;
         int32_t   sum = 1 << offset_bits;
-        for (int k = 0; k < ty; k++) sum += d.filter_y[k] * (int32_t)im[(r + k) * T + c];
+        _Pragma("unroll") for (int k = 0; k < 8; k++) sum += fy[k] * (int32_t)im[(r + k) * T + c];
         int32_t res = rnd(sum, r1) - ((1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1)));
         if (!is16)
             res = (int16_t)res;  // the 8-bit function narrows to int16 first (inter_prediction.c:343-345)
