@@ -128,50 +128,54 @@ __device__ uint64_t eval_position_t(Lds &L, const SearchCtx &s, int lx, int ly, 
         fy[k] = __builtin_amdgcn_readfirstlane((int)TF_KERNELS[kernel][sy][K0 + k]);
     }
     constexpr int  lb = bsize == 64 ? 6 : (bsize == 32 ? 5 : 4);  // compile-time block size: index arithmetic and trip counts fold
+    // a thread owns column c and every RS-th row from r0: all LDS offsets advance by constants (no multiply per sample and tap)
+    constexpr int  RS = 256 >> lb;
+    const int      c = tid & (bsize - 1), r0 = tid >> lb;
     if (sx && sy) {  // svt_av1_[highbd_]convolve_2d_sr_c: horizontal pass over rows -3*tstep .. bsize-1 + 4*tstep
         const int im_rows = bsize + 7 * tstep;
-        for (int i = tid; i < im_rows << lb; i += 256) {
-            const int r = i >> lb, c = i & (bsize - 1);
-            int32_t   sum = 1 << (bd + 7 - 1);
-            const uint16_t *w = &L.win[(py + r - 3 * tstep) * WP + px + c - 3 + K0];
+        int       woff = (py + r0 - 3 * tstep) * WP + px + c - 3 + K0, ioff = (r0 << lb) + c;
+        for (int r = r0; r < im_rows; r += RS, woff += RS * WP, ioff += RS << lb) {
+            int32_t acc = 1 << (bd + 7 - 1);
 #pragma unroll
-            for (int k = 0; k < NT; k++) sum += fx[k] * (int32_t)w[k];
-            L.im[(r << lb) + c] = (int16_t)(uint16_t)rnd(sum, 3);
+            for (int k = 0; k < NT; k++) acc += fx[k] * (int32_t)L.win[woff + k];
+            L.im[ioff] = (int16_t)(uint16_t)rnd(acc, 3);
         }
         __syncthreads();
     }
     // a lane sees at most 16 samples (64 x 64 over 256 lanes) of |difference| < 2^10 (8 / 10-bit): the sums of a whole wave fit 32 bits
-    int32_t  sum = 0;
-    uint32_t sse = 0;
-    for (int i = tid; i < rows_out << lb; i += 256) {
-        const int ro = i >> lb, c = i & (bsize - 1), r = ro << vshift;
-        int32_t   p;
+    int32_t   sum = 0;
+    uint32_t  sse = 0;
+    const int rstep = RS << vshift, istep = tstep << lb, wstep = tstep * WP;  // rows per iteration; tap steps in `im` / the window
+    int       ioff = ((r0 << vshift) << lb) + c + K0 * istep;                    // first tap of the 2-D vertical pass
+    int       woff = (py + (r0 << vshift)) * WP + px + c;                          // block sample (c, r) in the window
+    int       soff = (ly + (r0 << vshift)) * 64 + lx + c;
+    for (int ro = r0; ro < rows_out; ro += RS, ioff += rstep << lb, woff += rstep * WP, soff += rstep * 64) {
+        int32_t p;
         if (sx && sy) {
             const int offset_bits = bd + 2 * 7 - 3;
             int32_t   v = 1 << offset_bits;
 #pragma unroll
-            for (int k = 0; k < NT; k++) v += fy[k] * (int32_t)L.im[((r + (K0 + k) * tstep) << lb) + c];
+            for (int k = 0; k < NT; k++) v += fy[k] * (int32_t)L.im[ioff + k * istep];
             int32_t res = rnd(v, 11) - ((1 << (offset_bits - 11)) + (1 << (offset_bits - 11 - 1)));
             if (!s.is16)
                 res = (int16_t)res;
             p = res;
         } else if (sx) {  // x_sr
             int32_t v = 0;
-            const uint16_t *w = &L.win[(py + r) * WP + px + c - 3 + K0];
 #pragma unroll
-            for (int k = 0; k < NT; k++) v += fx[k] * (int32_t)w[k];
+            for (int k = 0; k < NT; k++) v += fx[k] * (int32_t)L.win[woff - 3 + K0 + k];
             p = rnd(rnd(v, 3), 4);
         } else if (sy) {  // y_sr
             int32_t v = 0;
 #pragma unroll
-            for (int k = 0; k < NT; k++) v += fy[k] * (int32_t)L.win[(py + r + (K0 + k - 3) * tstep) * WP + px + c];
+            for (int k = 0; k < NT; k++) v += fy[k] * (int32_t)L.win[woff + (K0 + k - 3) * wstep];
             p = rnd(v, 7);
         } else {
-            p = L.win[(py + r) * WP + px + c];
+            p = L.win[woff];
         }
         const int32_t hi = (1 << bd) - 1;
         p = (sx || sy) ? (p < 0 ? 0 : (p > hi ? hi : p)) : p;
-        const int32_t d = p - (int32_t)L.src[(ly + r) * 64 + lx + c];
+        const int32_t d = p - (int32_t)L.src[soff];
         sum += d, sse += (uint32_t)(d * d);
     }
 #pragma unroll
