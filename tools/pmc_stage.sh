@@ -1,19 +1,19 @@
 #!/bin/bash
 # Instruction counters of the temporal-filter / TPL kernels inside the headline bench (its roofline_all legs):
-#   bash tools/pmc_stage.sh -> gpurun_out/r2/pmc_stage.json
+#   [PMC_STAGE_REGEX='cdef_|sgr_|dlf_|wiener_'] bash tools/pmc_stage.sh -> gpurun_out/r2/pmc_stage.json
 REPO=$PWD
 mkdir -p $REPO/gpurun_out/r2
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcst
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-include-regex "tf_|tpl_" --kernel-trace --output-format csv -d /tmp/pmcst -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-pmc --no-cpu-baseline > $REPO/gpurun_out/r2/pmcst_run.log 2>&1 || { echo "pass failed"; tail -5 /tmp/pmcst.log; }
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-include-regex "${PMC_STAGE_REGEX:-tf_|tpl_}" --kernel-trace --output-format csv -d /tmp/pmcst -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-pmc --no-cpu-baseline > $REPO/gpurun_out/r2/pmcst_run.log 2>&1 || { echo "pass failed"; tail -5 /tmp/pmcst.log; }
 python3 - "$REPO/gpurun_out/r2/pmc_stage.json" <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
 acc, disp, dur = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(set)), defaultdict(list)
 def key(k):
-    for n in ("tf_refine_kernel", "tf_predict_kernel", "tf_blocks_kernel", "tf_accumulate_kernel", "tpl_kernel", "me_b64_kernel"):
-        if n in k: return n
-    return None
+    import re
+    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", k)
+    return m.group(1) if m else None
 for f in glob.glob("/tmp/pmcst/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = key(r["Kernel_Name"])
