@@ -691,7 +691,13 @@ def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
     ms = timed_launches(stream, 5, 2, run_tpl)
     nblk = a16 * rows16
     out.append(roof("tpl_kernel (svt_hip_tpl_dispenser_frame, 16x16 blocks, 3+2 references)", nblk * (256 * (1 + 5) + 2 * 256 + 64 + 40), ms,
-                    unit_of_work=f"one 4K picture, {nblk} blocks"))
+                    unit_of_work=f"one 4K picture, {nblk} blocks", result_checksum=int(stats.to(torch.int64).sum().item())))
+    # tpl level 5 (presets M10 and faster): 32x32 blocks in complete 64x64 blocks, transform on every 4th row, 32x32 synthesizer grid
+    tj.blk_size, tj.subsample_tx, tj.synth_blk_size = 32, 2, 32
+    stats.zero_()
+    ms5 = timed_launches(stream, 5, 2, run_tpl)
+    out.append(roof("tpl_kernel level 5 (32x32 / 16x16 blocks, TX_32X8 / TX_16X4 on every 4th row)", nblk * (256 * (1 + 5) + 2 * 256) + (nblk // 4) * (64 + 40), ms5,
+                    unit_of_work="one 4K picture", result_checksum=int(stats.to(torch.int64).sum().item())))
     return out
 
 
