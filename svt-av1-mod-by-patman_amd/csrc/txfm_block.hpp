@@ -158,15 +158,20 @@ __device__ __forceinline__ void quant_small(const QP &q, int32_t c, int ac, int3
     dqc               = (adq ^ sign) - sign;
 }
 
+// largest magnitude of N values: running signed maximum and minimum, two values per v_max3 / v_min3 (N instructions instead of the
+// 3 N of |v| then max); hi >= 0 >= lo, so max(hi, -lo) is it (as unsigned: -INT_MIN is 2^31)
 template <int N>
 __device__ __forceinline__ uint32_t max_abs(const int32_t *v) {
-    uint32_t m = 0;
+    int32_t hi = 0, lo = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        const uint32_t a = v[i] < 0 ? 0u - (uint32_t)v[i] : (uint32_t)v[i];
-        m                = a > m ? a : m;
+    for (int i = 0; i + 1 < N; i += 2) {
+        hi = max(max(v[i], v[i + 1]), hi);
+        lo = min(min(v[i], v[i + 1]), lo);
     }
-    return m;
+    if (N & 1)
+        hi = max(v[N - 1], hi), lo = min(v[N - 1], lo);
+    const uint32_t a = (uint32_t)hi, b = 0u - (uint32_t)lo;
+    return a > b ? a : b;
 }
 template <int L>
 __device__ __forceinline__ uint32_t group_max(uint32_t v) {
