@@ -15,6 +15,7 @@
 //     and the wait is bounded;
 //   then residual -> transform -> quantise -> error -> inverse + reconstruction by the same transform block, TplStats.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/svt_hip_tpl.h"
@@ -493,7 +494,7 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     TplArgs a;
     a.j = *job;
     a.src0 = s.buf + (size_t)s.org_y * s.stride + s.org_x, a.rec0 = r.buf + (size_t)r.org_y * r.stride + r.org_x;
-    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.coherent_rows = (r.stride % 4 == 0 && ((uintptr_t)(r.buf + (size_t)r.org_y * r.stride + r.org_x) % 4) == 0) ? 1u : 0u, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb);
+    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.coherent_rows = (r.stride % 4 == 0 && ((uintptr_t)(r.buf + (size_t)r.org_y * r.stride + r.org_x) % 4) == 0 && !getenv("SVTAV1_HIP_TPL_FENCE")) ? 1u : 0u,  /* (the variable forces the fence path: tests) */ a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb);
     if (b32)
         hipLaunchKernelGGL((tpl_kernel<1>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
     else

@@ -107,6 +107,18 @@ def test_level5_all_intra_and_inter_1080p(hip, orc):
             assert (a.src_stats["best_mode"] == 16).any() and (a.src_stats["best_mode"] == 0).any()
 
 
+def test_fence_publish_path(hip, orc, monkeypatch):
+    """A reconstruction plane whose rows are not 4-byte aligned cannot be published by write-through dword stores: the kernel then
+    falls back to one agent-scope release fence per block.  SVTAV1_HIP_TPL_FENCE forces that path on an aligned plane."""
+    monkeypatch.setenv("SVTAV1_HIP_TPL_FENCE", "1")
+    for case in (T.CASES[3], [c for c in T.CASES if c[0] == "l5_pan_half_column"][0]):
+        a, b = T.TplScene(orc, case), T.TplScene(orc, case)
+        got = run_gpu(hip, a)
+        assert orc.orc_tpl_dispenser_frame(C.byref(b.job())) == 0
+        for k, v in b.results().items():
+            assert np.array_equal(got[k], v), (case[0], k)
+
+
 def test_argument_checks(hip, orc):
     s = T.TplScene(orc, T.CASES[0])
     dm = DevMap(hip)
