@@ -54,6 +54,7 @@ from benchlib.scan import zigzag_scan  # noqa: E402
 from svtav1_hip import abi, frames, shard  # noqa: E402
 
 METRIC = "encoded fps (4K 10-bit preset 8) + ME+txfm HBM GB/s vs roofline, 1/2/4/8 GPU"
+VALU_SLOT_NS, N_SIMD = 2.0, 1024        # one wave-instruction per SIMD: 2.0 ns (tools/ubench/valu_rates.hip); 256 CUs x 4 SIMDs
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 PLANE_SLACK = 256                        # bytes past a plane's last row that must be readable (include/svt_hip_me.h)
 
@@ -295,7 +296,7 @@ def measure_traffic(child_args, patterns, timeout_s=420):
     tmp = tempfile.mkdtemp(prefix="svtpmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
@@ -322,8 +323,13 @@ def measure_traffic(child_args, patterns, timeout_s=420):
         if p in raw.get("FETCH_SIZE", {}) and p in raw.get("WRITE_SIZE", {}):
             res[p] = {"bytes": int((2.0 * raw["FETCH_SIZE"][p] + raw["WRITE_SIZE"][p]) * 1024),
                       "FETCH_SIZE_KiB_raw": round(raw["FETCH_SIZE"][p], 1), "WRITE_SIZE_KiB": round(raw["WRITE_SIZE"][p], 1)}
+            if p in raw.get("SQ_INSTS_VALU", {}) and p in raw.get("SQ_ACTIVE_INST_VALU", {}):
+                res[p]["valu_insts"], res[p]["valu_slots"] = int(raw["SQ_INSTS_VALU"][p]), int(raw["SQ_ACTIVE_INST_VALU"][p])
     return res, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes over a child run of this workload (2 timed steps); "
-                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch (gfx950 counts a 128-B read request as 64 B)")
+                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch (gfx950 counts a 128-B read request as 64 B); `issue`: "
+                 "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per dispatch from two more passes, issue_ms = slots x 2.0 ns / 1024 SIMDs (one wave-"
+                 "instruction per SIMD takes 2.0 ns on this part: tools/ubench/valu_rates.hip; quarter-rate instructions such as "
+                 "v_qsad_pk_u16_u8 count four slots) = the time the vector pipes alone need for the launch")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -759,12 +765,21 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
     if rank != 0:
         return
     tr = lambda pat: (traffic.get(pat) or {}).get("bytes")      # noqa: E731
-    rl_me = roof("me_b64_kernel", mw.alg_bytes, ms["me"], tr("me_b64_kernel"), unit_of_work=f"{F} 4K pictures x {mw.nb} b64 x {mw.n_refs} references")
+
+    def issue(pat, launch_ms):
+        # the vector-issue roof of the launch beside its HBM roof: what the instruction stream alone costs (see traffic_note)
+        t = traffic.get(pat) or {}
+        if "valu_slots" not in t:
+            return {}
+        ims = t["valu_slots"] * VALU_SLOT_NS * 1e-6 / N_SIMD
+        return {"issue": {"valu_insts": t["valu_insts"], "valu_slots": t["valu_slots"], "issue_ms": round(ims, 4), "frac_of_launch": round(ims / launch_ms, 3)}}
+    rl_me = roof("me_b64_kernel", mw.alg_bytes, ms["me"], tr("me_b64_kernel"), unit_of_work=f"{F} 4K pictures x {mw.nb} b64 x {mw.n_refs} references",
+                 **issue("me_b64_kernel", ms["me"]))
     rl_all = [rl_me]
     for s in sizes:
         L = tw.launches[s]
         rl_all.append(roof(f"txfm_kernel<{s[0]}, {s[1]}>", L["alg_bytes"], ms[s], tr(f"txfm_kernel<{s[0]}, {s[1]}>"),
-                           unit_of_work=f"{L['n']} transform blocks of {F} 4K 10-bit pictures"))
+                           unit_of_work=f"{L['n']} transform blocks of {F} 4K 10-bit pictures", **issue(f"txfm_kernel<{s[0]}, {s[1]}>", ms[s])))
     tx_ms = sum(ms[s] for s in sizes)
     tx_alg = sum(tw.launches[s]["alg_bytes"] for s in sizes)
     if not args.no_lf:
