@@ -1280,7 +1280,10 @@ __device__ int g_me_stop = 99;
 // ------------------------------------------------------------------------------------------------
 // One launch, one workgroup per b64: all stages back to back.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS, 8) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
+#ifndef SVT_HIP_ME_WGS
+#define SVT_HIP_ME_WGS 8  // workgroups per CU the register allocation aims for (64 VGPRs)
+#endif
+__global__ __launch_bounds__(WG_THREADS, SVT_HIP_ME_WGS) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
     __shared__ MeLds L;
 #ifdef SVT_HIP_ME_PROFILE
     unsigned long long prof_last = wall_clock64();
