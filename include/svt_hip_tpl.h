@@ -20,6 +20,10 @@
  * The intra blocks depend on the reconstruction of their left / top / top-left neighbours: the kernel runs the source-based
  * path of every block in parallel and orders only the reconstruction of intra blocks behind their neighbours' (flags in
  * device memory; block indices are handed out by a ticket counter, so no dispatch order is assumed).  The caller orders pictures (a reference picture's reconstruction must be complete before this call).
+ * A block hands its reconstruction to the other compute units by storing its samples once more with device scope (written through the
+ * XCD's L2), waiting for those stores and then setting its flags; this needs 4-byte aligned reconstruction rows (stride and sample
+ * (0,0) address multiples of 4), otherwise — or with SVTAV1_HIP_TPL_FENCE set in the environment — a device-scope release fence per
+ * block (an L2 write-back, about three times slower) does it.
  * Not provided: the other intra modes and the SATD source search (tpl levels 1, 2), sub-pel refinement (levels 1-3),
  * 64x64 dispenser blocks, subsample_tx 1, the rate estimate.
  */
