@@ -2,7 +2,8 @@
 """bench.py — hot-path throughput of libsvtav1_hip on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... --
+     or bare: with WORLD_SIZE unset the script starts its N ranks itself as child processes, before any GPU call)
 
 Default workload = BASELINE.json configs[2], the configuration the metric is quoted on ("4K 10-bit preset 8, 1xMI355X"):
 one STEP is one pass of the per-picture hot path over a batch of F synthetic 3840x2160 pictures resident in HBM:
@@ -819,6 +820,38 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
     print(json.dumps(line))
 
 
+def launch_ranks(n):
+    """Start `n` ranks of this script as child processes (one per GPU: RANK = LOCAL_RANK = 0 .. n-1, rendezvous on 127.0.0.1)
+    and wait for them: what `python -m torch.distributed.run --nproc-per-node n` would do.  The caller must not have touched
+    the GPU; it never does afterwards either (no exec of a GPU process, children only).  Rank 0's stdout carries the ONE JSON
+    line; a rank that dies takes the others down with it (they would otherwise hang in a collective)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc if 0 <= rc < 256 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -841,24 +874,46 @@ def main():
     if args.frames is None:
         args.frames = 16
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU (nothing
+        # above this line makes a HIP call) and never will: the N ranks are CHILD processes, it only waits for them.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # SVTAV1_BENCH_REHEARSAL=1: rehearse the multi-rank control flow on a ONE-GPU box (all ranks share device 0, process
     # group over gloo).  Never set by the driver; the numbers of such a run mean nothing.
     rehearsal = os.environ.get("SVTAV1_BENCH_REHEARSAL") == "1"
+    launch_only = os.environ.get("SVTAV1_BENCH_REHEARSAL") == "launch"
 
     # HBM traffic first, while this process has not touched the GPU yet (the profiled child is a separate program)
     traffic, traffic_note = {}, "not measured (--no-pmc, a multi-rank run, or a workload other than 4k10)"
-    if args.workload == "4k10" and world == 1 and not args.no_pmc and not args.pmc_child:
+    if args.workload == "4k10" and world == 1 and not args.no_pmc and not args.pmc_child and not launch_only:
         pats = ["me_b64_kernel"] + [f"txfm_kernel<{s}, {s}>" for s in (64, 32, 16, 8)]
         traffic, traffic_note = measure_traffic(["--steps", "2", "--warmup", "1", "--frames", str(args.frames), "--no-cpu-baseline", "--no-lf"], pats)
 
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if launch_only and os.environ.get("SVTAV1_BENCH_FAIL_RANK") == str(rank):
+        sys.exit(3)                                     # test hook of the launcher: this rank dies before the rendezvous
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="gloo" if rehearsal else "nccl")   # RCCL on ROCm: barrier, max-time reduction, reference publish
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if launch_only:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="gloo" if rehearsal else "nccl")   # RCCL on ROCm: barrier, max-time reduction, reference publish
+        assert dist.get_world_size() == args.gpus, f"communicator holds {dist.get_world_size()} ranks, --gpus {args.gpus}"
+    if launch_only:
+        # SVTAV1_BENCH_REHEARSAL=launch: the launch path and the rank plumbing only, no GPU (CPU test of `--gpus N`)
+        t = shard.max_over_ranks(1.0 + rank, "cpu")
+        shard.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "fps", "n_gpus": world, "steps": 0, "warmup": 0,
+                              "rehearsal": "launch-only (no GPU work)", "ranks_in_communicator": dist.get_world_size() if world > 1 else 1,
+                              "max_over_ranks_check": t}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)

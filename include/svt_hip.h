@@ -76,6 +76,20 @@ typedef struct SvtHipRtcdBinding {
 SVT_HIP_API void   *svt_hip_rtcd_lookup(const char *reference_pointer_name);
 SVT_HIP_API int32_t svt_hip_install_rtcd(const SvtHipRtcdBinding *bindings, uint32_t n, uint32_t *n_installed);
 
+/* Tier A leaves have the reference's `void` signatures and cannot report an error: when a HIP call fails inside one, the library
+ * (once per process) logs "HIP hot path disabled", puts back the CPU pointers svt_hip_install_rtcd had replaced and completes
+ * the call with the host's own function (SURVEY 8b "never abort").  svt_hip_tier_a_failed_over() returns 1 from then on: a
+ * host reports it; a parity test that compares "C" with "HIP" MUST assert it is 0, or it may have compared C with C. */
+SVT_HIP_API int32_t svt_hip_tier_a_failed_over(void);
+
+/* ---- test hooks ---------------------------------------------------------------------------------------------------------
+ * Inert unless the process was started with SVTAV1_HIP_TEST_HOOKS=1 in its environment.  svt_hip_debug_inject_failure(n):
+ * the n-th device check inside a Tier A leaf from now on fails (0 = the next one, negative = off).
+ * svt_hip_debug_tier_a_broken(reset): returns the fail-over latch (like svt_hip_tier_a_failed_over) and, with reset != 0,
+ * clears it so that a test suite can go on (the CPU pointers stay restored until svt_hip_install_rtcd runs again). */
+SVT_HIP_API void    svt_hip_debug_inject_failure(int32_t n);
+SVT_HIP_API int32_t svt_hip_debug_tier_a_broken(int32_t reset);
+
 /* One padded 8-bit plane (mirror of the luma part of EbPictureBufferDesc,
  * Source/Lib/Codec/pic_buffer_desc.h:34-75).  `buf` points at the first byte of the padded
  * buffer (buffer_y); sample (x,y) of the picture is buf[(org_y+y)*stride + org_x + x]. */

@@ -29,9 +29,15 @@ extern "C" {
 SVT_HIP_API uint32_t svt_hip_shard_layer(uint32_t pic_in_minigop, uint32_t minigop_size);
 
 /* Layer-aware owner for the CLOSED-loop stages: a mini-GOP can only run as many pictures at once as the
- * current layer holds (1, 1, 2, 4, 8, 16 for 32), so the k-th picture of a layer goes to GPU k mod n_gpus; the base
- * picture to GPU 0. */
+ * current layer holds (1, 1, 2, 4, 8, 16 for 32).  svt_hip_shard_slot numbers the pictures of a mini-GOP in the order they
+ * become startable (base picture 0, layer 1 -> 1, layer 2 -> 2..3, layer 3 -> 4..7, ...; display order inside a layer);
+ * svt_hip_shard_owner = slot mod n_gpus, so the pictures of one layer sit on different GPUs AND consecutive layers continue
+ * the round-robin (no GPU collects the first picture of every layer; 32 pictures over 8 GPUs = 4 each).
+ * svt_hip_shard_owner_gop takes the picture number in display order over the whole sequence (0 = key picture, mini-GOP m
+ * = pictures m*size+1 .. (m+1)*size) and additionally rotates by the mini-GOP index, so base-layer pictures alternate. */
+SVT_HIP_API uint32_t svt_hip_shard_slot(uint32_t pic_in_minigop, uint32_t minigop_size);
 SVT_HIP_API uint32_t svt_hip_shard_owner(uint32_t pic_in_minigop, uint32_t minigop_size, uint32_t n_gpus);
+SVT_HIP_API uint32_t svt_hip_shard_owner_gop(uint64_t picture_number, uint32_t minigop_size, uint32_t n_gpus);
 
 /* Contiguous segment for the OPEN-loop stages: out = {first, last, ctx_first, ctx_last}: pictures [first, last) are
  * analysed by `rank`, [ctx_first, ctx_last) must be resident on it (its references).  Only pictures with a full set of

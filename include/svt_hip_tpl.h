@@ -84,7 +84,16 @@ typedef struct SvtHipTplFrameJob {
     uint8_t  synth_blk_size;     /* 16 or 8 (tpl_ctrls.synth_blk_size; 32 too with 32x32 blocks): grid of `stats` */
     uint8_t  blk_size;           /* 0 / 16: 16x16 blocks (dispenser_search_level 0); 32: 32x32 blocks (level 1) */
     uint8_t  subsample_tx;       /* tpl_ctrls.subsample_tx: 0 with 16x16 blocks; 0 or 2 (transform TX_32X8 on every 4th row) with 32x32 */
-    uint8_t  pad_;
+    uint8_t  publish_fence;      /* how a block hands its reconstruction to the blocks that wait for it (other CUs / XCDs).
+                                  * 0 (default): every lane re-stores its samples with agent scope (global_store ... sc1: written
+                                  * through this XCD's L2 to the device's coherence point), waits for the acknowledgement and
+                                  * lane 0 sets the done-flags; used when the reconstruction rows are 4-byte aligned.
+                                  * 1: one agent-scope RELEASE fence per block (buffer_wbl2: writes back the whole L2, ~3x slower);
+                                  * also what unaligned rows get.  Consumers poll the flag and then issue an agent-scope ACQUIRE
+                                  * fence (buffer_inv sc1) in both cases, so a line of the reconstruction that their XCD's L2 cached
+                                  * BEFORE the neighbour was published is dropped.  Mode 0 relies on the gfx942 / gfx950 memory
+                                  * model as LLVM's AMDGPUUsage documents it (agent-scope atomic store = sc1 write-through;
+                                  * agent-scope acquire = buffer_inv sc1); it is not a release / acquire pair of the C++ model. */
     /* quants_8bit / deq_8bit of the picture's qindex: [0] DC, [1] AC */
     int16_t  round_fp[2], quant_fp[2], dequant[2];
     uint16_t pad2_;

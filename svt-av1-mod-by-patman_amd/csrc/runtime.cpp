@@ -359,12 +359,26 @@ extern "C" void *svt_hip_rtcd_lookup(const char *name) {
     return dlsym(self, sym);
 }
 
-// Test hook: the n-th Tier A device check from now on reports a failure (n = 0: the next one; n < 0: off); and a way to
-// clear the latch again between tests.  Not declared in the public headers.
-extern "C" __attribute__((visibility("default"))) void svt_hip_debug_inject_failure(int32_t n) { svthip::g_inject.store(n); }
-extern "C" __attribute__((visibility("default"))) int32_t svt_hip_debug_tier_a_broken(int32_t reset) {
+// Whether a Tier A leaf has failed over (public, read-only: a host reports it; tests assert it stays 0).
+extern "C" int32_t svt_hip_tier_a_failed_over(void) { return svthip::g_tier_a_broken.load() ? 1 : 0; }
+
+// Test hooks (declared in svt_hip.h under "test hooks"): the n-th Tier A device check from now on reports a failure (n = 0: the
+// next one; n < 0: off); and a way to clear the latch again between tests.  Inert unless the process was started with
+// SVTAV1_HIP_TEST_HOOKS=1 -- a production host cannot trip them by accident (reading the latch always works).
+static bool test_hooks_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("SVTAV1_HIP_TEST_HOOKS");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+extern "C" void svt_hip_debug_inject_failure(int32_t n) {
+    if (test_hooks_enabled())
+        svthip::g_inject.store(n);
+}
+extern "C" int32_t svt_hip_debug_tier_a_broken(int32_t reset) {
     const int32_t was = svthip::g_tier_a_broken.load() ? 1 : 0;
-    if (reset)
+    if (reset && test_hooks_enabled())
         svthip::g_tier_a_broken.store(false);
     return was;
 }

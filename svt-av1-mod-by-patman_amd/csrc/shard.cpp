@@ -75,12 +75,29 @@ uint32_t svt_hip_shard_layer(uint32_t pic, uint32_t minigop) {
     return layer;
 }
 
-uint32_t svt_hip_shard_owner(uint32_t pic, uint32_t minigop, uint32_t n_gpus) {
+uint32_t svt_hip_shard_slot(uint32_t pic, uint32_t minigop) {
+    // position of the picture in the order the closed-loop stages can start them: base picture, then layer by layer,
+    // display order inside a layer: 0 | 1 | 2 3 | 4..7 | 8..15 | 16..31
     const uint32_t layer = svt_hip_shard_layer(pic, minigop);
-    if (layer == 0 || n_gpus == 0)
+    if (layer == 0)
         return 0;
     const uint32_t step = minigop >> layer;  // the pictures of this layer are the odd multiples of `step`
-    return ((pic / step) / 2) % n_gpus;
+    return (1u << (layer - 1)) + (pic / step) / 2;
+}
+
+uint32_t svt_hip_shard_owner(uint32_t pic, uint32_t minigop, uint32_t n_gpus) {
+    return n_gpus ? svt_hip_shard_slot(pic, minigop) % n_gpus : 0;
+}
+
+uint32_t svt_hip_shard_owner_gop(uint64_t picture_number, uint32_t minigop, uint32_t n_gpus) {
+    if (n_gpus == 0 || minigop == 0 || (minigop & (minigop - 1)))
+        return 0;
+    if (picture_number == 0)
+        return 0;                                                 // the key picture
+    const uint64_t mg  = (picture_number - 1) / minigop;          // mini-GOP index: pictures mg*minigop+1 .. (mg+1)*minigop
+    const uint32_t pic = (uint32_t)(picture_number - mg * minigop);
+    // rotate by the mini-GOP index: base pictures (slot 0) alternate over the GPUs, and so does every other slot
+    return (uint32_t)((svt_hip_shard_slot(pic, minigop) + mg + 1) % n_gpus);
 }
 
 void svt_hip_shard_segment(uint32_t n, uint32_t world, uint32_t rank, uint32_t lookback, uint32_t lookahead, uint32_t out[4]) {

@@ -473,8 +473,12 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     for (int l = 0; l < SVT_HIP_ME_MAX_LIST; l++)
         for (int q = 0; q < SVT_HIP_ME_MAX_REF; q++) {
             const SvtHipTplRef &f = job->ref[l][q];
-            if (!f.src)
+            if (!f.src) {
+                // the kernel gates on `usable` alone and reads src / recon of every usable reference
+                if (f.usable)
+                    return bad("reference picture marked usable but its src plane is NULL");
                 continue;
+            }
             if (!f.recon || f.src_stride < s.width + 2u * TPL_PAD || f.recon_stride < s.width + 2u * TPL_PAD)
                 return bad("reference picture: reconstruction missing or stride too small");
             // the clipped vector keeps a block inside max_width + TPL_PAD: that must be inside the padded plane
@@ -494,7 +498,7 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     TplArgs a;
     a.j = *job;
     a.src0 = s.buf + (size_t)s.org_y * s.stride + s.org_x, a.rec0 = r.buf + (size_t)r.org_y * r.stride + r.org_x;
-    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.coherent_rows = (r.stride % 4 == 0 && ((uintptr_t)(r.buf + (size_t)r.org_y * r.stride + r.org_x) % 4) == 0 && !getenv("SVTAV1_HIP_TPL_FENCE")) ? 1u : 0u,  /* (the variable forces the fence path: tests) */ a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb);
+    a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.coherent_rows = (r.stride % 4 == 0 && ((uintptr_t)(r.buf + (size_t)r.org_y * r.stride + r.org_x) % 4) == 0 && !job->publish_fence) ? 1u : 0u, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb);
     if (b32)
         hipLaunchKernelGGL((tpl_kernel<1>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
     else

@@ -331,7 +331,7 @@ class TplFrameJob(C.Structure):          # SvtHipTplFrameJob
                 ("total_me_candidate_index", C.c_void_p), ("max_cand", C.c_uint8), ("max_refs", C.c_uint8), ("max_l0", C.c_uint8),
                 ("enable_me_16x16", C.c_uint8), ("stored_pus", C.c_uint8), ("pf_shape", C.c_uint8), ("disable_intra_pred", C.c_uint8),
                 ("is_ref", C.c_uint8), ("i_slice", C.c_uint8), ("tpl_i_slice", C.c_uint8), ("src_data_ready", C.c_uint8),
-                ("store_src_stats", C.c_uint8), ("synth_blk_size", C.c_uint8), ("blk_size", C.c_uint8), ("subsample_tx", C.c_uint8), ("pad_", C.c_uint8),
+                ("store_src_stats", C.c_uint8), ("synth_blk_size", C.c_uint8), ("blk_size", C.c_uint8), ("subsample_tx", C.c_uint8), ("publish_fence", C.c_uint8),
                 ("round_fp", C.c_int16 * 2),
                 ("quant_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2), ("pad2_", C.c_uint16), ("stats", C.c_void_p), ("src_stats", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]

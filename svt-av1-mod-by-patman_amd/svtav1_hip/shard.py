@@ -98,16 +98,30 @@ def layer_of(pic_in_minigop, minigop=32):
     return layer
 
 
-def layer_aware_owner(pic_in_minigop, world, minigop=32):
-    """SURVEY 8e: the closed-loop stages of a mini-GOP can only run as many pictures at once as the current layer holds
-    (1, 1, 2, 4, 8, 16 for a 32-picture mini-GOP), so the pictures of ONE layer go to DIFFERENT GPUs: picture k-th of its
-    layer (in display order) is owned by rank k mod world.  Open-loop stages ignore this (any GPU can take any picture)."""
+def slot_of(pic_in_minigop, minigop=32):
+    """Position of a picture in the order the closed-loop stages can start them: base picture 0, then layer by layer
+    (display order inside a layer): 0 | 1 | 2 3 | 4..7 | 8..15 | 16..31  (svt_hip_shard_slot)."""
     layer = layer_of(pic_in_minigop, minigop)
     if layer == 0:
         return 0
     step = minigop >> layer               # pictures of this layer: odd multiples of step
-    k = (pic_in_minigop // step) // 2     # 0-based index inside the layer
-    return k % world
+    return (1 << (layer - 1)) + (pic_in_minigop // step) // 2
+
+
+def layer_aware_owner(pic_in_minigop, world, minigop=32):
+    """SURVEY 8e: the closed-loop stages of a mini-GOP can only run as many pictures at once as the current layer holds
+    (1, 1, 2, 4, 8, 16 for a 32-picture mini-GOP), so the pictures of ONE layer go to DIFFERENT GPUs, and consecutive layers
+    continue the round-robin: owner = slot mod world.  Open-loop stages ignore this (any GPU can take any picture)."""
+    return slot_of(pic_in_minigop, minigop) % world
+
+
+def owner_in_sequence(picture_number, world, minigop=32):
+    """svt_hip_shard_owner_gop: display-order picture number over the whole sequence (0 = key picture); rotated by the
+    mini-GOP index so that base-layer pictures alternate over the GPUs."""
+    if picture_number == 0:
+        return 0
+    mg = (picture_number - 1) // minigop
+    return (slot_of(picture_number - mg * minigop, minigop) + mg + 1) % world
 
 
 class ReferencePublisher:
@@ -128,18 +142,25 @@ class ReferencePublisher:
         self.transport, self.lib, self.comm, self.done = "torch", lib, None, None
         if transport == "c" and lib is not None:
             import ctypes as C
-            try:
-                ident = (C.c_uint8 * 128)()
-                if rank == 0:
-                    assert lib.svt_hip_comm_get_unique_id(ident) == 0, lib.svt_hip_last_error().decode()
-                box = [bytes(ident)]
-                dist.broadcast_object_list(box, src=0)
-                ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
-                comm = C.c_void_p()
-                assert lib.svt_hip_comm_create(ident, world, rank, C.byref(comm)) == 0, lib.svt_hip_last_error().decode()
+            # Every rank walks the same sequence of collectives whatever fails locally: rank 0 always broadcasts (None when
+            # it could not make an id), every rank that got an id joins the communicator, and the transport is AGREED by an
+            # all-reduce(min) of the per-rank success flags -- a rank never ends up in a different collective than the others.
+            ident = None
+            if rank == 0:
+                buf = (C.c_uint8 * 128)()
+                if lib.svt_hip_comm_get_unique_id(buf) == 0:
+                    ident = bytes(buf)
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            ok, comm = 0, C.c_void_p()
+            if box[0] is not None:
+                ok = int(lib.svt_hip_comm_create((C.c_uint8 * 128).from_buffer_copy(box[0]), world, rank, C.byref(comm)) == 0)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 self.comm, self.done, self.transport = comm, C.c_void_p(), "c"
-            except Exception:       # noqa: BLE001  (keep the bench alive: the torch transport is always there)
-                self.transport = "torch"
+            elif ok:
+                lib.svt_hip_comm_destroy(comm)
 
     def publish(self, producer, owner):
         if self.transport == "c":

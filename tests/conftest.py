@@ -9,6 +9,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "svt-av1-mod-by
         sys.path.insert(0, p)
 
 
+# the failure-injection hooks of the library are inert without this (include/svt_hip.h "test hooks"); set before the library loads
+os.environ.setdefault("SVTAV1_HIP_TEST_HOOKS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

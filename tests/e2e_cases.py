@@ -78,3 +78,11 @@ def encode(case, workdir, asm, lp=1, env_extra=None, timeout=900):
 def golden():
     with open(GOLDEN) as f:
         return json.load(f)
+
+
+def assert_hip_ran_clean(log):
+    """A `--asm hip` encode must have kept its HIP leaves to the end: after a HIP error inside a leaf the library restores the
+    C pointers and the encode finishes on the CPU (runtime.cpp, "HIP hot path disabled"), which reproduces the golden md5
+    trivially.  Same for a batched hook that declined or failed ("stays on the CPU", "falls back")."""
+    for needle in ("HIP hot path disabled", "HIP hot path unavailable"):
+        assert needle not in log, f"the encode did not stay on the HIP path ({needle!r}):\n" + log[-2000:]

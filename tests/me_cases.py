@@ -48,6 +48,16 @@ def make_clip(kind, width, height, n, seed=1):
                     f[by:by + h, bx:bx + w] = big[32 + by + dy:32 + by + dy + h, 32 + bx + dx:32 + bx + dx + w]
             out.append(f)
         return out
+    if kind.startswith("stripes"):  # vertical stripes alternating static content (inter prediction wins) and fresh noise per picture (intra wins)
+        sw = int(kind[7:])
+        base = frames.synthetic_clip(width, height, 1, seed=seed)[0]
+        noisy = ((np.arange(width) // sw) & 1).astype(bool)
+        out = []
+        for _ in range(n):
+            f = base.copy()
+            f[:, noisy] = rng.integers(0, 256, size=(height, int(noisy.sum())), dtype=np.uint8)
+            out.append(f)
+        return out
     raise ValueError(kind)
 
 

@@ -47,6 +47,7 @@ def test_asm_hip_bitstream_md5(hip, case):
     """GPU: every RTCD pointer that has a HIP leaf is swapped, the encoder runs, the bitstream is unchanged."""
     with tempfile.TemporaryDirectory() as d:
         md5, log = E.encode(case, d, "hip")
+    E.assert_hip_ran_clean(log)
     m = re.search(r"HIP hot path: (\d+) of (\d+) RTCD pointers", log)
     assert m, "the HIP leaves were not installed:\n" + log[-2000:]
     assert int(m.group(1)) == int(m.group(2)) >= 170
@@ -63,6 +64,7 @@ def test_batched_me_bitstream_md5(hip, case, lp):
     svt_aom_motion_estimation_b64 per block; several ME threads (--lp) share the picture's results.  Same bitstream."""
     with tempfile.TemporaryDirectory() as d:
         md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_ME": "1"})
+    E.assert_hip_ran_clean(log)
     m = re.search(r"svt_hip_bind_me: (\d+) pictures / (\d+) blocks", log)
     assert m, "the batched ME path did not run:\n" + log[-2000:]
     w, h, n, bd, preset = E.CASES[case]
@@ -81,6 +83,7 @@ def test_batched_tf_bitstream_md5(hip, case, lp):
     with the batched open-loop ME.  Same bitstream."""
     with tempfile.TemporaryDirectory() as d:
         md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_ME": "1"})
+    E.assert_hip_ran_clean(log)
     m = re.search(r"svt_hip_bind_tf: (\d+) pictures", log)
     assert m and int(m.group(1)) >= 1, "the batched temporal filter did not run:\n" + log[-2000:]
     assert "stays on the CPU" not in log
@@ -97,6 +100,7 @@ def test_batched_tpl_bitstream_md5(hip, case, lp):
     ME and the batched temporal filter: all three whole-picture entry points inside the running encoder.  Same bitstream."""
     with tempfile.TemporaryDirectory() as d:
         md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_TPL": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_ME": "1"})
+    E.assert_hip_ran_clean(log)
     m = re.search(r"svt_hip_bind_tpl: (\d+) pictures", log)
     assert m, log[-2000:]
     # presets M7 ... M9 run tpl level 4 (16x16 blocks), M10 and faster level 5 (32x32 blocks, sub-sampled transform): both covered
@@ -125,6 +129,7 @@ def test_batched_paths_ragged_clip(hip, case, lp):
     env = {"SVTAV1_HIP_TIERB_TPL": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_ONLY": "__none__"}
     with tempfile.TemporaryDirectory() as d:
         md5, log = E.encode(case, d, "hip", lp=lp, env_extra=env)
+    E.assert_hip_ran_clean(log)
     for what in ("me", "tf", "tpl"):
         m = re.search(rf"svt_hip_bind_{what}: (\d+) pictures", log)
         assert m and int(m.group(1)) >= 1, f"{what}: the batched path did not run\n" + log[-1500:]

@@ -61,8 +61,13 @@ class DropIn:
 @pytest.fixture()
 def dropin(hip, ref):
     d = DropIn(hip, ref)
+    assert hip.svt_hip_debug_tier_a_broken(0) == 0, "the fail-over latch was already set when the test started"
     yield d
     d.restore()
+    # A HIP error inside a leaf puts the C pointers back and finishes the call with them (common.hpp TIER_A_CALL): the "hip"
+    # phase of a test would then compare C with C and pass.  Every test that installed the leaves must leave the latch clear
+    # (test_device_failure_restores_cpu_kernels un-latches it itself before it returns).
+    assert hip.svt_hip_debug_tier_a_broken(0) == 0, "a Tier A leaf failed over to the CPU function during this test"
 
 
 def test_every_tier_a_export_has_a_reference_pointer(dropin):

@@ -107,16 +107,40 @@ def test_level5_all_intra_and_inter_1080p(hip, orc):
             assert (a.src_stats["best_mode"] == 16).any() and (a.src_stats["best_mode"] == 0).any()
 
 
-def test_fence_publish_path(hip, orc, monkeypatch):
+def test_fence_publish_path(hip, orc):
     """A reconstruction plane whose rows are not 4-byte aligned cannot be published by write-through dword stores: the kernel then
-    falls back to one agent-scope release fence per block.  SVTAV1_HIP_TPL_FENCE forces that path on an aligned plane."""
-    monkeypatch.setenv("SVTAV1_HIP_TPL_FENCE", "1")
+    falls back to one agent-scope release fence per block.  job.publish_fence forces that path on an aligned plane."""
     for case in (T.CASES[3], [c for c in T.CASES if c[0] == "l5_pan_half_column"][0]):
+        case = case[:5] + (dict(case[5], publish_fence=1),)
         a, b = T.TplScene(orc, case), T.TplScene(orc, case)
         got = run_gpu(hip, a)
         assert orc.orc_tpl_dispenser_frame(C.byref(b.job())) == 0
         for k, v in b.results().items():
             assert np.array_equal(got[k], v), (case[0], k)
+
+
+@pytest.mark.parametrize("level,fence", [(4, 0), (5, 0), (4, 1)])
+def test_stale_line_pattern_4k(hip, orc, level, fence):
+    """The hand-over the write-through publication has to get right: block columns ALTERNATE between inter blocks (static
+    stripes: they start at once and read nothing of their neighbours) and intra blocks (fresh noise per picture: they wait for the
+    left / top / top-left neighbours and read their reconstructed border samples).  An inter block to the right of an intra block
+    shares 128-byte row lines with it and is reconstructed long before it, so the line is in some XCD's L2 in its old state when the
+    intra block next to it -- on another XCD -- publishes; the intra block one further right must still see the published samples.
+    3840x2160, tpl level 4 (16x16 blocks, 16-sample stripes) and level 5 (32x32 blocks, 32-sample stripes), both publication modes."""
+    bs = 16 if level == 4 else 32
+    opt = dict(T.BASE, publish_fence=fence, **(T.L5 if level == 5 else {}))
+    if level == 5:
+        opt["synth_blk_size"] = 32
+    case = (f"stripes{bs}_4k", f"stripes{bs}", 3840, 2160, 120, opt)
+    a, b = T.TplScene(orc, case, key="m8_4k_tl2"), T.TplScene(orc, case, key="m8_4k_tl2")
+    assert orc.orc_tpl_dispenser_frame(C.byref(b.job())) == 0
+    modes = b.src_stats["best_mode"].reshape(-1, 3840 // 16)
+    cols = (np.arange(3840 // 16) * 16 // bs) & 1
+    # the pattern is what the test is about: noisy columns intra (DC_PRED = 0), static columns inter (NEWMV = 16)
+    assert (modes[:, cols == 1] == 0).mean() > 0.95 and (modes[:, cols == 0] == 16).mean() > 0.95
+    got = run_gpu(hip, a)
+    for k, v in b.results().items():
+        assert np.array_equal(got[k], v), (case[0], k, int((got[k] != v).sum()))
 
 
 def test_argument_checks(hip, orc):

@@ -14,6 +14,8 @@ import torch.multiprocessing as mp
 import me_cases as M
 from svtav1_hip import frames, shard
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 W, H, N = 192, 128, 11
 L0, L1 = (-1, -2), (1, 2)
 
@@ -93,6 +95,19 @@ def test_c_abi_assignment_matches_python():
             for layer in range(1, mg.bit_length()):
                 members = [own[i - 1] for i in range(1, mg + 1) if shard.layer_of(i, mg) == layer]
                 assert len(set(members)) == min(len(members), world)
+            # balanced: no GPU collects the first picture of every layer (the round-2 assignment put 6 of 32 on GPU 0)
+            if mg % world == 0:
+                assert [own.count(g) for g in range(world)] == [mg // world] * world
+        # whole sequence: base-layer pictures (multiples of the mini-GOP size) alternate over the GPUs
+        lib.svt_hip_shard_owner_gop.restype = C.c_uint32
+        lib.svt_hip_shard_owner_gop.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        for world in (2, 4, 8):
+            seq = [lib.svt_hip_shard_owner_gop(n, mg, world) for n in range(0, 8 * mg + 1)]
+            assert seq == [shard.owner_in_sequence(n, world, mg) for n in range(0, 8 * mg + 1)]
+            bases = [seq[m * mg] for m in range(1, 9)]
+            assert all(bases[i] != bases[i + 1] for i in range(7)), bases
+            if mg % world == 0:
+                assert [seq[1:].count(g) for g in range(world)] == [8 * mg // world] * world
     seg = (C.c_uint32 * 4)()
     for n in (5, 11, 20, 64):
         for world in (1, 2, 3, 8):
@@ -135,3 +150,26 @@ def test_two_ranks_equal_one():
     assert sorted(merged) == list(range(2, N - 2))
     for i in sorted(merged):
         M.assert_same(analyse(i), merged[i], f"picture {i}")
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the way the driver starts it) must start 2 ranks itself, before any GPU
+    call, and print ONE line with n_gpus = 2, every rank having seen 2 ranks in the communicator.  SVTAV1_BENCH_REHEARSAL=launch
+    stops each rank after the rank plumbing (no GPU here)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SVTAV1_BENCH_REHEARSAL"] = "launch"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_in_communicator"] == 2 and line["max_over_ranks_check"] == 2.0
+    # a rank that dies takes the launcher down with a non-zero exit code instead of hanging the others
+    env["SVTAV1_BENCH_REHEARSAL"] = "launch"
+    env["SVTAV1_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "rank 1 exited" in r.stderr
