@@ -56,6 +56,9 @@ SVT_HIP_API int32_t svt_hip_upload(void *dptr, const void *hptr, size_t bytes, v
 SVT_HIP_API int32_t svt_hip_download(void *hptr, const void *dptr, size_t bytes, void *stream);
 SVT_HIP_API int32_t svt_hip_upload_2d(void *dptr, size_t dpitch, const void *hptr, size_t hpitch,
                                       size_t width_bytes, size_t height, void *stream);
+SVT_HIP_API int32_t svt_hip_download_2d(void *hptr, size_t hpitch, const void *dptr, size_t dpitch,
+                                        size_t width_bytes, size_t height, void *stream);
+SVT_HIP_API int32_t svt_hip_copy(void *d_dst, const void *d_src, size_t bytes, void *stream); /* device to device */
 SVT_HIP_API int32_t svt_hip_stream_create(void **stream);
 SVT_HIP_API int32_t svt_hip_stream_destroy(void *stream);
 SVT_HIP_API int32_t svt_hip_stream_sync(void *stream);

@@ -311,6 +311,19 @@ int32_t svt_hip_upload_2d(void *dptr, size_t dpitch, const void *hptr, size_t hp
                                    resolve_stream(stream)));
     return SVT_HIP_OK;
 }
+int32_t svt_hip_download_2d(void *hptr, size_t hpitch, const void *dptr, size_t dpitch, size_t width_bytes, size_t height,
+                            void *stream) {
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    SVT_HIP_CHECK(hipMemcpy2DAsync(hptr, hpitch, dptr, dpitch, width_bytes, height, hipMemcpyDeviceToHost, resolve_stream(stream)));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_copy(void *d_dst, const void *d_src, size_t bytes, void *stream) {
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    SVT_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, resolve_stream(stream)));
+    return SVT_HIP_OK;
+}
 int32_t svt_hip_stream_create(void **stream) {
     if (!stream)
         return SVT_HIP_ERR_BAD_PARAMETER;

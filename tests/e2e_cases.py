@@ -66,7 +66,8 @@ def encode(case, workdir, asm, lp=1, env_extra=None, timeout=900):
             os.remove(p)
     cmd = [APP, "-i", clip, "-w", str(w), "-h", str(h), "--fps", "30", "-n", str(n), "--preset", str(preset),
            "--lp", str(lp), "--asm", asm, "--input-depth", str(bd), "-b", ivf, "-o", rec]
-    env = dict(os.environ, SVTAV1_HIP_LIB=HIP_LIB)
+    # SVTAV1_HIP_MIRROR_VERIFY: every hit of the glue's device-resident picture mirrors is compared with the host buffer
+    env = dict(os.environ, SVTAV1_HIP_LIB=HIP_LIB, SVTAV1_HIP_MIRROR_VERIFY="1")
     env.update(env_extra or {})
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=timeout)
     if r.returncode != 0:
@@ -84,5 +85,5 @@ def assert_hip_ran_clean(log):
     """A `--asm hip` encode must have kept its HIP leaves to the end: after a HIP error inside a leaf the library restores the
     C pointers and the encode finishes on the CPU (runtime.cpp, "HIP hot path disabled"), which reproduces the golden md5
     trivially.  Same for a batched hook that declined or failed ("stays on the CPU", "falls back")."""
-    for needle in ("HIP hot path disabled", "HIP hot path unavailable"):
+    for needle in ("HIP hot path disabled", "HIP hot path unavailable", "STALE mirror"):
         assert needle not in log, f"the encode did not stay on the HIP path ({needle!r}):\n" + log[-2000:]

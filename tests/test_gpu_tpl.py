@@ -134,8 +134,9 @@ def test_stale_line_pattern_4k(hip, orc, level, fence):
     case = (f"stripes{bs}_4k", f"stripes{bs}", 3840, 2160, 120, opt)
     a, b = T.TplScene(orc, case, key="m8_4k_tl2"), T.TplScene(orc, case, key="m8_4k_tl2")
     assert orc.orc_tpl_dispenser_frame(C.byref(b.job())) == 0
-    modes = b.src_stats["best_mode"].reshape(-1, 3840 // 16)
-    cols = (np.arange(3840 // 16) * 16 // bs) & 1
+    step = bs // 16                                    # a 32x32 block stores its source statistics in its top-left 16x16 cell
+    modes = b.src_stats["best_mode"].reshape(-1, 3840 // 16)[::step, ::step]
+    cols = np.arange(3840 // bs) & 1
     # the pattern is what the test is about: noisy columns intra (DC_PRED = 0), static columns inter (NEWMV = 16)
     assert (modes[:, cols == 1] == 0).mean() > 0.95 and (modes[:, cols == 0] == 16).mean() > 0.95
     got = run_gpu(hip, a)

@@ -17,6 +17,7 @@
 
 #include "svt_hip.h" /* include/ of the svtav1-hip repository */
 #include "svt_hip_bind.h"
+#include "svt_hip_bind_dev.h"
 
 #define HIP_SLOT(p) {#p, (void **)&p},
 static const SvtHipRtcdBinding hip_bindings[] = {
@@ -94,6 +95,7 @@ int svt_hip_bind_install(char *msg, unsigned msg_len) {
         return -1;
     }
     g_lib = h;
+    svt_hip_bind_dev_setup(lib_sym); /* device API, PCIe counters, device-resident picture mirrors shared by the hooks below */
     svt_hip_bind_me_setup(lib_sym); /* Step 2b: batched open-loop ME (SVTAV1_HIP_TIERB_ME=1) */
     svt_hip_bind_tf_setup(lib_sym); /* Step 6b: whole-picture temporal filter (SVTAV1_HIP_TIERB_TF=1) */
     svt_hip_bind_tpl_setup(lib_sym); /* Step 3c: whole-picture TPL dispenser (SVTAV1_HIP_TIERB_TPL=1) */

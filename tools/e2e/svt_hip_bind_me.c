@@ -6,7 +6,8 @@
  * The patch puts ONE call in front of the reference's per-block call:
  *     if (svt_hip_bind_me_b64(pcs, b64_index, me_ctx, input_padded_pic, quarter_picture_ptr, sixteenth_picture_ptr)) <their call>;
  * The first block of a picture that arrives here (from whichever ME thread / segment) runs the whole picture on the GPU:
- * MeContext -> SvtHipMeParams (the field map of INTEGRATION.md), the source and reference pyramids uploaded, one launch, results
+ * MeContext -> SvtHipMeParams (the field map of INTEGRATION.md), the source and reference pyramids taken from the device-resident
+ * picture mirrors (svt_hip_bind_dev.h: a pyramid crosses PCIe once, however many pictures reference it), one launch, results
  * downloaded; every block — that one and all later ones, on any thread — then only copies its own results into the picture's
  * MeSbResults / distortion arrays.  Threads that arrive while the picture is being computed wait on a condition variable.
  * Active with `--asm hip` and SVTAV1_HIP_TIERB_ME=1 for pictures whose ME needs nothing but what the batched call produces
@@ -25,19 +26,10 @@
 #include "svt_hip.h"
 #include "svt_hip_me.h"
 #include "svt_hip_bind.h"
+#include "svt_hip_bind_dev.h"
 
-/* entry points of libsvtav1_hip.so, resolved by svt_hip_bind_install() (svt_hip_bind.c) */
-typedef struct HipApi {
-    int32_t (*malloc_)(void **, size_t);
-    int32_t (*free_)(void *);
-    int32_t (*upload)(void *, const void *, size_t, void *);
-    int32_t (*download)(void *, const void *, size_t, void *);
-    int32_t (*sync)(void *);
-    int32_t (*me_frames)(const SvtHipMeFrameJob *, uint32_t, void *);
-    const char *(*last_error)(void);
-} HipApi;
-static HipApi g_api;
-static int    g_active;
+static int32_t (*p_me_frames)(const SvtHipMeFrameJob *, uint32_t, void *);
+static int           g_active;
 static unsigned long g_pictures, g_blocks; /* statistics, printed at exit */
 
 static void report(void) {
@@ -45,39 +37,27 @@ static void report(void) {
 }
 
 void svt_hip_bind_me_setup(void *(*sym)(const char *)) {
-    g_api.malloc_    = (int32_t(*)(void **, size_t))sym("svt_hip_malloc");
-    g_api.free_      = (int32_t(*)(void *))sym("svt_hip_free");
-    g_api.upload     = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_upload");
-    g_api.download   = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_download");
-    g_api.sync       = (int32_t(*)(void *))sym("svt_hip_stream_sync");
-    g_api.me_frames  = (int32_t(*)(const SvtHipMeFrameJob *, uint32_t, void *))sym("svt_hip_me_frames");
-    g_api.last_error = (const char *(*)(void))sym("svt_hip_last_error");
-    const char *env  = getenv("SVTAV1_HIP_TIERB_ME");
-    g_active = env && atoi(env) && g_api.malloc_ && g_api.free_ && g_api.upload && g_api.download && g_api.sync && g_api.me_frames;
+    p_me_frames = (int32_t(*)(const SvtHipMeFrameJob *, uint32_t, void *))sym("svt_hip_me_frames");
+    g_active    = hd_env_on("SVTAV1_HIP_TIERB_ME") && g_hd.ok && p_me_frames;
     if (g_active)
         atexit(report);
 }
 
-/* ---- one picture in flight ------------------------------------------------------------------------------------------- */
-typedef struct PicEntry {
-    PictureParentControlSet *pcs;
-    uint64_t                 picture_number;
-    int                      state; /* 0 free, 1 being computed, 2 ready, 3 failed (blocks fall back to the reference's call) */
-    uint32_t                 consumed, total, stored, max_refs, max_cand;
-    uint32_t                *mv;    /* [nb][stored * max_refs] */
-    uint8_t                 *cand;  /* [nb][stored * max_cand] */
-    uint8_t                 *cnt;   /* [nb][stored] */
-    uint32_t                *dist[6]; /* 64, 32, 16, 8, 8x8 cost variance, rc */
-} PicEntry;
-#define N_ENTRIES 64
-static PicEntry        g_tab[N_ENTRIES];
-static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t  g_cv = PTHREAD_COND_INITIALIZER;
+/* ---- one picture in flight: what the first block downloads and every block copies its share of ----------------------- */
+typedef struct PicResults {
+    uint32_t  stored, max_refs, max_cand;
+    uint32_t *mv;      /* [nb][stored * max_refs] */
+    uint8_t  *cand;    /* [nb][stored * max_cand] */
+    uint8_t  *cnt;     /* [nb][stored] */
+    uint32_t *dist[6]; /* 64, 32, 16, 8, 8x8 cost variance, rc */
+} PicResults;
+static HdOnceTable g_tab;
 
-static void entry_release(PicEntry *e) {
+static void results_free(void *p) {
+    PicResults *e = (PicResults *)p;
     free(e->mv), free(e->cand), free(e->cnt);
     for (int i = 0; i < 6; i++) free(e->dist[i]);
-    memset(e, 0, sizeof(*e));
+    free(e);
 }
 
 #define SA(dst, srcv) (dst).width = (uint16_t)(srcv).width, (dst).height = (uint16_t)(srcv).height
@@ -144,47 +124,50 @@ void svt_hip_bind_me_params(SvtHipMeParams *out, const PictureParentControlSet *
         for (int r = 0; r < out->num_of_ref_pic_to_search[l]; r++) out->ref_picture_number[l][r] = me->me_ds_ref_array[l][r].picture_number;
 }
 
+
 static size_t plane_bytes(const EbPictureBufferDesc *d) { return (size_t)d->stride_y * (d->height + 2u * d->org_y); }
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-/* device copy of one luma plane at dev + *off */
-static int put_plane(SvtHipPlane8 *p, const EbPictureBufferDesc *d, uint8_t *dev, size_t *off) {
-    p->buf = dev + *off, p->stride = d->stride_y, p->org_x = d->org_x, p->org_y = d->org_y, p->width = d->width, p->height = d->height;
-    const size_t n = plane_bytes(d);
-    *off += al256(n + 64);
-    return g_api.upload(p->buf, d->buffer_y, n, NULL);
+/* the device mirror of one luma plane; `pinned` collects the host addresses to unpin after the launch */
+static int get_plane(SvtHipPlane8 *p, const EbPictureBufferDesc *d, uint64_t picture_number, const void **pinned, int *n_pinned) {
+    p->stride = d->stride_y, p->org_x = d->org_x, p->org_y = d->org_y, p->width = d->width, p->height = d->height;
+    p->buf = hd_mirror_get(d->buffer_y, plane_bytes(d), HD_TAG(picture_number, HD_ST_FILTERED));
+    if (!p->buf)
+        return -1;
+    pinned[(*n_pinned)++] = d->buffer_y;
+    return 0;
 }
 
-static int compute_picture(PicEntry *e, PictureParentControlSet *pcs, MeContext *me, EbPictureBufferDesc *full, EbPictureBufferDesc *quarter,
-                           EbPictureBufferDesc *sixteenth) {
+static PicResults *compute_picture(PictureParentControlSet *pcs, MeContext *me, EbPictureBufferDesc *full, EbPictureBufferDesc *quarter,
+                                   EbPictureBufferDesc *sixteenth) {
     SvtHipMeFrameJob *job = (SvtHipMeFrameJob *)calloc(1, sizeof(*job));
-    if (!job)
-        return -1;
+    PicResults       *e   = (PicResults *)calloc(1, sizeof(*e));
+    if (!job || !e) {
+        free(job), free(e);
+        return NULL;
+    }
     svt_hip_bind_me_params(&job->prm, pcs, me);
     const SvtHipMeParams *p = &job->prm;
     const uint32_t nb = pcs->b64_total_count, stored = svt_hip_me_stored_pus(p);
-    e->total = nb, e->stored = stored, e->max_refs = p->max_refs, e->max_cand = p->max_cand;
+    e->stored = stored, e->max_refs = p->max_refs, e->max_cand = p->max_cand;
     const size_t n_mv = (size_t)nb * stored * p->max_refs * 4, n_cand = (size_t)nb * stored * p->max_cand, n_cnt = (size_t)nb * stored;
     const size_t n_best = (size_t)nb * 2 * 4 * 85 * 4, n_sr = (size_t)nb * 8 * sizeof(SvtHipMeSearchResult), n_d = (size_t)nb * 4;
-    size_t       need = 0;
-    const EbPictureBufferDesc *planes[3] = {full, quarter, sixteenth};
-    for (int k = 0; k < 3; k++) need += al256(plane_bytes(planes[k]) + 64);
-    for (int l = 0; l < p->num_of_list_to_search; l++)
-        for (int r = 0; r < p->num_of_ref_pic_to_search[l]; r++)
-            need += al256(plane_bytes(me->me_ds_ref_array[l][r].picture_ptr) + 64) + al256(plane_bytes(me->me_ds_ref_array[l][r].quarter_picture_ptr) + 64) +
-                al256(plane_bytes(me->me_ds_ref_array[l][r].sixteenth_picture_ptr) + 64);
-    need += al256(n_mv) + al256(n_cand) + al256(n_cnt) + 2 * al256(n_best) + al256(n_sr) + 6 * al256(n_d);
-    uint8_t *dev = NULL;
-    int      rc  = g_api.malloc_((void **)&dev, need);
-    size_t   off = 0;
-    if (rc == 0)
-        rc = put_plane(&job->src.full, full, dev, &off) | put_plane(&job->src.quarter, quarter, dev, &off) | put_plane(&job->src.sixteenth, sixteenth, dev, &off);
+    const void  *pinned[3 + 3 * SVT_HIP_ME_MAX_LIST * SVT_HIP_ME_MAX_REF];
+    int          n_pinned = 0;
+    int          rc = get_plane(&job->src.full, full, pcs->picture_number, pinned, &n_pinned) |
+        get_plane(&job->src.quarter, quarter, pcs->picture_number, pinned, &n_pinned) |
+        get_plane(&job->src.sixteenth, sixteenth, pcs->picture_number, pinned, &n_pinned);
     for (int l = 0; rc == 0 && l < p->num_of_list_to_search; l++)
-        for (int r = 0; rc == 0 && r < p->num_of_ref_pic_to_search[l]; r++)
-            rc = put_plane(&job->ref[l][r].full, me->me_ds_ref_array[l][r].picture_ptr, dev, &off) |
-                put_plane(&job->ref[l][r].quarter, me->me_ds_ref_array[l][r].quarter_picture_ptr, dev, &off) |
-                put_plane(&job->ref[l][r].sixteenth, me->me_ds_ref_array[l][r].sixteenth_picture_ptr, dev, &off);
-    uint8_t *d_mv = dev + off, *d_cand = d_mv + al256(n_mv), *d_cnt = d_cand + al256(n_cand), *d_bs = d_cnt + al256(n_cnt);
+        for (int r = 0; rc == 0 && r < p->num_of_ref_pic_to_search[l]; r++) {
+            const EbDownScaledBufDescPtrArray *a = &me->me_ds_ref_array[l][r];
+            rc = get_plane(&job->ref[l][r].full, a->picture_ptr, a->picture_number, pinned, &n_pinned) |
+                get_plane(&job->ref[l][r].quarter, a->quarter_picture_ptr, a->picture_number, pinned, &n_pinned) |
+                get_plane(&job->ref[l][r].sixteenth, a->sixteenth_picture_ptr, a->picture_number, pinned, &n_pinned);
+        }
+    uint8_t *dev = rc == 0 ? hd_alloc(al256(n_mv) + al256(n_cand) + al256(n_cnt) + 2 * al256(n_best) + al256(n_sr) + 6 * al256(n_d)) : NULL;
+    if (rc == 0 && !dev)
+        rc = -1;
+    uint8_t *d_mv = dev, *d_cand = d_mv + al256(n_mv), *d_cnt = d_cand + al256(n_cand), *d_bs = d_cnt + al256(n_cnt);
     uint8_t *d_bm = d_bs + al256(n_best), *d_sr = d_bm + al256(n_best), *d_dist = d_sr + al256(n_sr);
     if (rc == 0) {
         SvtHipMeFrameOut *o = &job->out;
@@ -193,22 +176,28 @@ static int compute_picture(PicEntry *e, PictureParentControlSet *pcs, MeContext 
         uint32_t **dd[6] = {&o->me_64x64_distortion, &o->me_32x32_distortion, &o->me_16x16_distortion, &o->me_8x8_distortion,
                             &o->me_8x8_cost_variance, &o->rc_me_distortion};
         for (int i = 0; i < 6; i++) *dd[i] = (uint32_t *)(d_dist + i * al256(n_d));
-        rc = g_api.me_frames(job, 1, NULL);
+        rc = p_me_frames(job, 1, NULL);
     }
     if (rc == 0) {
         e->mv = (uint32_t *)malloc(n_mv), e->cand = (uint8_t *)malloc(n_cand), e->cnt = (uint8_t *)malloc(n_cnt);
         for (int i = 0; i < 6; i++) e->dist[i] = (uint32_t *)malloc(n_d);
-        rc = g_api.download(e->mv, d_mv, n_mv, NULL) | g_api.download(e->cand, d_cand, n_cand, NULL) | g_api.download(e->cnt, d_cnt, n_cnt, NULL);
-        for (int i = 0; i < 6; i++) rc |= g_api.download(e->dist[i], d_dist + i * al256(n_d), n_d, NULL);
-        rc |= g_api.sync(NULL);
+        rc = hd_download(e->mv, d_mv, n_mv) | hd_download(e->cand, d_cand, n_cand) | hd_download(e->cnt, d_cnt, n_cnt);
+        for (int i = 0; i < 6; i++) rc |= hd_download(e->dist[i], d_dist + i * al256(n_d), n_d);
+        rc |= hd_sync();
+    } else {
+        hd_sync();
     }
+    for (int i = 0; i < n_pinned; i++) hd_mirror_unpin(pinned[i]);
     if (rc != 0)
-        fprintf(stderr, "svt_hip_bind_me: picture %llu falls back to the CPU search (%s)\n", (unsigned long long)pcs->picture_number,
-                g_api.last_error ? g_api.last_error() : "?");
-    if (dev)
-        g_api.free_(dev);
+        fprintf(stderr, "svt_hip_bind_me: picture %llu falls back to the CPU search (%s)\n", (unsigned long long)pcs->picture_number, hd_error());
+    hd_free(dev);
     free(job);
-    return rc;
+    if (rc != 0) {
+        results_free(e);
+        return NULL;
+    }
+    hd_count_picture();
+    return e;
 }
 
 /* Returns 0 when block b64_index of the picture has been filled in from the GPU results, 1 when the caller must run the
@@ -217,32 +206,20 @@ int svt_hip_bind_me_b64(PictureParentControlSet *pcs, uint32_t b64_index, MeCont
                         EbPictureBufferDesc *sixteenth) {
     if (!g_active || me->me_type != ME_OPEN_LOOP || pcs->gm_ctrls.enabled || pcs->frame_superres_enabled || pcs->frame_resize_enabled)
         return 1;
-    pthread_mutex_lock(&g_mu);
-    PicEntry *e = NULL, *fr = NULL;
-    for (int i = 0; i < N_ENTRIES; i++) {
-        if (g_tab[i].state && g_tab[i].pcs == pcs && g_tab[i].picture_number == pcs->picture_number)
-            e = &g_tab[i];
-        else if (!g_tab[i].state && !fr)
-            fr = &g_tab[i];
+    int     first;
+    HdOnce *once = hd_once_enter(&g_tab, pcs, pcs->picture_number, pcs->b64_total_count, &first);
+    if (!once)
+        return 1;
+    if (first) {
+        PicResults *r = compute_picture(pcs, me, full, quarter, sixteenth);
+        if (r)
+            __atomic_add_fetch(&g_pictures, 1, __ATOMIC_RELAXED);
+        hd_once_done(once, r != NULL, r);
     }
-    if (!e) {
-        if (!fr) { /* table full: cannot happen with the reference's look-ahead depth; let the CPU do this block */
-            pthread_mutex_unlock(&g_mu);
-            return 1;
-        }
-        e = fr;
-        e->pcs = pcs, e->picture_number = pcs->picture_number, e->state = 1, e->consumed = 0, e->total = pcs->b64_total_count;
-        pthread_mutex_unlock(&g_mu);
-        const int rc = compute_picture(e, pcs, me, full, quarter, sixteenth);
-        pthread_mutex_lock(&g_mu);
-        e->state = rc == 0 ? 2 : 3;
-        g_pictures += rc == 0;
-        pthread_cond_broadcast(&g_cv);
-    }
-    while (e->state == 1) pthread_cond_wait(&g_cv, &g_mu);
-    const int ok = e->state == 2;
+    const int ok = hd_once_ok(once);
     if (ok) {
-        MeSbResults *res = pcs->pa_me_data->me_results[b64_index];
+        const PicResults *e   = (const PicResults *)hd_once_payload(once);
+        MeSbResults      *res = pcs->pa_me_data->me_results[b64_index];
         memcpy(res->me_mv_array, e->mv + (size_t)b64_index * e->stored * e->max_refs, (size_t)e->stored * e->max_refs * 4);
         memcpy(res->me_candidate_array, e->cand + (size_t)b64_index * e->stored * e->max_cand, (size_t)e->stored * e->max_cand);
         memcpy(res->total_me_candidate_index, e->cnt + (size_t)b64_index * e->stored, e->stored);
@@ -255,10 +232,8 @@ int svt_hip_bind_me_b64(PictureParentControlSet *pcs, uint32_t b64_index, MeCont
         /* the tail of svt_aom_motion_estimation_b64 with global motion off (motion_estimation.c:3213-3215) */
         pcs->stationary_block_present_sb[b64_index] = 0;
         pcs->rc_me_allow_gm[b64_index]              = 0;
-        g_blocks++;
+        __atomic_add_fetch(&g_blocks, 1, __ATOMIC_RELAXED);
     }
-    if (++e->consumed >= e->total)
-        entry_release(e);
-    pthread_mutex_unlock(&g_mu);
+    hd_once_release(&g_tab, once, results_free);
     return ok ? 0 : 1;
 }

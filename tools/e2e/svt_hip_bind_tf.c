@@ -2,9 +2,10 @@
  * svt_hip_bind_tf.c — OUR glue compiled into the reference encoder by tools/reference_hip.patch (Step 6b of INTEGRATION.md):
  * the block loop of produce_temporally_filtered_pic (Source/Lib/Codec/temporal_filtering.c:2752-3308) through the BATCHED entry
  * point svt_hip_tf_filter_picture.  The patch puts `if (svt_hip_bind_tf_picture(...))` in front of the reference's block loop:
- * the first temporal-filter segment of a picture that arrives here runs the WHOLE picture on the GPU (window pictures uploaded,
- * one call, the filtered centre picture downloaded into the planes the reference's loop would have written); the other
- * segments of that picture wait for it and return.  What stays in the reference: which pictures are in the window and the
+ * the first temporal-filter segment of a picture that arrives here runs the WHOLE picture on the GPU (window pictures from the
+ * device-resident picture mirrors of svt_hip_bind_dev.h, one call, the filtered centre picture downloaded into host staging and
+ * copied into the planes the reference's loop would have written only once everything has succeeded — a failure half-way leaves
+ * the picture untouched for the reference's own loop); the other segments of that picture wait for it and return.  What stays in the reference: which pictures are in the window and the
  * outlier tests (re-evaluated here exactly as at :3002-3030, they are scalar), the decay factors (computed by the reference
  * right before the hook), 10-bit packing before / unpacking after, padding + decimation of the filtered picture.
  * Active with `--asm hip` and SVTAV1_HIP_TIERB_TF=1; a picture this path does not cover (8x8 prediction, sub-64 pictures ...)
@@ -24,19 +25,10 @@
 #include "svt_hip.h"
 #include "svt_hip_tf.h"
 #include "svt_hip_bind.h"
+#include "svt_hip_bind_dev.h"
 
-typedef struct TfApi {
-    int32_t (*malloc_)(void **, size_t);
-    int32_t (*free_)(void *);
-    int32_t (*upload)(void *, const void *, size_t, void *);
-    int32_t (*download)(void *, const void *, size_t, void *);
-    int32_t (*memset_)(void *, int32_t, size_t, void *);
-    int32_t (*sync)(void *);
-    int32_t (*tf_picture)(const SvtHipTfPictureJob *, void *);
-    uint64_t (*tf_ws_bytes)(uint32_t, uint32_t, uint32_t);
-    const char *(*last_error)(void);
-} TfApi;
-static TfApi         g_api;
+static int32_t (*p_tf_picture)(const SvtHipTfPictureJob *, void *);
+static uint64_t (*p_tf_ws_bytes)(uint32_t, uint32_t, uint32_t);
 static int           g_active;
 static unsigned long g_pictures;
 
@@ -45,88 +37,87 @@ void svt_hip_bind_me_params(SvtHipMeParams *out, const PictureParentControlSet *
 static void report(void) { fprintf(stderr, "svt_hip_bind_tf: %lu pictures through svt_hip_tf_filter_picture\n", g_pictures); }
 
 void svt_hip_bind_tf_setup(void *(*sym)(const char *)) {
-    g_api.malloc_     = (int32_t(*)(void **, size_t))sym("svt_hip_malloc");
-    g_api.free_       = (int32_t(*)(void *))sym("svt_hip_free");
-    g_api.upload      = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_upload");
-    g_api.download    = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_download");
-    g_api.memset_     = (int32_t(*)(void *, int32_t, size_t, void *))sym("svt_hip_memset");
-    g_api.sync        = (int32_t(*)(void *))sym("svt_hip_stream_sync");
-    g_api.tf_picture  = (int32_t(*)(const SvtHipTfPictureJob *, void *))sym("svt_hip_tf_filter_picture");
-    g_api.tf_ws_bytes = (uint64_t(*)(uint32_t, uint32_t, uint32_t))sym("svt_hip_tf_workspace_bytes");
-    g_api.last_error  = (const char *(*)(void))sym("svt_hip_last_error");
-    const char *env   = getenv("SVTAV1_HIP_TIERB_TF");
-    g_active = env && atoi(env) && g_api.malloc_ && g_api.free_ && g_api.upload && g_api.download && g_api.memset_ && g_api.sync &&
-        g_api.tf_picture && g_api.tf_ws_bytes;
+    p_tf_picture  = (int32_t(*)(const SvtHipTfPictureJob *, void *))sym("svt_hip_tf_filter_picture");
+    p_tf_ws_bytes = (uint64_t(*)(uint32_t, uint32_t, uint32_t))sym("svt_hip_tf_workspace_bytes");
+    g_active      = hd_env_on("SVTAV1_HIP_TIERB_TF") && g_hd.ok && p_tf_picture && p_tf_ws_bytes;
     if (g_active)
         atexit(report);
 }
 
-/* ---- pictures in flight: the first segment computes, the others wait ---------------------------------------------------- */
-typedef struct TfEntry {
-    PictureParentControlSet *pcs;
-    uint64_t                 picture_number;
-    int                      state; /* 0 free, 1 being computed, 2 done on the GPU, 3 not covered / failed */
-    int                      seen, total;
-    uint32_t                 tot[2];
-} TfEntry;
-#define N_TF 16
-static TfEntry         g_tab[N_TF];
-static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t  g_cv = PTHREAD_COND_INITIALIZER;
+static HdOnceTable g_tab;
+static size_t      al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-
+/* device copies of one picture of the window */
 typedef struct DevPic {
     SvtHipTfPic pic;
-    uint8_t    *d_luma8, *d_c8[2], *d_hbd[3];
+    uint8_t    *d_luma8, *d_c8[2], *d_hbd[3]; /* d_hbd: scratch owned by this struct; the 8-bit planes are mirrors */
     size_t      n_luma8, n_c8, n_hbd_y, n_hbd_c;
+    const void *pinned[5];
+    int         n_pinned;
 } DevPic;
 
-/* device copies of one picture of the window: 8-bit luma pyramid (pa reference object), 8-bit chroma, 16-bit planes */
-static int put_picture(DevPic *dp, PictureParentControlSet *pcs, EbPictureBufferDesc *pic, int is_highbd, int chroma, uint8_t *dev, size_t *off) {
+static uint8_t *mirror(DevPic *dp, const void *host, size_t n, uint64_t picture_number) {
+    uint8_t *d = hd_mirror_get(host, n, HD_TAG(picture_number, HD_ST_FILTERED));
+    if (d)
+        dp->pinned[dp->n_pinned++] = host;
+    return d;
+}
+
+/* 8-bit luma pyramid (the picture + its pa reference object's decimations) and 8-bit chroma from the mirrors -- "FILTERED" stands
+ * for "what the buffer holds until this picture's own temporal filter rewrites it" (release_picture_mirrors); the packed 16-bit
+ * planes are per-call temporaries of the reference (altref_buffer_highbd) and go through scratch memory. */
+static int put_picture(DevPic *dp, PictureParentControlSet *pcs, EbPictureBufferDesc *pic, int is_highbd, int chroma, int scratch_8bit) {
     EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
     EbPictureBufferDesc *pl[3] = {pic, pa->quarter_downsampled_picture_ptr, pa->sixteenth_downsampled_picture_ptr};
     SvtHipPlane8        *dst[3] = {&dp->pic.pyr.full, &dp->pic.pyr.quarter, &dp->pic.pyr.sixteenth};
-    int                  rc = 0;
     memset(dp, 0, sizeof(*dp));
     for (int k = 0; k < 3; k++) {
         const size_t n = (size_t)pl[k]->stride_y * (pl[k]->height + 2u * pl[k]->org_y);
-        dst[k]->buf = dev + *off, dst[k]->stride = pl[k]->stride_y, dst[k]->org_x = pl[k]->org_x, dst[k]->org_y = pl[k]->org_y;
+        dst[k]->stride = pl[k]->stride_y, dst[k]->org_x = pl[k]->org_x, dst[k]->org_y = pl[k]->org_y;
         dst[k]->width = pl[k]->width, dst[k]->height = pl[k]->height;
-        rc |= g_api.upload(dst[k]->buf, pl[k]->buffer_y, n, NULL);
         if (k == 0)
-            dp->d_luma8 = dst[k]->buf, dp->n_luma8 = n;
-        *off += al256(n + 64);
+            dp->n_luma8 = n;
+        if (k == 0 && scratch_8bit) /* the centre picture of an 8-bit filter: the caller supplies a scratch copy (filtered in place) */
+            continue;
+        if (!(dst[k]->buf = mirror(dp, pl[k]->buffer_y, n, pcs->picture_number)))
+            return -1;
+        if (k == 0)
+            dp->d_luma8 = dst[k]->buf;
     }
     dp->pic.chroma8_stride = pic->stride_cb;
     dp->n_c8               = (size_t)pic->stride_cb * ((pic->height + 2u * pic->org_y) >> 1);
-    if (chroma && !is_highbd)
-        for (int c = 0; c < 2; c++) {
-            dp->d_c8[c] = dp->pic.chroma8[c] = dev + *off;
-            rc |= g_api.upload(dp->d_c8[c], c ? pic->buffer_cr : pic->buffer_cb, dp->n_c8, NULL);
-            *off += al256(dp->n_c8 + 64);
-        }
+    if (chroma && !is_highbd && !scratch_8bit)
+        for (int c = 0; c < 2; c++)
+            if (!(dp->d_c8[c] = dp->pic.chroma8[c] = mirror(dp, c ? pic->buffer_cr : pic->buffer_cb, dp->n_c8, pcs->picture_number)))
+                return -1;
     if (is_highbd) {
         dp->n_hbd_y = (size_t)pic->stride_y * (pic->height + 2u * pic->org_y) * 2, dp->n_hbd_c = dp->n_c8 * 2;
         for (int c = 0; c < (chroma ? 3 : 1); c++) {
             const size_t n = c ? dp->n_hbd_c : dp->n_hbd_y;
-            dp->d_hbd[c]   = dev + *off;
+            if (!(dp->d_hbd[c] = hd_alloc(n + 256)))
+                return -1;
             dp->pic.hbd[c] = (uint16_t *)dp->d_hbd[c];
-            rc |= g_api.upload(dp->d_hbd[c], pcs->altref_buffer_highbd[c], n, NULL);
-            *off += al256(n + 64);
+            if (hd_upload(dp->d_hbd[c], pcs->altref_buffer_highbd[c], n) != 0)
+                return -1;
         }
     }
     dp->pic.picture_number = pcs->picture_number;
-    return rc;
+    return 0;
+}
+static void release_picture(DevPic *dp) {
+    for (int i = 0; i < dp->n_pinned; i++) hd_mirror_unpin(dp->pinned[i]);
+    for (int c = 0; c < 3; c++) hd_free(dp->d_hbd[c]);
+    dp->n_pinned = 0;
 }
 
-static size_t picture_bytes(PictureParentControlSet *pcs, EbPictureBufferDesc *pic) {
+/* The temporal filter is about to rewrite (or has rewritten) the centre picture: its source planes and, right behind the block
+ * loop, the pa reference object's padded copy and decimations (temporal_filtering.c: pad + decimate of the filtered picture). */
+static void drop_picture_mirrors(PictureParentControlSet *pcs, EbPictureBufferDesc *pic) {
     EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
-    EbPictureBufferDesc *pl[3] = {pic, pa->quarter_downsampled_picture_ptr, pa->sixteenth_downsampled_picture_ptr};
-    size_t               n = 0;
-    for (int k = 0; k < 3; k++) n += al256((size_t)pl[k]->stride_y * (pl[k]->height + 2u * pl[k]->org_y) + 64);
-    const size_t c8 = (size_t)pic->stride_cb * ((pic->height + 2u * pic->org_y) >> 1);
-    return n + 2 * al256(c8 + 64) + al256((size_t)pic->stride_y * (pic->height + 2u * pic->org_y) * 2 + 64) + 2 * al256(c8 * 2 + 64);
+    hd_mirror_drop(pic->buffer_y), hd_mirror_drop(pic->buffer_cb), hd_mirror_drop(pic->buffer_cr);
+    if (pa->input_padded_pic)
+        hd_mirror_drop(pa->input_padded_pic->buffer_y);
+    hd_mirror_drop(pa->quarter_downsampled_picture_ptr->buffer_y), hd_mirror_drop(pa->sixteenth_downsampled_picture_ptr->buffer_y);
 }
 
 static int run_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc **pics, int index_center, MeContext *ctx, int is_highbd, uint32_t tot[2]) {
@@ -187,84 +178,110 @@ static int run_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc *
     job->mv_dist_th = ctx->tf_mv_dist_th, job->chroma = ctx->tf_chroma, job->bit_depth = is_highbd ? 10 : 8;
     job->mi_rows = (uint32_t)centre->av1_cm->mi_rows, job->mi_cols = (uint32_t)centre->av1_cm->mi_cols, job->n_refs = (uint32_t)n;
 
-    const uint64_t wsb = g_api.tf_ws_bytes(cpic->width, cpic->height, (uint32_t)n);
-    size_t         need = al256(wsb) + 256;
-    need += picture_bytes(centre, cpic);
-    for (int k = 0; k < n; k++) need += picture_bytes(pcs_list[idx[k]], pics[idx[k]]);
-    uint8_t *dev = NULL;
-    int      rc  = g_api.malloc_((void **)&dev, need);
-    size_t   off = 0;
-    DevPic   dc, dr;
+    const uint64_t wsb = p_tf_ws_bytes(cpic->width, cpic->height, (uint32_t)n);
+    uint8_t       *ws  = hd_alloc(al256(wsb) + 256);
+    int            rc  = ws ? 0 : -1;
+    DevPic         dc, dr[SVT_HIP_TF_MAX_REFS];
+    int            n_dr = 0;
+    memset(&dc, 0, sizeof(dc));
     if (rc == 0)
-        rc = put_picture(&dc, centre, cpic, is_highbd, job->chroma, dev, &off);
+        rc = put_picture(&dc, centre, cpic, is_highbd, job->chroma, !is_highbd);
     job->centre = dc.pic;
     for (int k = 0; rc == 0 && k < n; k++) {
-        rc = put_picture(&dr, pcs_list[idx[k]], pics[idx[k]], is_highbd, job->chroma, dev, &off);
-        job->ref[k] = dr.pic;
+        rc = put_picture(&dr[k], pcs_list[idx[k]], pics[idx[k]], is_highbd, job->chroma, 0);
+        n_dr++;
+        job->ref[k] = dr[k].pic;
     }
+    /* the kernel filters the centre picture IN PLACE on the device: it must not do that to the cached mirror (a later window may
+     * ask for the unfiltered picture again if this call fails) -- the centre's 8-bit planes are copied into scratch first */
+    uint8_t *d_out[3] = {NULL, NULL, NULL};
+    size_t   n_out[3] = {0, 0, 0};
+    uint8_t *h_out[3] = {NULL, NULL, NULL};
     if (rc == 0) {
-        job->workspace = dev + off, job->workspace_bytes = wsb, off += al256(wsb);
-        job->tot_blks = (uint32_t *)(dev + off);
-        rc = g_api.memset_(job->tot_blks, 0, 8, NULL);
+        const int np = job->chroma ? 3 : 1;
+        for (int c = 0; c < np; c++) n_out[c] = is_highbd ? (c ? dc.n_hbd_c : dc.n_hbd_y) : (c ? dc.n_c8 : dc.n_luma8);
+        if (!is_highbd) {
+            /* fresh scratch copies of the centre planes (uploaded from the host: the same bytes the mirror holds) */
+            const uint8_t *hsrc[3] = {cpic->buffer_y, cpic->buffer_cb, cpic->buffer_cr};
+            for (int c = 0; rc == 0 && c < np; c++) {
+                if (!(d_out[c] = hd_alloc(n_out[c] + 256)))
+                    rc = -1;
+                else
+                    rc = hd_upload(d_out[c], hsrc[c], n_out[c]);
+            }
+            if (rc == 0) {
+                job->centre.pyr.full.buf = d_out[0];
+                if (job->chroma)
+                    job->centre.chroma8[0] = d_out[1], job->centre.chroma8[1] = d_out[2];
+            }
+        } else {
+            for (int c = 0; c < np; c++) d_out[c] = NULL; /* the 16-bit planes already are scratch (dc.d_hbd) */
+        }
+    }
+    uint32_t *d_tot = NULL;
+    if (rc == 0) {
+        job->workspace = ws, job->workspace_bytes = wsb;
+        d_tot = (uint32_t *)(ws + al256(wsb));
+        job->tot_blks = d_tot;
+        rc = g_hd.memset_(d_tot, 0, 8, NULL);
     }
     if (rc == 0)
-        rc = g_api.tf_picture(job, NULL);
-    if (rc == 0) { /* the filtered centre picture back into the planes the reference's loop writes */
-        if (!is_highbd) {
-            rc = g_api.download(cpic->buffer_y, dc.d_luma8, dc.n_luma8, NULL);
-            if (job->chroma)
-                rc |= g_api.download(cpic->buffer_cb, dc.d_c8[0], dc.n_c8, NULL) | g_api.download(cpic->buffer_cr, dc.d_c8[1], dc.n_c8, NULL);
-        } else {
-            for (int c = 0; c < (job->chroma ? 3 : 1); c++) rc |= g_api.download(centre->altref_buffer_highbd[c], dc.d_hbd[c], c ? dc.n_hbd_c : dc.n_hbd_y, NULL);
+        rc = p_tf_picture(job, NULL);
+    if (rc == 0) { /* the filtered centre picture into host staging; into the encoder's planes only when all of it has arrived */
+        const int np = job->chroma ? 3 : 1;
+        for (int c = 0; rc == 0 && c < np; c++) {
+            h_out[c] = (uint8_t *)malloc(n_out[c]);
+            rc = h_out[c] ? hd_download(h_out[c], is_highbd ? dc.d_hbd[c] : d_out[c], n_out[c]) : -1;
         }
-        rc |= g_api.download(tot, job->tot_blks, 8, NULL);
-        rc |= g_api.sync(NULL);
+        if (rc == 0)
+            rc = hd_download(tot, d_tot, 8);
+        rc |= hd_sync();
+        if (rc == 0) {
+            uint8_t *hdst[3] = {cpic->buffer_y, cpic->buffer_cb, cpic->buffer_cr};
+            for (int c = 0; c < np; c++) memcpy(is_highbd ? (uint8_t *)centre->altref_buffer_highbd[c] : hdst[c], h_out[c], n_out[c]);
+        }
+    } else {
+        hd_sync();
     }
+    release_picture(&dc);
+    for (int k = 0; k < n_dr; k++) release_picture(&dr[k]);
+    for (int c = 0; c < 3; c++) hd_free(d_out[c]), free(h_out[c]);
+    hd_free(ws);
     if (rc != 0)
-        fprintf(stderr, "svt_hip_bind_tf: picture %llu stays on the CPU (%s)\n", (unsigned long long)centre->picture_number,
-                g_api.last_error ? g_api.last_error() : "?");
-    if (dev)
-        g_api.free_(dev);
+        fprintf(stderr, "svt_hip_bind_tf: picture %llu stays on the CPU (%s)\n", (unsigned long long)centre->picture_number, hd_error());
+    else
+        hd_count_picture();
     free(job);
     return rc != 0;
 }
 
 /* Returns 0 when the picture has been filtered on the GPU (the caller skips its block loop), 1 when the caller must run it. */
 int svt_hip_bind_tf_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc **pics, int index_center, MeContext *ctx, int is_highbd) {
-    if (!g_active)
-        return 1;
     PictureParentControlSet *centre = pcs_list[index_center];
-    pthread_mutex_lock(&g_mu);
-    TfEntry *e = NULL, *fr = NULL;
-    for (int i = 0; i < N_TF; i++) {
-        if (g_tab[i].state && g_tab[i].pcs == centre && g_tab[i].picture_number == centre->picture_number)
-            e = &g_tab[i];
-        else if (!g_tab[i].state && !fr)
-            fr = &g_tab[i];
+    if (!g_active) {
+        if (g_hd.ok)
+            drop_picture_mirrors(centre, pics[index_center]); /* other hooks may hold mirrors of the picture this loop rewrites */
+        return 1;
     }
-    if (!e) {
-        if (!fr) {
-            pthread_mutex_unlock(&g_mu);
-            return 1;
-        }
-        e = fr;
-        e->pcs = centre, e->picture_number = centre->picture_number, e->state = 1, e->seen = 0, e->total = centre->tf_segments_total_count;
-        pthread_mutex_unlock(&g_mu);
+    int     first;
+    HdOnce *once = hd_once_enter(&g_tab, centre, centre->picture_number, centre->tf_segments_total_count, &first);
+    if (!once) {
+        drop_picture_mirrors(centre, pics[index_center]);
+        return 1;
+    }
+    if (first) {
         uint32_t  tot[2] = {0, 0};
         const int rc = run_picture(pcs_list, pics, index_center, ctx, is_highbd, tot);
-        pthread_mutex_lock(&g_mu);
-        e->state = rc == 0 ? 2 : 3;
+        /* either way the centre picture changes now: here (GPU) or in the reference's loop right behind this call (CPU) */
+        drop_picture_mirrors(centre, pics[index_center]);
         if (rc == 0) {
             /* tf_tot_*_blks of the whole picture go to this segment's context (the caller adds every segment's into the pcs) */
             ctx->tf_tot_horz_blks += tot[0], ctx->tf_tot_vert_blks += tot[1];
-            g_pictures++;
+            __atomic_add_fetch(&g_pictures, 1, __ATOMIC_RELAXED);
         }
-        pthread_cond_broadcast(&g_cv);
+        hd_once_done(once, rc == 0, NULL);
     }
-    while (e->state == 1) pthread_cond_wait(&g_cv, &g_mu);
-    const int on_gpu = e->state == 2;
-    if (++e->seen >= e->total)
-        memset(e, 0, sizeof(*e));
-    pthread_mutex_unlock(&g_mu);
+    const int on_gpu = hd_once_ok(once);
+    hd_once_release(&g_tab, once, NULL);
     return on_gpu ? 0 : 1;
 }

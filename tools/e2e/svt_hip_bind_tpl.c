@@ -3,9 +3,10 @@
  * the TPL dispenser of a whole picture through svt_hip_tpl_dispenser_frame instead of one tpl_mc_flow_dispenser_sb_generic call
  * per 64x64 block (Source/Lib/Codec/src_ops_process.c:519-1207, called from svt_aom_tpl_disp_kernel :1964).
  * The patch puts `if (svt_hip_bind_tpl_sb(pcs, frame_idx, sb_index, qIndex))` in front of the reference's per-block call: the
- * first block of a picture that arrives runs the whole picture on the GPU (source, the references' source and TPL
- * reconstruction pictures and the picture's ME results uploaded; the TPL reconstruction, TplStats and TplSrcStats downloaded and
- * stored where the reference's loop stores them, result_model_store's grids included); the other blocks wait and return.
+ * first block of a picture that arrives runs the whole picture on the GPU (the source, the references' source and TPL
+ * reconstruction pictures from the device-resident mirrors of svt_hip_bind_dev.h, the picture's ME results uploaded; the TPL
+ * reconstruction, TplStats and TplSrcStats downloaded into host staging, the kernel's status word checked, and only then stored
+ * where the reference's loop stores them, result_model_store's grids included); the other blocks wait and return.
  * Covered: the configuration of include/svt_hip_tpl.h (the tpl level of presets M7 ... M9); anything else returns 1 for every block
  * of the picture and the reference's own loop runs.  Active with `--asm hip` and SVTAV1_HIP_TIERB_TPL=1.
  */
@@ -22,52 +23,26 @@
 #include "svt_hip.h"
 #include "svt_hip_tpl.h"
 #include "svt_hip_bind.h"
+#include "svt_hip_bind_dev.h"
 
-typedef struct TplApi {
-    int32_t (*malloc_)(void **, size_t);
-    int32_t (*free_)(void *);
-    int32_t (*upload)(void *, const void *, size_t, void *);
-    int32_t (*download)(void *, const void *, size_t, void *);
-    int32_t (*memset_)(void *, int32_t, size_t, void *);
-    int32_t (*sync)(void *);
-    int32_t (*tpl_frame)(const SvtHipTplFrameJob *, void *);
-    uint64_t (*ws_bytes)(uint32_t, uint32_t);
-    const char *(*last_error)(void);
-} TplApi;
-static TplApi        g_api;
+static int32_t (*p_tpl_frame)(const SvtHipTplFrameJob *, void *);
+static uint64_t (*p_ws_bytes)(uint32_t, uint32_t);
+static uint64_t (*p_status_offset)(uint32_t, uint32_t);
 static int           g_active;
 static unsigned long g_pictures;
 
 static void report(void) { fprintf(stderr, "svt_hip_bind_tpl: %lu pictures through svt_hip_tpl_dispenser_frame\n", g_pictures); }
 
 void svt_hip_bind_tpl_setup(void *(*sym)(const char *)) {
-    g_api.malloc_    = (int32_t(*)(void **, size_t))sym("svt_hip_malloc");
-    g_api.free_      = (int32_t(*)(void *))sym("svt_hip_free");
-    g_api.upload     = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_upload");
-    g_api.download   = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_download");
-    g_api.memset_    = (int32_t(*)(void *, int32_t, size_t, void *))sym("svt_hip_memset");
-    g_api.sync       = (int32_t(*)(void *))sym("svt_hip_stream_sync");
-    g_api.tpl_frame  = (int32_t(*)(const SvtHipTplFrameJob *, void *))sym("svt_hip_tpl_dispenser_frame");
-    g_api.ws_bytes   = (uint64_t(*)(uint32_t, uint32_t))sym("svt_hip_tpl_workspace_bytes");
-    g_api.last_error = (const char *(*)(void))sym("svt_hip_last_error");
-    const char *env  = getenv("SVTAV1_HIP_TIERB_TPL");
-    g_active = env && atoi(env) && g_api.malloc_ && g_api.free_ && g_api.upload && g_api.download && g_api.memset_ && g_api.sync &&
-        g_api.tpl_frame && g_api.ws_bytes;
+    p_tpl_frame     = (int32_t(*)(const SvtHipTplFrameJob *, void *))sym("svt_hip_tpl_dispenser_frame");
+    p_ws_bytes      = (uint64_t(*)(uint32_t, uint32_t))sym("svt_hip_tpl_workspace_bytes");
+    p_status_offset = (uint64_t(*)(uint32_t, uint32_t))sym("svt_hip_tpl_status_offset");
+    g_active        = hd_env_on("SVTAV1_HIP_TIERB_TPL") && g_hd.ok && p_tpl_frame && p_ws_bytes && p_status_offset;
     if (g_active)
         atexit(report);
 }
 
-typedef struct TplEntry {
-    PictureParentControlSet *pcs;
-    uint64_t                 picture_number;
-    int32_t                  frame_idx;
-    int                      state; /* 0 free, 1 being computed, 2 done on the GPU, 3 not covered / failed */
-    uint32_t                 seen, total;
-} TplEntry;
-#define N_TPL 16
-static TplEntry        g_tab[N_TPL];
-static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t  g_cv = PTHREAD_COND_INITIALIZER;
+static HdOnceTable g_tab;
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t luma_bytes(const EbPictureBufferDesc *d) { return (size_t)d->stride_y * (d->height + 2u * d->org_y); }
@@ -98,23 +73,21 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
     const uint32_t stored = pcs->enable_me_16x16 ? (pcs->enable_me_8x8 ? 85u : 21u) : 5u;
     const size_t   n_mv = (size_t)nb * stored * med->max_refs * 4, n_cand = (size_t)nb * stored * med->max_cand, n_cnt = (size_t)nb * stored;
     const size_t   n_stats = (size_t)a16 * rows16 * sizeof(SvtHipTplStats), n_sst = (size_t)a16 * rows16 * sizeof(SvtHipTplSrcStats);
-    const uint64_t wsb = g_api.ws_bytes(W, H);
-    /* every uploaded array takes al256(bytes + 64) (PUT below); the statistics grid and the workspace al256(bytes) */
-    size_t         need = al256(luma_bytes(src) + 64) + al256(luma_bytes(recon) + 64) + al256(n_mv + 64) + al256(n_cand + 64) + al256(n_cnt + 64) +
-        al256(n_stats) + al256(n_sst + 64) + al256(wsb);
+    const uint64_t wsb = p_ws_bytes(W, H);
     EbPictureBufferDesc *rsrc[2][4] = {{0}}, *rrec[2][4] = {{0}};
+    uint64_t             rrec_poc[2][4] = {{0}};
     for (int l = 0; l < 2; l++)
         for (int r = 0; r < 4; r++) {
             EbPictureBufferDesc *p = (EbPictureBufferDesc *)pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_ptr;
             if (!p || !p->buffer_y)
                 continue;
-            rsrc[l][r] = p, need += al256(luma_bytes(p) + 64);
+            rsrc[l][r] = p;
             if (pcs->tpl_data.ref_in_slide_window[l][r]) {
                 const uint64_t poc = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
                 uint32_t       k = 0;
                 while (k < MAX_TPL_LA_SW && enc->poc_map_idx[k] != poc) k++;
                 if (k < MAX_TPL_LA_SW && enc->mc_flow_rec_picture_buffer[k])
-                    rrec[l][r] = enc->mc_flow_rec_picture_buffer[k], need += al256(luma_bytes(rrec[l][r]) + 64);
+                    rrec[l][r] = enc->mc_flow_rec_picture_buffer[k], rrec_poc[l][r] = poc;
             }
         }
     /* host-side staging of the scattered inputs: the ME results live in one MeSbResults per block */
@@ -133,17 +106,25 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
         h_sst[i].mv_row = q->mv.row, h_sst[i].mv_col = q->mv.col, h_sst[i].best_rf_idx = q->best_rf_idx, h_sst[i].best_mode = q->best_mode;
         h_sst[i].best_intra_mode = (uint8_t)q->best_intra_mode;
     }
-    uint8_t *dev = NULL;
-    int      rc  = g_api.malloc_((void **)&dev, need);
-    size_t   off = 0;
-#define PUT(dst, hostp, n) (dst = dev + off, off += al256((n) + 64), g_api.upload(dst, hostp, n, NULL))
+    /* device side: the picture's own scratch (ME results, statistics, reconstruction, workspace) in one allocation; the source
+     * picture, the references' source pictures and their TPL reconstructions from the device-resident mirrors */
+    const size_t n_rec = luma_bytes(recon);
+    const size_t need  = al256(n_rec + 64) + al256(n_mv + 64) + al256(n_cand + 64) + al256(n_cnt + 64) + al256(n_stats) + al256(n_sst + 64) + al256(wsb);
+    uint8_t     *dev   = hd_alloc(need);
+    int          rc    = dev ? 0 : -1;
+    size_t       off   = 0;
+    const void  *pinned[1 + 2 * 2 * 4];
+    int          n_pinned = 0;
+#define PUT(dst, hostp, n) (dst = dev + off, off += al256((n) + 64), hd_upload(dst, hostp, n))
+#define MIRROR(dst, hostp, n, tag) ((dst = hd_mirror_get(hostp, n, tag)) ? (pinned[n_pinned++] = (hostp), 0) : -1)
     uint8_t *d_src = NULL, *d_rec = NULL, *d_mv = NULL, *d_cand = NULL, *d_cnt = NULL, *d_st = NULL, *d_sst = NULL, *d_p = NULL;
     if (rc == 0)
-        rc = PUT(d_src, src->buffer_y, luma_bytes(src)) | PUT(d_rec, recon->buffer_y, luma_bytes(recon)) | PUT(d_mv, h_mv, n_mv) |
-            PUT(d_cand, h_cand, n_cand) | PUT(d_cnt, h_cnt, n_cnt) | PUT(d_sst, h_sst, n_sst);
+        rc = MIRROR(d_src, src->buffer_y, luma_bytes(src), HD_TAG(pcs->picture_number, HD_ST_FILTERED));
+    if (rc == 0) /* the reconstruction buffer keeps what the kernel does not write (its padding) */
+        rc = PUT(d_rec, recon->buffer_y, n_rec) | PUT(d_mv, h_mv, n_mv) | PUT(d_cand, h_cand, n_cand) | PUT(d_cnt, h_cnt, n_cnt) | PUT(d_sst, h_sst, n_sst);
     if (rc == 0) {
         d_st = dev + off, off += al256(n_stats);
-        rc   = g_api.memset_(d_st, 0, n_stats, NULL);
+        rc   = g_hd.memset_(d_st, 0, n_stats, NULL);
     }
     job->src.buf = d_src, job->src.stride = src->stride_y, job->src.org_x = src->org_x, job->src.org_y = src->org_y, job->src.width = (uint16_t)W,
     job->src.height = (uint16_t)H;
@@ -154,19 +135,25 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
                 continue;
             SvtHipTplRef        *f = &job->ref[l][r];
             EbPictureBufferDesc *p = rsrc[l][r];
-            rc                     = PUT(d_p, p->buffer_y, luma_bytes(p));
+            const uint64_t       poc = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
+            rc                       = MIRROR(d_p, p->buffer_y, luma_bytes(p), HD_TAG(poc, HD_ST_FILTERED));
+            if (rc != 0)
+                break;
             f->src = d_p + (size_t)p->org_y * p->stride_y + p->org_x, f->src_stride = p->stride_y;
             f->recon = f->src, f->recon_stride = f->src_stride;
-            if (rc == 0 && rrec[l][r]) {
+            if (rrec[l][r]) {
                 EbPictureBufferDesc *q = rrec[l][r];
-                rc                     = PUT(d_p, q->buffer_y, luma_bytes(q));
+                rc                     = MIRROR(d_p, q->buffer_y, luma_bytes(q), HD_TAG(rrec_poc[l][r], HD_ST_TPL_RECON));
+                if (rc != 0)
+                    break;
                 f->recon = d_p + (size_t)q->org_y * q->stride_y + q->org_x, f->recon_stride = q->stride_y;
             }
-            f->picture_number = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
+            f->picture_number = poc;
             f->max_width = p->max_width, f->max_height = p->max_height;
             const int32_t grp = pcs->tpl_data.ref_tpl_group_idx[l][r];
             f->usable = !(grp > 0 && pcs->tpl_data.base_pcs->tpl_valid_pic[grp] == 0);
         }
+    uint8_t *h_rec = NULL;
     if (rc == 0) {
         job->me_mv_array = (const uint32_t *)d_mv, job->me_candidate_array = d_cand, job->total_me_candidate_index = d_cnt;
         job->max_cand = med->max_cand, job->max_refs = med->max_refs, job->max_l0 = med->max_l0;
@@ -183,12 +170,28 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
         }
         job->stats = (SvtHipTplStats *)d_st, job->src_stats = (SvtHipTplSrcStats *)d_sst;
         job->workspace = dev + off, job->workspace_bytes = wsb;
-        rc = g_api.tpl_frame(job, NULL);
+        rc = p_tpl_frame(job, NULL);
     }
     if (rc == 0) {
-        rc = g_api.download(recon->buffer_y, d_rec, luma_bytes(recon), NULL) | g_api.download(h_st, d_st, n_stats, NULL) |
-            g_api.download(h_sst, d_sst, n_sst, NULL) | g_api.sync(NULL);
+        /* everything comes back into host staging first; the status word says whether a dependency wait inside the kernel ran into
+         * its bound (the kernel then went on with unsynchronised neighbours: the results are unusable and the CPU loop runs) */
+        uint32_t status = 1;
+        h_rec = (uint8_t *)malloc(n_rec);
+        rc = h_rec ? (hd_download(h_rec, d_rec, n_rec) | hd_download(h_st, d_st, n_stats) | hd_download(h_sst, d_sst, n_sst) |
+                      hd_download(&status, (uint8_t *)job->workspace + p_status_offset(W, H), 4) | hd_sync())
+                   : -1;
+        if (rc == 0 && status != 0) {
+            fprintf(stderr, "svt_hip_bind_tpl: picture %llu: a dependency wait of the kernel timed out\n", (unsigned long long)pcs->picture_number);
+            rc = -1;
+        }
+        if (rc == 0)
+            memcpy(recon->buffer_y, h_rec, n_rec);
+    } else {
+        hd_sync();
     }
+    for (int i = 0; i < n_pinned; i++) hd_mirror_unpin(pinned[i]);
+#undef PUT
+#undef MIRROR
     if (rc == 0) {
         /* result_model_store (src_ops_process.c:266-340) from the one-cell-per-block grid, and the source-based statistics, block by
          * block in the reference's order (64x64 blocks raster, blocks in z-order inside: with 16x16 blocks a 32x32 synthesizer cell
@@ -243,45 +246,35 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
         }
     }
     if (rc != 0)
-        fprintf(stderr, "svt_hip_bind_tpl: picture %llu stays on the CPU (%s)\n", (unsigned long long)pcs->picture_number,
-                g_api.last_error ? g_api.last_error() : "?");
-    if (dev)
-        g_api.free_(dev);
-    free(h_mv), free(h_cand), free(h_cnt), free(h_sst), free(h_st), free(job);
+        fprintf(stderr, "svt_hip_bind_tpl: picture %llu stays on the CPU (%s)\n", (unsigned long long)pcs->picture_number, hd_error());
+    else
+        hd_count_picture();
+    hd_free(dev);
+    free(h_rec), free(h_mv), free(h_cand), free(h_cnt), free(h_sst), free(h_st), free(job);
     return rc != 0;
 }
 
 /* Returns 0 when the picture's dispenser ran on the GPU (the caller skips its per-block call), 1 when the caller must run it. */
 int svt_hip_bind_tpl_sb(PictureParentControlSet *pcs, int32_t frame_idx, uint32_t sb_index, int32_t qindex) {
     (void)sb_index;
-    if (!g_active)
+    if (!g_hd.ok)
         return 1;
-    pthread_mutex_lock(&g_mu);
-    TplEntry *e = NULL, *fr = NULL;
-    for (int i = 0; i < N_TPL; i++) {
-        if (g_tab[i].state && g_tab[i].pcs == pcs && g_tab[i].picture_number == pcs->picture_number && g_tab[i].frame_idx == frame_idx)
-            e = &g_tab[i];
-        else if (!g_tab[i].state && !fr)
-            fr = &g_tab[i];
+    /* this picture's TPL reconstruction is rewritten now (GPU or CPU; a picture is dispensed again when it belongs to the next TPL
+     * group too): the first block forgets the mirror other pictures' dispensers used */
+    int     first;
+    HdOnce *once = hd_once_enter(&g_tab, pcs, ((uint64_t)pcs->picture_number << 8) | (uint32_t)(frame_idx & 0xff), pcs->b64_total_count, &first);
+    if (!once)
+        return 1;
+    if (first) {
+        EbPictureBufferDesc *recon = pcs->scs->enc_ctx->mc_flow_rec_picture_buffer[frame_idx];
+        if (recon)
+            hd_mirror_drop(recon->buffer_y);
+        const int rc = g_active ? run_picture(pcs, frame_idx, qindex) : 1;
+        if (rc == 0)
+            __atomic_add_fetch(&g_pictures, 1, __ATOMIC_RELAXED);
+        hd_once_done(once, rc == 0, NULL);
     }
-    if (!e) {
-        if (!fr) {
-            pthread_mutex_unlock(&g_mu);
-            return 1;
-        }
-        e = fr;
-        e->pcs = pcs, e->picture_number = pcs->picture_number, e->frame_idx = frame_idx, e->state = 1, e->seen = 0, e->total = pcs->b64_total_count;
-        pthread_mutex_unlock(&g_mu);
-        const int rc = run_picture(pcs, frame_idx, qindex);
-        pthread_mutex_lock(&g_mu);
-        e->state = rc == 0 ? 2 : 3;
-        g_pictures += rc == 0;
-        pthread_cond_broadcast(&g_cv);
-    }
-    while (e->state == 1) pthread_cond_wait(&g_cv, &g_mu);
-    const int on_gpu = e->state == 2;
-    if (++e->seen >= e->total)
-        memset(e, 0, sizeof(*e));
-    pthread_mutex_unlock(&g_mu);
+    const int on_gpu = hd_once_ok(once);
+    hd_once_release(&g_tab, once, NULL);
     return on_gpu ? 0 : 1;
 }

@@ -4,7 +4,7 @@
 // profiles/ (r03_ubench_valu_issue.txt).  Every kernel runs CH independent chains of ONE instruction (inline asm, so the
 // instruction timed is the instruction named); a workgroup is 256 threads = one wave on each of the CU's four SIMDs, and the
 // dynamic LDS size pins the number of workgroups per CU, i.e. the waves per SIMD.  Reported: ns per wave-instruction per SIMD
-// (= elapsed / instructions each SIMD issued) and the same in cycles at the clock measured by an s_memtime pair.
+// (= elapsed / instructions each SIMD issued; the best of three launches of ~0.5 ms or more).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -83,27 +83,22 @@ CHAIN64(v_add_f64, "v_add_f64 %0, %0, %0")
 CHAIN64(v_fma_f64, "v_fma_f64 %0, %0, %0, %0")
 
 template <class OP, class ACC>
-__global__ __launch_bounds__(256) void k(unsigned *out, unsigned seed, unsigned long long *clk) {
+__global__ __launch_bounds__(256) void k(unsigned *out, unsigned seed, int iters) {
     extern __shared__ unsigned char pin[];  // only its size matters (workgroups per CU)
     ACC      a[CH];
     unsigned x = seed + threadIdx.x, y = seed * 3 + threadIdx.x;
     const unsigned long long m = 0x5555555555555555ull ^ seed;
     for (int c = 0; c < CH; c++) a[c] = c + x;
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int i = 0; i < IT; i++) {
+    for (int i = 0; i < iters; i++) {
 #pragma unroll
         for (int c = 0; c < CH; c++) OP::op(a[c], x, y, m);
     }
-    const unsigned long long t1 = __builtin_readcyclecounter();
     ACC s = 0;
     for (int c = 0; c < CH; c++) s += a[c];
     out[blockIdx.x * 256 + threadIdx.x] = (unsigned)s + pin[threadIdx.x & 3] * 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        clk[0] = t1 - t0;
 }
 
 static unsigned           *d_out;
-static unsigned long long *d_clk;
 static int                 n_cu = 256;
 static const size_t        LDS_CU = 160 * 1024;
 
@@ -117,23 +112,20 @@ void run(int per_inst = 1) {
         const int  blocks = n_cu * w;
         hipEvent_t e0, e1;
         hipEventCreate(&e0), hipEventCreate(&e1);
-        hipLaunchKernelGGL((k<OP, ACC>), dim3(blocks), dim3(256), lds, 0, d_out, 1u, d_clk);
+        const int iters = IT * 8 / w;  // the same number of wave-instructions per SIMD at every occupancy: ~0.5 ms per launch or more
+        hipLaunchKernelGGL((k<OP, ACC>), dim3(blocks), dim3(256), lds, 0, d_out, 1u, iters);
         float best = 1e30f;
         for (int rep = 0; rep < 3; rep++) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL((k<OP, ACC>), dim3(blocks), dim3(256), lds, 0, d_out, 2u + rep, d_clk);
+            hipLaunchKernelGGL((k<OP, ACC>), dim3(blocks), dim3(256), lds, 0, d_out, 2u + rep, iters);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
             best = ms < best ? ms : best;
         }
-        unsigned long long clk = 0;
-        hipMemcpy(&clk, d_clk, 8, hipMemcpyDeviceToHost);
-        const double inst_per_simd = (double)w * CH * IT * per_inst;  // wave-instructions each SIMD issues
-        // s_memtime ticks at 100 MHz on this part (constant clock), so the in-kernel figure is also a time: ns per instruction of
-        // ONE wave (its own stream, other waves interleaved)
-        printf("  w=%d %6.3f ns/inst/SIMD (wave's own %6.2f ns)", w, best * 1e6 / inst_per_simd, clk * 10.0 / (CH * IT * per_inst));
+        const double inst_per_simd = (double)w * CH * iters * per_inst;  // wave-instructions each SIMD issues
+        printf("  w=%d %6.3f", w, best * 1e6 / inst_per_simd);
         hipEventDestroy(e0), hipEventDestroy(e1);
     }
     printf("\n");
@@ -147,7 +139,6 @@ int main() {
     printf("# %s, %d CUs, clockRate %d kHz; %d chains x %d iterations per lane; ns per wave-instruction per SIMD at w waves per SIMD\n", p.gcnArchName,
            n_cu, p.clockRate, CH, IT);
     hipMalloc(&d_out, (size_t)n_cu * 8 * 256 * 4);
-    hipMalloc(&d_clk, 64);
 #define R(op) run<op, unsigned>()
 #define R64(op) run<op, unsigned long long>()
     R(v_add_u32); R(v_sub_u32); R(v_and_b32); R(v_xor_b32); R(v_lshlrev_b32); R(v_ashrrev_i32); R(v_max_i32); R(v_min_u32); R(v_mov_b32);
