@@ -30,7 +30,15 @@ TIER_B_CASES = {
     "p8_8bit_ragged": (424, 232, 17, 8, 8),
     "p10_10bit_ragged": (376, 216, 10, 10, 10),   # preset 10 = tpl level 5: an even number of 16x16 columns / rows, see svt_hip_bind_tpl.c
 }
-ALL_CASES = dict(CASES, **TIER_B_CASES)
+# clips for the in-loop-filter and picture-analysis hooks (row h): presets where each stage runs its search (frame-level
+# deblocking with the level search at <= M5 and on base-layer pictures at M6, Wiener at M4 - M8, self-guided restoration at <= M3, CDEF
+# everywhere), 8 and 10 bit, <= 10 frames
+LF_CASES = {
+    "p5_8bit_lf": (256, 192, 6, 8, 5),
+    "p6_10bit_lf": (256, 192, 7, 10, 6),   # BASELINE.json configs[3]'s preset
+    "p3_8bit_lf": (192, 128, 3, 8, 3),
+}
+ALL_CASES = dict(CASES, **TIER_B_CASES, **LF_CASES)
 
 
 def have_app():

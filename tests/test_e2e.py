@@ -136,3 +136,73 @@ def test_batched_paths_ragged_clip(hip, case, lp):
     assert "stays on the CPU" not in log and "falls back" not in log
     g = E.golden()[case]
     assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.parametrize("case", list(E.LF_CASES))
+def test_c_path_reproduces_golden_lf(case):
+    """CPU: the md5s of the in-loop-filter clips are the reference's C path."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, _ = E.encode(case, d, "c", lp=2)
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}
+
+
+@needs_app
+@pytest.mark.parametrize("case", ["p8_8bit", "p8_10bit", "p6_10bit_lf", "p10_10bit_ragged"])
+def test_deferred_sb_deblocking_equals_the_sb_schedule(case):
+    """CPU: the patch moves SB-based deblocking (presets M6 and faster, coding_loop.c:2260-2281) out of the EncDec loop into ONE
+    svt_av1_loop_filter_frame call in dlf_process.c whenever the GPU hook is active.  SVTAV1_HIP_DLF_DEFER_TEST=1 makes that move
+    with the reference's own C loops doing the frame call: the bitstream must not change (several EncDec threads)."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, _ = E.encode(case, d, "c", lp=4, env_extra={"SVTAV1_HIP_DLF_DEFER_TEST": "1"})
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}
+
+
+LF_ENV = {"SVTAV1_HIP_TIERB_PA": "1", "SVTAV1_HIP_TIERB_DLF": "1", "SVTAV1_HIP_TIERB_CDEF": "1", "SVTAV1_HIP_TIERB_LR": "1"}
+
+
+@needs_app
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,lp,wiener", [("p12_8bit", 2, False), ("p8_8bit", 4, True), ("p8_10bit", 2, True), ("p5_8bit_lf", 3, True),
+                                            ("p6_10bit_lf", 4, True), ("p3_8bit_lf", 2, None), ("p8_8bit_ragged", 4, True)])
+def test_batched_in_loop_filters_bitstream_md5(hip, case, lp, wiener):
+    """GPU, Tier B inside the real encoder (INTEGRATION.md steps 2a and 4, row h of the coverage table): pyramid + block variances
+    of the picture-analysis kernel, frame deblocking (the level search's trials included; SB-based deblocking deferred to one frame
+    call), CDEF search and application, Wiener statistics and the final restoration pass through their whole-picture entry points
+    (tools/e2e/svt_hip_bind_pa.c, svt_hip_bind_lf.c), no Tier A leaves.  Same bitstream and reconstruction as the C-only encode."""
+    env = dict(LF_ENV, SVTAV1_HIP_ONLY="__none__")
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra=env)
+    E.assert_hip_ran_clean(log)
+    assert "stays on the CPU" not in log, log[-2000:]
+    m = re.search(r"svt_hip_bind_lf: (\d+) frame deblocking calls, (\d+) CDEF searches, (\d+) CDEF applications, (\d+) Wiener statistics planes, "
+                  r"(\d+) restoration", log)
+    assert m, log[-2000:]
+    dlf, cdef_s, cdef_a, wn, lr = map(int, m.groups())
+    assert dlf >= 1 and cdef_s >= 1, (case, m.groups())
+    if wiener:
+        assert wn >= 1 and lr >= 1, (case, m.groups())
+    m = re.search(r"svt_hip_bind_pa: (\d+) pyramids, (\d+) variance maps", log)
+    w, h, n, bd, preset = E.ALL_CASES[case]
+    assert m and int(m.group(1)) == n and int(m.group(2)) == n, log[-2000:]
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched in-loop filters {m.groups()}\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,lp", [("p8_10bit", 3), ("p6_10bit_lf", 4), ("p10_10bit_ragged", 3)])
+def test_every_batched_path_together(hip, case, lp):
+    """GPU: picture analysis, open-loop ME, temporal filter, TPL dispenser, deblocking, CDEF, restoration — every whole-picture entry
+    point that is wired, together, sharing the device-resident picture mirrors (each hit compared with the host buffer)."""
+    env = dict(LF_ENV, SVTAV1_HIP_TIERB_ME="1", SVTAV1_HIP_TIERB_TF="1", SVTAV1_HIP_TIERB_TPL="1", SVTAV1_HIP_ONLY="__none__")
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra=env)
+    E.assert_hip_ran_clean(log)
+    assert "stays on the CPU" not in log and "falls back" not in log, log[-2000:]
+    m = re.search(r"mirrors: (\d+) hits", log)
+    assert m and int(m.group(1)) > 0, log[-1500:]
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs\n{log[-1500:]}"

@@ -75,13 +75,127 @@ def patch_src_ops_process(t):
     return edit(t, old, new)
 
 
+def patch_deblocking_filter(t):
+    """Step 4a: the whole-picture deblocking in front of the SB loop of svt_av1_loop_filter_frame (also reached by every trial of
+    the level search through try_filter_frame)."""
+    t = edit(t, '#include "deblocking_filter.h"\n', '#include "deblocking_filter.h"\n#include "svt_hip_bind.h"\n')
+    old = ("    uint32_t picture_height_in_sb = (pcs->ppcs->aligned_height + scs->sb_size - 1) / scs->sb_size;\n\n"
+           "    svt_av1_loop_filter_frame_init(&pcs->ppcs->frm_hdr, &pcs->ppcs->lf_info, plane_start, plane_end);\n")
+    new = ("    uint32_t picture_height_in_sb = (pcs->ppcs->aligned_height + scs->sb_size - 1) / scs->sb_size;\n\n"
+           "    if (svt_hip_bind_dlf_frame(frame_buffer, pcs, plane_start, plane_end) == 0)\n"
+           "        return;\n"
+           "    svt_av1_loop_filter_frame_init(&pcs->ppcs->frm_hdr, &pcs->ppcs->lf_info, plane_start, plane_end);\n")
+    return edit(t, old, new)
+
+
+def patch_coding_loop(t):
+    """Step 4a, SB-based deblocking (presets M6 and faster): the per-SB filter call is left out when the frame call of
+    dlf_process.c takes over (svt_hip_bind_dlf_deferred)."""
+    t = edit(t, '#include "coding_loop.h"\n', '#include "coding_loop.h"\n#include "svt_hip_bind.h"\n')
+    old = "            svt_aom_loop_filter_sb(recon_buffer, pcs, sb_org_y >> 2, sb_org_x >> 2, 0, 3, last_col);\n"
+    new = "            if (!svt_hip_bind_dlf_deferred())\n    " + old
+    return edit(t, old, new)
+
+
+def patch_dlf_process(t):
+    """Step 4a: ... and the frame call that replaces the per-SB calls (levels were picked from Q at the first SB, coding_loop.c:2265-2270)."""
+    t = edit(t, '#include "dlf_process.h"\n', '#include "dlf_process.h"\n#include "svt_hip_bind.h"\n')
+    old = "            svt_av1_loop_filter_frame(recon_buffer, pcs, 0, 3);\n        }\n"
+    new = (old[:-len("        }\n")] +
+           "        } else if (dlf_enable_flag && tg_count == 1 && svt_hip_bind_dlf_deferred() &&\n"
+           "                   (pcs->ppcs->frm_hdr.loop_filter_params.filter_level[0] || pcs->ppcs->frm_hdr.loop_filter_params.filter_level[1])) {\n"
+           "            EbPictureBufferDesc *recon_buffer;\n"
+           "            svt_aom_get_recon_pic(pcs, &recon_buffer, is_16bit);\n"
+           "            svt_av1_loop_filter_frame(recon_buffer, pcs, 0, 3);\n"
+           "        }\n")
+    return edit(t, old, new)
+
+
+def patch_cdef_process(t):
+    """Step 4b: the whole-picture CDEF search in front of the filter-block loop of cdef_seg_search."""
+    t = edit(t, '#include "cdef_process.h"\n', '#include "cdef_process.h"\n#include "svt_hip_bind.h"\n')
+    old = ("static void cdef_seg_search(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index) {\n"
+           "    struct PictureParentControlSet *ppcs     = pcs->ppcs;\n")
+    new = ("static void cdef_seg_search(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index) {\n"
+           "    if (svt_hip_bind_cdef_seg(pcs, scs, segment_index) == 0)\n"
+           "        return;\n"
+           "    struct PictureParentControlSet *ppcs     = pcs->ppcs;\n")
+    return edit(t, old, new)
+
+
+def patch_enc_cdef(t):
+    """Step 4b: the whole-picture CDEF application in front of svt_av1_cdef_frame's filter-block loop."""
+    t = edit(t, '#include "enc_cdef.h"\n', '#include "enc_cdef.h"\n#include "svt_hip_bind.h"\n')
+    old = ("void svt_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs) {\n"
+           "    struct PictureParentControlSet *ppcs     = pcs->ppcs;\n")
+    new = ("void svt_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs) {\n"
+           "    if (svt_hip_bind_cdef_frame(scs, pcs) == 0)\n"
+           "        return;\n"
+           "    struct PictureParentControlSet *ppcs     = pcs->ppcs;\n")
+    return edit(t, old, new)
+
+
+def patch_restoration(t):
+    """Step 4e: the whole-picture restoration in front of svt_av1_loop_restoration_filter_frame's plane loop."""
+    t = edit(t, '#include "restoration.h"\n', '#include "restoration.h"\n#include "svt_hip_bind.h"\n')
+    old = ("    static const CopyFun copy_funs[3] = {\n"
+           "        svt_aom_yv12_copy_y_c, svt_aom_yv12_copy_u_c, svt_aom_yv12_copy_v_c}; //CHKN SSE\n\n")
+    new = old + ("    if (svt_hip_bind_lr_frame(frame, cm, optimized_lr) == 0)\n"
+                 "        return;\n")
+    return edit(t, old, new)
+
+
+def patch_restoration_pick(t):
+    """Step 4d: the Wiener statistics of a whole plane in front of svt_av1_compute_stats(_highbd) in search_wiener_seg."""
+    t = edit(t, '#include "restoration_pick.h"\n', '#include "restoration_pick.h"\n#include "svt_hip_bind.h"\n')
+    old = ("        int32_t              vfilterd[WIENER_WIN], hfilterd[WIENER_WIN];\n\n"
+           "        if (cm->use_highbitdepth)\n"
+           "            svt_av1_compute_stats_highbd(wiener_win,\n")
+    new = ("        int32_t              vfilterd[WIENER_WIN], hfilterd[WIENER_WIN];\n\n"
+           "        if (svt_hip_bind_wiener_stats(cm->child_pcs, rsc->plane, rest_unit_idx, wiener_win, rsc->dgd_buffer, rsc->src_buffer, limits,\n"
+           "                                      rsc->dgd_stride, rsc->src_stride, cm->use_highbitdepth, cm->bit_depth, M, H) == 0)\n"
+           "            ;\n"
+           "        else if (cm->use_highbitdepth)\n"
+           "            svt_av1_compute_stats_highbd(wiener_win,\n")
+    assert t.count(old) >= 1
+    i = t.index(old, t.index("static void search_wiener_seg("))
+    return t[:i] + new + t[i + len(old):]
+
+
+def patch_pic_analysis_process(t):
+    """Step 2a: pyramid and block variances of a whole picture in front of the reference's own loops."""
+    t = edit(t, '#include "pic_analysis_process.h"\n', '#include "pic_analysis_process.h"\n#include "svt_hip_bind.h"\n')
+    old = ("    // Downsample input picture for HME L0 and L1\n"
+           "    if (pcs->enable_hme_flag || pcs->tf_enable_hme_flag) {\n")
+    new = ("    if (svt_hip_bind_pa_pyramid(pcs, input_padded_pic, quarter_picture_ptr, sixteenth_picture_ptr) == 0)\n"
+           "        return;\n" + old)
+    t = edit(t, old, new)
+    old = ("    uint16_t b64_total_count  = pcs->b64_total_count;\n\n"
+           "    for (uint16_t b64_idx = 0; b64_idx < b64_total_count; ++b64_idx) {\n"
+           "        B64Geom *b64_geom = &pcs->b64_geom[b64_idx];\n")
+    new = ("    uint16_t b64_total_count  = pcs->b64_total_count;\n\n"
+           "    if (svt_hip_bind_pa_variance(scs, pcs, input_padded_pic) == 0)\n"
+           "        return;\n"
+           "    for (uint16_t b64_idx = 0; b64_idx < b64_total_count; ++b64_idx) {\n"
+           "        B64Geom *b64_geom = &pcs->b64_geom[b64_idx];\n")
+    return edit(t, old, new)
+
+
 def main():
     pieces = []
     for rel, fn in (("Source/Lib/Globals/enc_settings.c", patch_enc_settings),
                     ("Source/Lib/Globals/enc_handle.c", patch_enc_handle),
                     ("Source/Lib/Codec/me_process.c", patch_me_process),
                     ("Source/Lib/Codec/temporal_filtering.c", patch_temporal_filtering),
-                    ("Source/Lib/Codec/src_ops_process.c", patch_src_ops_process)):
+                    ("Source/Lib/Codec/src_ops_process.c", patch_src_ops_process),
+                    ("Source/Lib/Codec/pic_analysis_process.c", patch_pic_analysis_process),
+                    ("Source/Lib/Codec/deblocking_filter.c", patch_deblocking_filter),
+                    ("Source/Lib/Codec/coding_loop.c", patch_coding_loop),
+                    ("Source/Lib/Codec/dlf_process.c", patch_dlf_process),
+                    ("Source/Lib/Codec/cdef_process.c", patch_cdef_process),
+                    ("Source/Lib/Codec/enc_cdef.c", patch_enc_cdef),
+                    ("Source/Lib/Codec/restoration_pick.c", patch_restoration_pick),
+                    ("Source/Lib/Codec/restoration.c", patch_restoration)):
         with open(os.path.join(REF, rel), encoding="utf-8", errors="surrogateescape") as f:
             a = f.read()
         b = fn(a)

@@ -41,4 +41,30 @@ void svt_hip_bind_tf_setup(void *(*sym)(const char *));
 int  svt_hip_bind_tpl_sb(struct PictureParentControlSet *pcs, int32_t frame_idx, uint32_t sb_index, int32_t qindex);
 void svt_hip_bind_tpl_setup(void *(*sym)(const char *));
 
+
+/* Step 2a (svt_hip_bind_pa.c): pyramid and block variances of the picture-analysis kernel through svt_hip_pyramid_frame /
+ * svt_hip_variance_frame.  0 = done on the GPU, 1 = the caller runs its own code. */
+struct SequenceControlSet;
+int  svt_hip_bind_pa_pyramid(struct PictureParentControlSet *pcs, struct EbPictureBufferDesc *full, struct EbPictureBufferDesc *quarter,
+                             struct EbPictureBufferDesc *sixteenth);
+int  svt_hip_bind_pa_variance(struct SequenceControlSet *scs, struct PictureParentControlSet *pcs, struct EbPictureBufferDesc *full);
+void svt_hip_bind_pa_setup(void *(*sym)(const char *));
+
+/* Step 4 (svt_hip_bind_lf.c): the in-loop filters of a whole picture.  0 = done on the GPU, 1 = the caller runs its own code.
+ * svt_hip_bind_dlf_deferred() != 0: SB-based deblocking is left out of the EncDec loop (coding_loop.c) and dlf_process.c makes one
+ * frame call instead. */
+struct PictureControlSet;
+struct Av1Common;
+struct Yv12BufferConfig;
+struct RestorationTileLimits;
+int  svt_hip_bind_dlf_deferred(void);
+int  svt_hip_bind_dlf_frame(struct EbPictureBufferDesc *frame_buffer, struct PictureControlSet *pcs, int32_t plane_start, int32_t plane_end);
+int  svt_hip_bind_cdef_seg(struct PictureControlSet *pcs, struct SequenceControlSet *scs, uint32_t segment_index);
+int  svt_hip_bind_cdef_frame(struct SequenceControlSet *scs, struct PictureControlSet *pcs);
+int  svt_hip_bind_wiener_stats(struct PictureControlSet *pcs, int plane, int rest_unit_idx, int wiener_win, const uint8_t *dgd, const uint8_t *src,
+                               const struct RestorationTileLimits *limits, int dgd_stride, int src_stride, int highbd, int bit_depth, int64_t *M,
+                               int64_t *H);
+int  svt_hip_bind_lr_frame(struct Yv12BufferConfig *frame, struct Av1Common *cm, int32_t optimized_lr);
+void svt_hip_bind_lf_setup(void *(*sym)(const char *));
+
 #endif

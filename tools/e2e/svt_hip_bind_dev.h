@@ -54,7 +54,9 @@ enum {
     HD_ST_TPL_RECON = 7,  /* mc_flow_rec_picture_buffer of a picture, after its dispenser */
     HD_ST_MI_LF     = 8,  /* gathered SvtHipLfMi grid of a picture */
     HD_ST_MI_SKIP   = 9,  /* gathered 8x8 skip bitmap (CDEF) */
-    HD_ST_SOURCE16  = 10, /* pcs->input_frame16bit */
+    HD_ST_SOURCE16  = 10, /* pcs->input_frame16bit as the CDEF stage sees it */
+    HD_ST_CDEF_EXT  = 11, /* reconstruction after CDEF with the borders the restoration search extended (restoration_pick.c:1511) */
+    HD_ST_SOURCE16_LR = 12, /* pcs->input_frame16bit after set_unscaled_input_16bit (cdef_process.c:418) */
 };
 #define HD_TAG(picture_number, stage) (((uint64_t)(picture_number) << 8) | (uint64_t)(stage))
 
