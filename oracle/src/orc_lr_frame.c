@@ -41,7 +41,8 @@ static int32_t stripe_px(const SvtHipLrPlane *pl, int x, int y, int ys, int h, i
             const int row = 2 * stripe + (i < 1 ? i : 1);
             return px(pl->boundary_below, (ptrdiff_t)row * pl->boundary_stride + x + SVT_HIP_LR_EXTRA_HORZ, is16);
         }
-        return px(pl->src, (ptrdiff_t)(i == 2 ? ys + h + 1 : y) * pl->src_stride + xc, is16);
+        const int yb = i == 2 ? ys + h + 1 : y; /* below the last picture row: its replica (svt_extend_frame) */
+        return px(pl->src, (ptrdiff_t)(yb < H ? yb : H - 1) * pl->src_stride + xc, is16);
     }
     const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y); /* svt_extend_frame: the picture's own edge rows */
     return px(pl->src, (ptrdiff_t)yc * pl->src_stride + xc, is16);

@@ -31,13 +31,16 @@ __device__ __forceinline__ int32_t stripe_px(const SvtHipLrPlane &pl, int x, int
         const int i = y - ys;  // -3 .. -1
         if (!pl.optimized_lr)
             return ldpx(pl.boundary_above, (size_t)(2 * stripe + (i + 2 > 0 ? i + 2 : 0)) * pl.boundary_stride + (x + SVT_HIP_LR_EXTRA_HORZ), is16);
-        return ldpx(pl.src, (size_t)((ptrdiff_t)(i == -3 ? ys - 2 : y) * pl.src_stride + xc), is16);
+        const int ya = i == -3 ? ys - 2 : y;
+        return ldpx(pl.src, (size_t)((ptrdiff_t)(ya > 0 ? ya : 0) * pl.src_stride + xc), is16);
     }
     if (y >= ys + h && !last) {  // copy_below
         const int i = y - (ys + h);  // 0 .. 2
         if (!pl.optimized_lr)
             return ldpx(pl.boundary_below, (size_t)(2 * stripe + (i < 1 ? i : 1)) * pl.boundary_stride + (x + SVT_HIP_LR_EXTRA_HORZ), is16);
-        return ldpx(pl.src, (size_t)((ptrdiff_t)(i == 2 ? ys + h + 1 : y) * pl.src_stride + xc), is16);
+        // the picture's own rows: below the last picture row they are its replica (svt_extend_frame), e.g. H = 64 k + 57
+        const int yb = i == 2 ? ys + h + 1 : y;
+        return ldpx(pl.src, (size_t)((ptrdiff_t)(yb < H ? yb : H - 1) * pl.src_stride + xc), is16);
     }
     const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
     return ldpx(pl.src, (size_t)((ptrdiff_t)yc * pl.src_stride + xc), is16);

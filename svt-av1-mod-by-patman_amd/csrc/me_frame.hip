@@ -285,10 +285,10 @@ __device__ void fp_search(LDS &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint
                 a11 = __builtin_amdgcn_qsad_pk_u16_u8(pair64(d3, d4), sv.w, a11);
             }
         }
-        // running minima over this lane's four positions: positions are visited in raster order, so a strict '<' on the
-        // SAD keeps the first minimum; the 64-bit (sad, order) keys are only built for the LDS update
-        uint32_t m8[4] = {~0u, ~0u, ~0u, ~0u}, o8[4] = {0, 0, 0, 0}, m16 = ~0u, o16 = 0, m32 = ~0u, o32 = 0, m64 = ~0u, o64 = 0;
-        const uint32_t ord_row = order0 + y * order_pitch + 4 * q;
+        // running minima over this lane's four positions as packed (sad << 2 | position) keys: a SAD is below 2^20, the four
+        // positions are in raster order, so the smallest key is the first minimum; the 64-bit (sad, order) keys are only built
+        // for the LDS update
+        uint32_t k8[4] = {~0u, ~0u, ~0u, ~0u}, k16 = ~0u, k32 = ~0u, k64 = ~0u;
 #pragma unroll
         for (uint32_t pp = 0; pp < 4; pp++) {
             const uint32_t lo_hi_shift = 16 * (pp & 1);
@@ -302,26 +302,23 @@ __device__ void fp_search(LDS &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint
             uint32_t s64       = dpp_add<0x124>(s32);  // row_ror:4
             s64                = dpp_add<0x128>(s64);  // row_ror:8
             if (4 * q + pp < cw) {
-                const uint32_t ord = ord_row + pp;
-                if (c0 < m8[0]) m8[0] = c0, o8[0] = ord;
-                if (c1 < m8[1]) m8[1] = c1, o8[1] = ord;
-                if (c2 < m8[2]) m8[2] = c2, o8[2] = ord;
-                if (c3 < m8[3]) m8[3] = c3, o8[3] = ord;
-                if (s16 < m16) m16 = s16, o16 = ord;
-                if (s32 < m32) m32 = s32, o32 = ord;
-                if (s64 < m64) m64 = s64, o64 = ord;
+                k8[0] = min(k8[0], (c0 << 2) | pp), k8[1] = min(k8[1], (c1 << 2) | pp);
+                k8[2] = min(k8[2], (c2 << 2) | pp), k8[3] = min(k8[3], (c3 << 2) | pp);
+                k16 = min(k16, (s16 << 2) | pp), k32 = min(k32, (s32 << 2) | pp), k64 = min(k64, (s64 << 2) | pp);
             }
         }
-        if (on && m16 != ~0u) {
+        if (on && k16 != ~0u) {
             const uint32_t sh1 = sub ? 1 : 0;  // sub-sampled rows: SAD x 2 (motion_estimation.c:520-530)
+            const uint32_t ord_row = order0 + y * order_pitch + 4 * q;
+#define FP_KEY(k) (((unsigned long long)(((k) >> 2) << sh1) << 32) | (ord_row + ((k) & 3u)))
 #pragma unroll
-            for (uint32_t c = 0; c < 4; c++)
-                atomicMin((unsigned long long *)&L.bestkey[21 + 4 * zo + c], ((unsigned long long)(m8[c] << sh1) << 32) | o8[c]);
-            atomicMin((unsigned long long *)&L.bestkey[5 + zo], ((unsigned long long)(m16 << sh1) << 32) | o16);
+            for (uint32_t c = 0; c < 4; c++) atomicMin((unsigned long long *)&L.bestkey[21 + 4 * zo + c], FP_KEY(k8[c]));
+            atomicMin((unsigned long long *)&L.bestkey[5 + zo], FP_KEY(k16));
             if ((zo & 3) == 0)
-                atomicMin((unsigned long long *)&L.bestkey[1 + (zo >> 2)], ((unsigned long long)(m32 << sh1) << 32) | o32);
+                atomicMin((unsigned long long *)&L.bestkey[1 + (zo >> 2)], FP_KEY(k32));
             if (zo == 0)
-                atomicMin((unsigned long long *)&L.bestkey[0], ((unsigned long long)(m64 << sh1) << 32) | o64);
+                atomicMin((unsigned long long *)&L.bestkey[0], FP_KEY(k64));
+#undef FP_KEY
         }
     }
     __syncthreads();
@@ -1238,24 +1235,28 @@ __device__ void finalize_b64(LDS &L, const Ctx &c) {
     __syncthreads();
 
     // ---- compute_distortion (motion_estimation.c:3034-3077) + result write-back ----
-    if (tid == 0) {
-        uint32_t d64 = L.me_dist[0], d32 = 0, d16 = 0, d8 = 0;
-        for (int i = 0; i < 4; i++) d32 += L.me_dist[1 + i];
-        for (int i = 0; i < 16; i++) d16 += L.me_dist[5 + i];
-        for (int i = 0; i < 64; i++) d8 += L.me_dist[21 + i];
+    // one wave: lane i holds the 8x8 entry i (and the 16x16 / 32x32 / 64x64 entries in its first lanes); sums by wave reductions
+    // (the sum of squared deviations in 64 bits, as the reference's uint64 accumulation)
+    if (tid < 64) {
+        const uint32_t e8 = L.me_dist[21 + tid];
+        const uint32_t d8 = wave_sum_all(e8);
+        const uint32_t d16 = wave_sum_all(tid < 16 ? L.me_dist[5 + tid] : 0u), d32 = wave_sum_all(tid < 4 ? L.me_dist[1 + tid] : 0u);
         const uint64_t mean = d8 / 64;
-        uint64_t       ssq  = 0;
-        for (int i = 0; i < 64; i++) {
-            const int64_t d = (int64_t)L.me_dist[21 + i] - (int64_t)mean;
-            ssq += (uint64_t)(d * d);
+        const int64_t  dv   = (int64_t)e8 - (int64_t)mean;
+        const uint64_t sq   = (uint64_t)(dv * dv);
+        const uint32_t lo = wave_sum_all((uint32_t)sq & 0xffffu), mid = wave_sum_all((uint32_t)(sq >> 16) & 0xffffu),
+                       hi = wave_sum_all((uint32_t)(sq >> 32) & 0xffffu), top = wave_sum_all((uint32_t)(sq >> 48));
+        if (tid == 0) {
+            const uint64_t ssq = (uint64_t)lo + ((uint64_t)mid << 16) + ((uint64_t)hi << 32) + ((uint64_t)top << 48);
+            const uint32_t d64 = L.me_dist[0];
+            const uint32_t pix = b64_w * b64_h;
+            out.me_8x8_cost_variance[b64] = (uint32_t)(ssq / 64);
+            out.rc_me_distortion[b64]     = p.input_resolution_le_480p ? d8 : d16;
+            out.me_64x64_distortion[b64]  = (d64 * 4096u) / pix;
+            out.me_32x32_distortion[b64]  = (d32 * 4096u) / pix;
+            out.me_16x16_distortion[b64]  = (d16 * 4096u) / pix;
+            out.me_8x8_distortion[b64]    = (d8 * 4096u) / pix;
         }
-        const uint32_t pix = b64_w * b64_h;
-        out.me_8x8_cost_variance[b64] = (uint32_t)(ssq / 64);
-        out.rc_me_distortion[b64]     = p.input_resolution_le_480p ? d8 : d16;
-        out.me_64x64_distortion[b64]  = (d64 * 4096u) / pix;
-        out.me_32x32_distortion[b64]  = (d32 * 4096u) / pix;
-        out.me_16x16_distortion[b64]  = (d16 * 4096u) / pix;
-        out.me_8x8_distortion[b64]    = (d8 * 4096u) / pix;
     }
     if (tid < NL * NR)
         out.search_results[(size_t)b64 * NL * NR + tid] = (&S.sr[0][0])[tid];

@@ -22,6 +22,7 @@ constexpr int      WG_THREADS = 256;
 constexpr int      MAX_SEARCH = 32;
 constexpr uint32_t SEG_ALIGN  = 4;    // segments of the window buffer start on 16-byte boundaries
 constexpr uint64_t KEY_NONE   = ((uint64_t)0xffffffu << 32) | 0xffffffffu;  // best starts at 0xffffff
+constexpr int      MAX_PASS   = 9;     // passes the plan-once path can hold (more: the per-pass planner takes over)
 
 struct SearchDesc {
     const uint8_t *ref;         // global: window origin (search position (0,0), block row 0)
@@ -58,7 +59,12 @@ template <int NS> struct SearchSharedT {
     SearchSeg  seg[NS];
     uint64_t   best[NS];
     uint32_t   nseg, nitems, nstage_dw;
-    uint32_t   next_d, next_j;  // continuation point of the planner
+    uint32_t   next_d, next_j;  // continuation point of the per-pass planner
+    // plan of ALL passes (made once when no descriptor has to be split): pass p = segments [pass_seg0[p], pass_seg0[p+1]),
+    // pass_item0[p+1] - pass_item0[p] work items
+    uint32_t   npass;           // 0: no such plan, the per-pass planner runs
+    uint32_t   pass_item0[MAX_PASS + 1];
+    uint8_t    pass_seg0[MAX_PASS + 3];
 #ifdef SVT_HIP_ME_PROFILE
     uint32_t   prof_site;  // PROF=1 builds: which caller the phase times are booked to
 #endif
@@ -320,8 +326,77 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
     }
     __syncthreads();
 
+    // ---- plan ALL passes at once (first wave, lane = descriptor) when no descriptor needs to be split over passes: one prefix scan
+    // and a ballot per pass boundary instead of a scan per pass, and one barrier less per pass ----
+    if (tid < 64) {
+        uint32_t need = 0, items = 0, nstage = 0;
+        bool     valid = false;
+        if (tid < n) {
+            const SearchDesc &ds = sh.desc[tid];
+            if (ds.fast && ds.n_srows) {
+                nstage = (ds.n_srows - 1) * (ds.skip ? 2u : 1u) + ds.rows_per_pos;
+                need   = (nstage * ds.pitch_dw + SEG_ALIGN - 1) & ~(SEG_ALIGN - 1);
+                items  = ds.n_srows * ds.no;
+                valid  = true;
+            }
+        }
+        const bool plan_once = n <= 64 && __ballot(valid && need > win_cap_dw) == 0;
+        uint32_t   npass = 0;
+        if (plan_once) {
+            uint32_t pn = need, pi = items;  // inclusive prefix sums
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t a = __shfl_up(pn, off, 64), b2 = __shfl_up(pi, off, 64);
+                if ((int)tid >= off)
+                    pn += a, pi += b2;
+            }
+            const uint64_t vmask = __ballot(valid);
+            const uint32_t total_items = __shfl(pi, 63, 64);              // (every lane takes part: the source lane must be active)
+            const uint32_t en = pn - need, ei = pi - items;               // exclusive
+            const uint32_t sidx = (uint32_t)__popcll(vmask & ((1ull << tid) - 1ull));  // compact segment index
+            uint64_t       starts = 0;                                    // lanes that begin a pass
+            uint32_t       base = 0;                                      // exclusive prefix of the current pass's first descriptor
+            if (vmask) {
+                uint32_t first = (uint32_t)__ffsll((unsigned long long)vmask) - 1u;
+                for (;;) {
+                    starts |= 1ull << first, npass++;
+                    base = __shfl(en, (int)first, 64);
+                    const uint64_t over = __ballot(valid && tid > first && pn - base > win_cap_dw);
+                    if (!over || npass == (uint32_t)MAX_PASS)
+                        break;
+                    first = (uint32_t)__ffsll((unsigned long long)over) - 1u;
+                }
+                // a plan with more passes than the table holds: leave it to the per-pass planner
+                if (npass == (uint32_t)MAX_PASS && __ballot(valid && tid > first && pn - base > win_cap_dw))
+                    npass = 0;
+            }
+            if (npass && valid) {
+                const uint64_t below = starts & ((2ull << tid) - 1ull);    // pass starts at or before this lane
+                const uint32_t mypass = (uint32_t)__popcll(below) - 1u, ps = 63u - (uint32_t)__clzll((unsigned long long)below);
+                const uint32_t en0 = __shfl(en, (int)ps, 64), ei0 = __shfl(ei, (int)ps, 64);
+                SearchSeg     &sg = sh.seg[sidx];
+                sg.d = tid, sg.j0 = 0, sg.nj = sh.desc[tid].n_srows, sg.lds_dw = en - en0, sg.nstage = nstage, sg.item_base = ei - ei0;
+                if (tid == ps)
+                    sh.pass_seg0[mypass] = (uint8_t)sidx, sh.pass_item0[mypass] = ei;
+            }
+            if (npass && tid == 0)
+                sh.pass_seg0[npass] = (uint8_t)__popcll(vmask), sh.pass_item0[npass] = total_items;
+        }
+        if (tid == 0)
+            sh.npass = npass;
+    }
+    __syncthreads();
+    const uint32_t npass_once = sh.npass;
+
     // ---- fast path: passes of (stage -> search) until every descriptor row has been searched ----
-    for (;;) {
+    for (uint32_t pass = 0;; pass++) {
+      uint32_t s0 = 0, nseg, nitems_pass;
+      bool     onepass;
+      if (npass_once) {
+        s0 = sh.pass_seg0[pass], nseg = sh.pass_seg0[pass + 1] - s0, nitems_pass = sh.pass_item0[pass + 1] - sh.pass_item0[pass];
+        onepass = pass + 1 == npass_once;
+      } else {
+
         // plan, by the first wave (lane = descriptor): starting at the continuation point, take as many whole descriptors
         // as fit the window buffer (prefix sum of their needs); a descriptor too big to fit even alone gets a pass of
         // its own for as many of its search rows as fit.
@@ -375,9 +450,10 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
             }
         }
         __syncthreads();
-        const bool onepass = sh.next_d >= n;  // nothing left after this pass
+        onepass = sh.next_d >= n;  // nothing left after this pass
         MS_PHASE(0);
-        const uint32_t nseg = sh.nseg;
+        nseg = sh.nseg, nitems_pass = sh.nitems;
+      }
         if (nseg == 0)
             break;
         // stage: 16-byte loads, 2..32 lanes per window row (stage_rows16).  With at least as many segments as waves every wave
@@ -387,7 +463,7 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
             const bool     per_wave = nseg >= nwv;
             const uint32_t lanes = per_wave ? 64u : blockDim.x, lid = per_wave ? (tid & 63u) : tid;
             for (uint32_t s = per_wave ? (tid >> 6) : 0u; s < nseg; s += per_wave ? nwv : 1u) {
-                const SearchSeg   sg = sh.seg[s];
+                const SearchSeg   sg = sh.seg[s0 + s];
                 const SearchDesc &ds = sh.desc[sg.d];
                 const uint32_t    rstride = ds.raw_stride;
 #ifdef SVT_HIP_ME_ABLATE
@@ -402,13 +478,14 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
         MS_PHASE(1);
         // search: one work item = eight horizontally adjacent positions (two quads) of one searched row
 #ifdef SVT_HIP_ME_ABLATE
-        const uint32_t nitems = (g_ms_skip & 4) ? 0u : sh.nitems;  // bit 2: no work items at all
+        const uint32_t nitems = (g_ms_skip & 4) ? 0u : nitems_pass;  // bit 2: no work items at all
 #else
-        const uint32_t nitems = sh.nitems;
+        const uint32_t nitems = nitems_pass;
 #endif
+        uint32_t s = 0;  // items grow from one iteration to the next, and so does the segment that holds them: advance, never search
         for (uint32_t item = tid; item < nitems; item += blockDim.x) {
-            const uint32_t   s  = find_seg<true, SH>(sh, nseg, item);
-            const SearchSeg  sg = sh.seg[s];
+            while (s + 1 < nseg && item >= sh.seg[s0 + s + 1].item_base) s++;
+            const SearchSeg  sg = sh.seg[s0 + s];
             const SearchDesc &ds = sh.desc[sg.d];
             const uint32_t   li = item - sg.item_base;
             const uint32_t   jl = fast_div(li, ds.inv_no), q = 2u * (li - jl * ds.no);  // q: first quad of the pair
@@ -443,13 +520,17 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
             const uint32_t saw = (uint32_t)ds.sa_w;
             // the eight positions are in raster order: a strict '<' on the SAD keeps the first minimum, and the
             // 64-bit (sad, raster index) key is built once
-            uint32_t best = ~0u, bpos = 0;
+            // (a SAD is below 2^22: (sad << 3 | position) orders exactly like the pair, one v_min per position instead of a
+            // compare and two selects)
+            const uint32_t nvalid = saw - 4 * q;  // >= 1
+            uint32_t       kmin   = ~0u;
 #pragma unroll
-            for (uint32_t p = 0; p < 8; p++)
-                if (4 * q + p < saw && sad[p] < best)
-                    best = sad[p], bpos = p;
-            if (best != ~0u)
-                atomicMin((unsigned long long *)&sh.best[sg.d], ((unsigned long long)best << 32) | (sy * saw + 4 * q + bpos));
+            for (uint32_t p = 0; p < 8; p++) {
+                const uint32_t k = (p < nvalid && sad[p] != ~0u) ? ((sad[p] << 3) | p) : ~0u;
+                kmin             = k < kmin ? k : kmin;
+            }
+            if (kmin != ~0u)
+                atomicMin((unsigned long long *)&sh.best[sg.d], ((unsigned long long)(kmin >> 3) << 32) | (sy * saw + 4 * q + (kmin & 7u)));
         }
         __syncthreads();
         MS_PHASE(2);
@@ -504,6 +585,13 @@ __device__ __forceinline__ void wg_stage_block(uint32_t *__restrict__ dst, uint3
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Wave64 sum, every lane gets the total (butterfly).
+__device__ __forceinline__ uint32_t wave_sum_all(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 

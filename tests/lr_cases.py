@@ -15,6 +15,7 @@ CASES = {
     "c_opt_10bit": (264, 152, 10, 1, 64, 1, 3),
     "d_8in16": (136, 264, 8, 1, 64, 0, 4),
     "e_one_unit": (72, 40, 10, 1, 256, 0, 5),
+    "f_opt_h57": (136, 121, 8, 0, 64, 1, 6),    # H = 64 + 57: the rows below the second stripe run past the picture
 }
 
 
