@@ -55,7 +55,59 @@ from benchlib.scan import zigzag_scan  # noqa: E402
 from svtav1_hip import abi, frames, shard  # noqa: E402
 
 METRIC = "encoded fps (4K 10-bit preset 8) + ME+txfm HBM GB/s vs roofline, 1/2/4/8 GPU"
-VALU_SLOT_NS, N_SIMD = 2.0, 1024        # one wave-instruction per SIMD: 2.0 ns (tools/ubench/valu_rates.hip); 256 CUs x 4 SIMDs
+N_SIMD = 1024                            # 256 CUs x 4 SIMDs
+# ns per wave-instruction per SIMD by issue class and waves per SIMD: tools/ubench/valu_issue.hip, table committed as
+# profiles/r03_ubench_valu_issue.txt (fast = v_add/sub/and/or/xor/mov/ashr and v_add_f32 in their VOP1/VOP2 forms; full = every other
+# single-pass instruction: three-operand integer forms, multiplies, min/max/med3, shifts-left, packed 16-bit, dot, sad, cndmask, DPP;
+# quad = v_qsad_pk_u16_u8).  One wave alone on a SIMD issues an instruction every ~4.9 ns whatever the class.
+ISSUE_NS = {"fast": {1: 4.9, 2: 1.30, 4: 1.29, 8: 1.12}, "full": {1: 4.85, 2: 2.95, 4: 2.31, 8: 2.00}, "quad": {1: 7.7, 2: 7.05, 4: 6.97, 8: 6.90}}
+ISA_MIX_FILE = os.path.join(ROOT, "profiles", "r03_isa_mix.json")   # static class mix + occupancy per kernel (tools/isa_mix.py)
+
+
+def issue_ns(cls, waves):
+    t = ISSUE_NS[cls]
+    w = min(8.0, max(1.0, float(waves)))
+    pts = sorted(t)
+    for a, b in zip(pts, pts[1:]):
+        if a <= w <= b:
+            return t[a] + (t[b] - t[a]) * (w - a) / (b - a)
+    return t[8]
+
+
+_ISA_MIX = None
+
+
+def isa_mix(kernel):
+    """Static instruction-class mix and waves per SIMD of a kernel (profiles/r03_isa_mix.json); longest matching name wins."""
+    global _ISA_MIX
+    if _ISA_MIX is None:
+        try:
+            _ISA_MIX = json.load(open(ISA_MIX_FILE))
+        except OSError:
+            _ISA_MIX = {}
+    best = None
+    for name, r in _ISA_MIX.items():
+        if name.startswith(kernel) or kernel.startswith(name):
+            if best is None or len(name) > len(best[0]):
+                best = (name, r)
+    return best[1] if best else {"class_frac": {"fast": 0.0, "full": 1.0, "quad": 0.0}, "waves_per_simd": 8}
+
+
+def issue_estimate(kernel, valu_insts, valu_slots, launch_ms):
+    """The time the vector pipes alone need for a launch.  SQ_INSTS_VALU = instructions, SQ_ACTIVE_INST_VALU = issue slots (a
+    quarter-rate instruction such as v_qsad_pk_u16_u8 counts four): quarter-rate instructions = (slots - insts) / 3; the rest is split
+    fast / full by the kernel's static mix and priced per class at the kernel's occupancy (ISSUE_NS)."""
+    mix = isa_mix(kernel)
+    w = mix["waves_per_simd"]
+    quad = max(0.0, (valu_slots - valu_insts) / 3.0)
+    rest = valu_insts - quad
+    ff, fu = mix["class_frac"]["fast"], mix["class_frac"]["full"]
+    f_fast = ff / (ff + fu) if ff + fu else 0.0
+    ns = quad * issue_ns("quad", w) + rest * (f_fast * issue_ns("fast", w) + (1.0 - f_fast) * issue_ns("full", w))
+    ims = ns * 1e-6 / N_SIMD
+    return {"valu_insts": int(valu_insts), "valu_slots": int(valu_slots), "quarter_rate_insts": int(quad), "static_fast_class_frac": round(f_fast, 3),
+            "waves_per_simd": w, "issue_ms": round(ims, 4), "frac_of_launch": round(ims / launch_ms, 3),
+            "issue_ms_all_full_class": round(valu_slots * issue_ns("full", w) * 1e-6 / N_SIMD, 4)}
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 PLANE_SLACK = 256                        # bytes past a plane's last row that must be readable (include/svt_hip_me.h)
 
@@ -287,9 +339,19 @@ class TxfmWorkload:
 # HBM traffic by rocprofv3 PMC passes over a child process (MI355X_MICROARCH.md "HBM": separate --pmc passes, FETCH_SIZE and
 # WRITE_SIZE in KiB, FETCH_SIZE doubled on gfx950)
 # ---------------------------------------------------------------------------------------------------------------------
-def measure_traffic(child_args, patterns, timeout_s=420):
-    """-> ({pattern: bytes per dispatch}, note).  Must run BEFORE this process touches the GPU: the child is a separate
-    program under rocprofv3 (`-- python3 bench.py --pmc-child ...`, no shell / env hop behind the `--`)."""
+T_START = time.time()
+
+
+def progress(msg):
+    """one line on stderr per stage of the run (a silent GPU job is taken to be hung by the box's watchdog)"""
+    print(f"[bench {time.time() - T_START:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
+def measure_traffic(child_args, groups, timeout_s=600):
+    """-> ({group: {...}}, note).  `groups` maps a name to (list of kernel-name substrings, invocations in the child run or None = per
+    dispatch).  Must run BEFORE this process touches the GPU: the child is a separate program under rocprofv3 (`-- python3 bench.py
+    --pmc-child ...`, no shell / env hop behind the `--`).  Four passes, one counter each (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU,
+    SQ_ACTIVE_INST_VALU)."""
     exe = shutil.which("rocprofv3")
     if not exe:
         return {}, "rocprofv3 not found"
@@ -301,6 +363,7 @@ def measure_traffic(child_args, patterns, timeout_s=420):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
+            progress(f"rocprofv3 --pmc {counter} pass over a child run")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -310,27 +373,30 @@ def measure_traffic(child_args, patterns, timeout_s=420):
                 for row in csv.DictReader(open(fcsv)):
                     if row.get("Counter_Name") != counter:
                         continue
-                    for pat in patterns:
-                        if pat in row.get("Kernel_Name", ""):
-                            acc[pat] = acc.get(pat, 0.0) + float(row["Counter_Value"])
-                            disp.setdefault(pat, set()).add(row.get("Dispatch_Id"))
-            raw[counter] = {p: acc[p] / max(1, len(disp[p])) for p in acc}
+                    kn = row.get("Kernel_Name", "")
+                    for g, (pats, _) in groups.items():
+                        if any(pat in kn for pat in pats):
+                            acc[g] = acc.get(g, 0.0) + float(row["Counter_Value"])
+                            disp.setdefault(g, set()).add(row.get("Dispatch_Id"))
+            raw[counter] = {g: acc[g] / (groups[g][1] or max(1, len(disp[g]))) for g in acc}
     except subprocess.TimeoutExpired:
         return {}, "rocprofv3 pass timed out"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     res = {}
-    for p in patterns:
-        if p in raw.get("FETCH_SIZE", {}) and p in raw.get("WRITE_SIZE", {}):
-            res[p] = {"bytes": int((2.0 * raw["FETCH_SIZE"][p] + raw["WRITE_SIZE"][p]) * 1024),
-                      "FETCH_SIZE_KiB_raw": round(raw["FETCH_SIZE"][p], 1), "WRITE_SIZE_KiB": round(raw["WRITE_SIZE"][p], 1)}
-            if p in raw.get("SQ_INSTS_VALU", {}) and p in raw.get("SQ_ACTIVE_INST_VALU", {}):
-                res[p]["valu_insts"], res[p]["valu_slots"] = int(raw["SQ_INSTS_VALU"][p]), int(raw["SQ_ACTIVE_INST_VALU"][p])
-    return res, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes over a child run of this workload (2 timed steps); "
-                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch (gfx950 counts a 128-B read request as 64 B); `issue`: "
-                 "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per dispatch from two more passes, issue_ms = slots x 2.0 ns / 1024 SIMDs (one wave-"
-                 "instruction per SIMD takes 2.0 ns on this part: tools/ubench/valu_rates.hip; quarter-rate instructions such as "
-                 "v_qsad_pk_u16_u8 count four slots) = the time the vector pipes alone need for the launch")
+    for g in groups:
+        if g in raw.get("FETCH_SIZE", {}) and g in raw.get("WRITE_SIZE", {}):
+            res[g] = {"bytes": int((2.0 * raw["FETCH_SIZE"][g] + raw["WRITE_SIZE"][g]) * 1024),
+                      "FETCH_SIZE_KiB_raw": round(raw["FETCH_SIZE"][g], 1), "WRITE_SIZE_KiB": round(raw["WRITE_SIZE"][g], 1)}
+            if g in raw.get("SQ_INSTS_VALU", {}) and g in raw.get("SQ_ACTIVE_INST_VALU", {}):
+                res[g]["valu_insts"], res[g]["valu_slots"] = int(raw["SQ_INSTS_VALU"][g]), int(raw["SQ_ACTIVE_INST_VALU"][g])
+    return res, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes over a child run of this workload (2 timed steps, the stage "
+                 "measurements included); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (gfx950 counts a 128-B read request as 64 B), "
+                 "for an entry made of several kernels the sum over its kernels per invocation; `issue`: SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU "
+                 "from two more passes, priced per instruction class at the kernel's occupancy (ISSUE_NS from tools/ubench/valu_issue.hip = "
+                 "profiles/r03_ubench_valu_issue.txt; static class mix and waves per SIMD from tools/isa_mix.py = profiles/r03_isa_mix.json): "
+                 "issue_ms = the time the vector pipes alone need for the launch, issue_ms_all_full_class = the round-2 figure (every slot "
+                 "at the full-class price)")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -439,80 +505,106 @@ def cpu_txfm_seconds_per_picture(ref, W, H, cores, frac_rows=1.0):
     return dt * total_px / done_px, done_px / total_px
 
 
+ALL_TIERB = {"SVTAV1_HIP_TIERB_PA": "1", "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_TPL": "1",
+             "SVTAV1_HIP_TIERB_DLF": "1", "SVTAV1_HIP_TIERB_CDEF": "1", "SVTAV1_HIP_TIERB_LR": "1", "SVTAV1_HIP_ONLY": "__none__"}
+
+
 def encoder_level_fps(cores, frames_n=5, timeout_s=240):
-    """the reference encoder itself (oracle/_ref/e2e/SvtAv1EncApp, built in the build container from the
-    reference's sources, C kernels only: no nasm there) on a synthetic 4K 10-bit clip, preset 8."""
+    """the reference encoder itself (oracle/_ref/e2e/SvtAv1EncApp = the reference's own sources + tools/reference_hip.patch,
+    built in the build container) on synthetic clips, preset 8, in four configurations of the SAME binary:
+      asm_c        C kernels only (the build container has no NASM: the reference's own `--asm avx2` build cannot be made there)
+      x86_simd     the reference's x86 C-intrinsics ladder (SSE2 ... AVX2; 746 RTCD pointers) installed over the C table
+                   (tools/e2e/svt_hip_bind_simd.c) -- the CPU baseline worth comparing with
+      gpu          C table + every whole-picture hook that is wired (picture analysis, open-loop ME, temporal filter, TPL dispenser,
+                   deblocking, CDEF, restoration) on the GPU through the device-resident picture mirrors; and the same without the mirrors
+                   (SVTAV1_HIP_MIRROR_MB=0: every call uploads its planes) for the PCIe bytes before / after
+      x86_simd+gpu the intrinsics table for everything that stays on the CPU, the hooks on the GPU
+    Bitstreams are compared byte by byte with asm_c."""
     app = os.path.join(ROOT, "oracle", "_ref", "e2e", "SvtAv1EncApp")
     if not os.path.exists(app):
         return None
     tmp = tempfile.mkdtemp(prefix="svtenc_", dir="/tmp")
+    lib_so = os.path.join(ROOT, "svt-av1-mod-by-patman_amd", "csrc", "libsvtav1_hip.so")
+    have_gpu = torch.cuda.is_available() and os.path.exists(lib_so)
+    simd_ok = cpu_has_avx2()
+
+    def run(path, W, H, n, bd, asm, env_extra, out_name):
+        cmd = [app, "-i", path, "-w", str(W), "-h", str(H), "--fps", "30", "-n", str(n), "--preset", "8", "--lp", str(cores),
+               "--asm", asm, "--input-depth", str(bd), "-b", os.path.join(tmp, out_name)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s, env=dict(os.environ, **env_extra))
+        m = re.search(r"Average Speed:\s+([0-9.]+) fps", r.stdout)
+        return (float(m.group(1)) if r.returncode == 0 and m else None), r.stdout
+
+    def same(a, b):
+        try:
+            return open(os.path.join(tmp, a), "rb").read() == open(os.path.join(tmp, b), "rb").read()
+        except OSError:
+            return None
+
+    def pcie(log, n):
+        m = re.search(r"PCIe ([0-9.]+) MB up / ([0-9.]+) MB down over (\d+) pictures; mirrors: (\d+) hits \(([0-9.]+) MB not uploaded again\), (\d+) uploads", log)
+        if not m:
+            return None
+        return {"MB_up_per_encoded_picture": round(float(m.group(1)) / n, 1), "MB_down_per_encoded_picture": round(float(m.group(2)) / n, 1),
+                "mirror_hits": int(m.group(4)), "MB_not_uploaded_again_per_encoded_picture": round(float(m.group(5)) / n, 1), "mirror_uploads": int(m.group(6))}
+
+    def hooks(log):
+        out = {}
+        for key, pat in (("me_pictures", r"svt_hip_bind_me: (\d+) pictures"), ("tf_pictures", r"svt_hip_bind_tf: (\d+) pictures"),
+                         ("tpl_pictures", r"svt_hip_bind_tpl: (\d+) pictures"), ("pyramids", r"svt_hip_bind_pa: (\d+) pyramids"),
+                         ("deblock_frames", r"svt_hip_bind_lf: (\d+) frame deblocking"), ("cdef_searches", r"(\d+) CDEF searches"),
+                         ("cdef_applications", r"(\d+) CDEF applications"), ("wiener_statistics_planes", r"(\d+) Wiener statistics planes"),
+                         ("restoration_frames", r"(\d+) restoration frames")):
+            m = re.search(pat, log)
+            out[key] = int(m.group(1)) if m else 0
+        out["stayed_on_cpu_messages"] = log.count("stays on the CPU") + log.count("falls back")
+        return out
+
+    def suite(tag, path, W, H, n, bd):
+        progress(f"encoder runs on the {W}x{H} clip")
+        res = {"clip": f"{W}x{H} {bd}-bit, {n} frames, --preset 8 --lp {cores}"}
+        fps_c, _ = run(path, W, H, n, bd, "c", {}, tag + "_c.ivf")
+        res["asm_c_fps"] = fps_c
+        if simd_ok:
+            fps_s, log = run(path, W, H, n, bd, "hip", {"SVTAV1_E2E_SIMD": "1"}, tag + "_s.ivf")
+            res["x86_simd_fps"], res["x86_simd_bitstream_identical"] = fps_s, same(tag + "_c.ivf", tag + "_s.ivf")
+        if have_gpu:
+            genv = dict(ALL_TIERB, SVTAV1_HIP_LIB=lib_so)
+            fps_g, log = run(path, W, H, n, bd, "hip", genv, tag + "_g.ivf")
+            res["gpu_fps"], res["gpu_bitstream_identical"], res["gpu_hooks"], res["gpu_pcie"] = fps_g, same(tag + "_c.ivf", tag + "_g.ivf"), hooks(log), pcie(log, n)
+            fps_n, log = run(path, W, H, n, bd, "hip", dict(genv, SVTAV1_HIP_MIRROR_MB="0"), tag + "_n.ivf")
+            res["gpu_without_mirrors_fps"], res["gpu_without_mirrors_pcie"] = fps_n, pcie(log, n)
+            if simd_ok:
+                fps_b, log = run(path, W, H, n, bd, "hip", dict(genv, SVTAV1_E2E_SIMD="2"), tag + "_b.ivf")
+                res["x86_simd_plus_gpu_fps"], res["x86_simd_plus_gpu_bitstream_identical"] = fps_b, same(tag + "_c.ivf", tag + "_b.ivf")
+        return res
+
     try:
         W, H = 3840, 2160
-        clip = frames.synthetic_clip(W, H, frames_n, seed=7)
         rng = np.random.default_rng(1)
         path = os.path.join(tmp, "clip.yuv")
         with open(path, "wb") as f:
-            for y in clip:
+            for y in frames.synthetic_clip(W, H, frames_n, seed=7):
                 f.write((y.astype(np.uint16) * 4 + rng.integers(0, 4, size=y.shape, dtype=np.uint16)).astype("<u2").tobytes())
                 f.write(np.full((H // 2) * (W // 2) * 2, 512, "<u2").tobytes())
-        def run(asm, env_extra, out_name):
-            cmd = [app, "-i", path, "-w", str(W), "-h", str(H), "--fps", "30", "-n", str(frames_n), "--preset", "8", "--lp", str(cores),
-                   "--asm", asm, "--input-depth", "10", "-b", os.path.join(tmp, out_name)]
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s,
-                               env=dict(os.environ, **env_extra))
-            m = re.search(r"Average Speed:\s+([0-9.]+) fps", r.stdout)
-            return (float(m.group(1)) if r.returncode == 0 and m else None), r
-        fps_c, r = run("c", {}, "c.ivf")
-        if fps_c is None:
-            return {"value": None, "note": f"encoder run failed (rc {r.returncode})"}
-        res = {"value": fps_c, "unit": "fps", "cores": cores,
-               "sample": f"reference SvtAv1EncApp (built from the reference's sources in the build container, `--asm c`: C kernels only, "
-                         f"no nasm there), {frames_n} synthetic 4K 10-bit frames, --preset 8 --lp {cores}; whole encode incl. mode decision "
-                         f"and entropy coding; 'Average Speed' of the encoder's own summary"}
-        # the same encoder with its open-loop ME handed to svt_hip_me_frames picture by picture (tools/reference_hip.patch step 2b:
-        # SVTAV1_HIP_TIERB_ME=1; SVTAV1_HIP_ONLY=<nothing>: every other kernel stays on the C table) — only with a GPU
-        lib_so = os.path.join(ROOT, "svt-av1-mod-by-patman_amd", "csrc", "libsvtav1_hip.so")
-        gpu_env = {"SVTAV1_HIP_LIB": lib_so, "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_TPL": "1", "SVTAV1_HIP_ONLY": "__none__"}
-        if torch.cuda.is_available() and os.path.exists(lib_so):
-            fps_h, r2 = run("hip", gpu_env, "h.ivf")
-            m = re.search(r"svt_hip_bind_me: (\d+) pictures / (\d+) blocks", r2.stdout)
-            mt = re.search(r"svt_hip_bind_tf: (\d+) pictures", r2.stdout)
-            mp = re.search(r"svt_hip_bind_tpl: (\d+) pictures", r2.stdout)
-            same = None
-            try:
-                same = open(os.path.join(tmp, "c.ivf"), "rb").read() == open(os.path.join(tmp, "h.ivf"), "rb").read()
-            except OSError:
-                pass
-            res["with_gpu_me_tf_tpl"] = {
-                "value": fps_h, "unit": "fps", "me_pictures_on_gpu": int(m.group(1)) if m else 0,
-                "tf_pictures_on_gpu": int(mt.group(1)) if mt else 0, "tpl_pictures_on_gpu": int(mp.group(1)) if mp else 0,
-                "bitstream_identical_to_asm_c": same,
-                "sample": "the same binary with `--asm hip`, SVTAV1_HIP_TIERB_ME=1 SVTAV1_HIP_TIERB_TF=1 SVTAV1_HIP_TIERB_TPL=1, no Tier A leaves: "
-                          "me_process.c calls svt_hip_me_frames, produce_temporally_filtered_pic calls svt_hip_tf_filter_picture and the TPL "
-                          "dispenser kernel calls svt_hip_tpl_dispenser_frame, each once per picture (planes uploaded and results downloaded "
-                          "per call over PCIe); every other kernel on the C table"}
-            # a clip long enough for the steady state (two mini-GOPs) at a size the C-only encoder finishes in seconds
-            W2, H2, N2 = 1920, 1080, 33
-            path2 = os.path.join(tmp, "clip1080.yuv")
-            with open(path2, "wb") as f:
-                for y in frames.synthetic_clip(W2, H2, N2, seed=7):
-                    f.write(y.tobytes())
-                    f.write(np.full((H2 // 2) * (W2 // 2) * 2, 128, np.uint8).tobytes())
-
-            def run2(asm, env_extra, out_name):
-                cmd = [app, "-i", path2, "-w", str(W2), "-h", str(H2), "--fps", "30", "-n", str(N2), "--preset", "8", "--lp", str(cores),
-                       "--asm", asm, "-b", os.path.join(tmp, out_name)]
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s, env=dict(os.environ, **env_extra))
-                m = re.search(r"Average Speed:\s+([0-9.]+) fps", r.stdout)
-                return float(m.group(1)) if r.returncode == 0 and m else None
-            a = run2("c", {}, "c2.ivf")
-            b = run2("hip", gpu_env, "h2.ivf")
-            try:
-                same2 = open(os.path.join(tmp, "c2.ivf"), "rb").read() == open(os.path.join(tmp, "h2.ivf"), "rb").read()
-            except OSError:
-                same2 = None
-            res["gpu_me_tf_tpl_1080p_33_frames"] = {"asm_c_fps": a, "with_gpu_me_tf_tpl_fps": b, "bitstream_identical": same2,
-                                                      "sample": f"same binary, 1920x1080 8-bit, 33 frames, --preset 8 --lp {cores}"}
+        r4k = suite("4k", path, W, H, frames_n, 10)
+        os.remove(path)
+        res = {"value": r4k.get("asm_c_fps"), "unit": "fps", "cores": cores,
+               "sample": "reference SvtAv1EncApp (the reference's own sources + tools/reference_hip.patch, built in the build container) on synthetic "
+                         "clips; 'Average Speed' of the encoder's own summary; whole encode incl. mode decision and entropy coding.  `value` = "
+                         "asm_c on the 4K 10-bit clip; see the keys of each clip for the intrinsics baseline and the GPU-assisted runs",
+               "4k_10bit": r4k}
+        if r4k.get("asm_c_fps") is None:
+            res["note"] = "encoder run failed"
+            return res
+        # a clip long enough for the steady state (two mini-GOPs) at a size the C-only encoder finishes in seconds
+        W2, H2, N2 = 1920, 1080, 33
+        path2 = os.path.join(tmp, "clip1080.yuv")
+        with open(path2, "wb") as f:
+            for y in frames.synthetic_clip(W2, H2, N2, seed=7):
+                f.write(y.tobytes())
+                f.write(np.full((H2 // 2) * (W2 // 2) * 2, 128, np.uint8).tobytes())
+        res["1080p_8bit_33_frames"] = suite("hd", path2, W2, H2, N2, 8)
         return res
     except subprocess.TimeoutExpired:
         return {"value": None, "note": "encoder run timed out"}
@@ -559,6 +651,7 @@ def cpu_baseline_headline(mw, W, H, budget_s=14.0):
                       f"svt_aom_inv_transform_recon over one picture's transform blocks (C: a quarter of the block rows, scaled); `value` = the AVX2 table "
                       f"(aom_dsp_rtcd.c ladder; kernels that exist only as NASM, e.g. the dav1d inverse transforms, run their SSE4.1 intrinsics form) "
                       f"if the CPU has AVX2, else the C table; `c_only` = svt_aom_setup_rtcd_internal(0)")
+    progress("encoder-level runs")
     out["encoder_level"] = encoder_level_fps(cores)
     return out
 
@@ -591,18 +684,36 @@ def lf_stage_rooflines(lib, dev, args, sp, stream, rank):
     W4, H4, bd = 3840, 2160, 10
     inp = LB.build(lib, dev, np.random.default_rng(11 + rank), W4, H4, bd, torch)
     P, d = W4 * H4, 2
-    stages = [("dlf_pass_kernel x2 (deblock frame, 3 planes)", lambda: LB.run_deblock(lib, inp, sp), 2 * 2 * 1.5 * P * d + (P // 16) * 8),
-              ("cdef_search_kernel x3 (8 strengths, 3 planes)", lambda: LB.run_cdef_search(lib, inp, sp), 2 * 1.5 * P * d + inp["n_fb"] * 3 * 8 * 8),
-              ("cdef_apply_kernel (3 planes)", lambda: LB.run_cdef_apply(lib, inp, sp), 2 * 1.5 * P * d),
-              ("sgr_filter_kernel (luma, one eps)", lambda: LB.run_sgr_filter(lib, inp, sp), P * d + 8 * P),
-              ("sgr_filter_kernel fused apply (luma)", lambda: LB.run_sgr_apply(lib, inp, sp), 2 * P * d),
-              ("wiener_stats_kernel (luma, win 7)", lambda: LB.run_wiener_stats(lib, inp, sp), 2 * P * d + inp["n_wiener"] * (49 + 49 * 49) * 8),
-              ("wiener_convolve_kernel (luma)", lambda: LB.run_wiener_convolve(lib, inp, sp), 2 * P * d)]
+    stages = [("dlf_pass_kernel x2 (deblock frame, 3 planes)", lambda: LB.run_deblock(lib, inp, sp), 2 * 2 * 1.5 * P * d + (P // 16) * 8, "dlf"),
+              ("cdef_search_kernel x3 (8 strengths, 3 planes)", lambda: LB.run_cdef_search(lib, inp, sp), 2 * 1.5 * P * d + inp["n_fb"] * 3 * 8 * 8, "cdef_search"),
+              ("cdef_apply_kernel (3 planes)", lambda: LB.run_cdef_apply(lib, inp, sp), 2 * 1.5 * P * d, "cdef_apply"),
+              ("sgr_filter_kernel (luma, one eps)", lambda: LB.run_sgr_filter(lib, inp, sp), P * d + 8 * P, "sgr_filter"),
+              ("sgr_filter_kernel fused apply (luma)", lambda: LB.run_sgr_apply(lib, inp, sp), 2 * P * d, "sgr_apply"),
+              ("wiener_stats_kernel (luma, win 7)", lambda: LB.run_wiener_stats(lib, inp, sp), 2 * P * d + inp["n_wiener"] * (49 + 49 * 49) * 8, "wiener_stats"),
+              ("wiener_convolve_kernel (luma)", lambda: LB.run_wiener_convolve(lib, inp, sp), 2 * P * d, "wiener_convolve")]
     out = []
-    for name, fn, alg in stages:
-        ms = timed_launches(stream, max(3, args.steps // 2), 2, fn)
-        out.append(roof(name, alg, ms, unit_of_work="one 4K 10-bit 4:2:0 picture"))
+    for name, fn, alg, key in stages:
+        ms = timed_launches(stream, *((1, 0) if args.pmc_child else (lf_steps(args), 2)), fn)
+        out.append(roof(name, alg, ms, unit_of_work="one 4K 10-bit 4:2:0 picture", pmc_key=key))
     return out
+
+
+def lf_steps(args):
+    return max(3, args.steps // 2)
+
+
+# what the PMC child passes attribute to each roofline_all entry: kernel-name substrings, and how many times the child run invokes the
+# entry (None: one kernel, per dispatch).  The child runs --steps 2 --warmup 1 of the headline step and every stage measurement once.
+def pmc_groups():
+    g = {"me": (["me_b64_kernel<false>"], None)}
+    for sz in (64, 32, 16, 8):
+        g[f"txfm{sz}"] = ([f"txfm_kernel<{sz}, {sz}>"], None)
+    g.update({"dlf": (["dlf_pass_kernel"], 1), "cdef_search": (["cdef_search_kernel"], 1), "cdef_apply": (["cdef_apply_frame_kernel", "cdef_apply_kernel"], 1),
+              "sgr_filter": (["sgr_filter_kernel<0>"], 1), "sgr_apply": (["sgr_filter_kernel<1>"], 1),
+              "wiener_stats": (["wiener_stats_kernel", "wiener_finalize_kernel"], 1), "wiener_convolve": (["wiener_convolve_kernel"], 1),
+              "tf": (["me_b64_kernel<true>", "tf_refine_kernel", "tf_blocks_kernel", "tf_predict", "tf_accumulate_kernel", "tf_central_kernel", "tf_normalise_kernel"], 1),
+              "tpl4": (["tpl_kernel<0>"], 1), "tpl5": (["tpl_kernel<1>"], 1)})
+    return g
 
 
 def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
@@ -647,7 +758,7 @@ def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
 
     def run_tf():
         check(lib, lib.svt_hip_tf_filter_picture(C.byref(job), sp))
-    ms = timed_launches(stream, 3, 1, run_tf)
+    ms = timed_launches(stream, *((1, 0) if args.pmc_child else (3, 1)), run_tf)
     torch.cuda.synchronize()
     # (the four calls filter the picture in place one after the other: a fixed sequence, so this sum identifies the results)
     tf_sum = int(mw.dpyr[c].full.t.to(torch.int64).sum().item())
@@ -656,7 +767,7 @@ def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
     # per reference: centre + reference pyramids through ME, sub-pel windows, prediction written + read, accumulators; once: normalise
     alg = 4 * (1.3125 * 2 * P + 2 * P + 1.5 * P * (1 + 1 + 6 + 6)) + 1.5 * P * (6 + 1 + 1)
     out.append(roof("svt_hip_tf_filter_picture (ME_MCTF + sub-pel + predict + accumulate, 4 refs, luma + chroma)", alg, ms,
-                    unit_of_work="one 4K 8-bit 4:2:0 picture against 4 reference pictures", result_checksum=tf_sum))
+                    unit_of_work="one 4K 8-bit 4:2:0 picture against 4 reference pictures", result_checksum=tf_sum, pmc_key="tf"))
     del ws
     # ---- TPL dispenser
     o = mw.outs[c - mw.lead]
@@ -695,16 +806,16 @@ def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
 
     def run_tpl():
         check(lib, lib.svt_hip_tpl_dispenser_frame(C.byref(tj), sp))
-    ms = timed_launches(stream, 5, 2, run_tpl)
+    ms = timed_launches(stream, *((1, 0) if args.pmc_child else (5, 2)), run_tpl)
     nblk = a16 * rows16
     out.append(roof("tpl_kernel (svt_hip_tpl_dispenser_frame, 16x16 blocks, 3+2 references)", nblk * (256 * (1 + 5) + 2 * 256 + 64 + 40), ms,
-                    unit_of_work=f"one 4K picture, {nblk} blocks", result_checksum=int(stats.to(torch.int64).sum().item())))
+                    unit_of_work=f"one 4K picture, {nblk} blocks", result_checksum=int(stats.to(torch.int64).sum().item()), pmc_key="tpl4"))
     # tpl level 5 (presets M10 and faster): 32x32 blocks in complete 64x64 blocks, transform on every 4th row, 32x32 synthesizer grid
     tj.blk_size, tj.subsample_tx, tj.synth_blk_size = 32, 2, 32
     stats.zero_()
-    ms5 = timed_launches(stream, 5, 2, run_tpl)
+    ms5 = timed_launches(stream, *((1, 0) if args.pmc_child else (5, 2)), run_tpl)
     out.append(roof("tpl_kernel level 5 (32x32 / 16x16 blocks, TX_32X8 / TX_16X4 on every 4th row)", nblk * (256 * (1 + 5) + 2 * 256) + (nblk // 4) * (64 + 40), ms5,
-                    unit_of_work="one 4K picture", result_checksum=int(stats.to(torch.int64).sum().item())))
+                    unit_of_work="one 4K picture", result_checksum=int(stats.to(torch.int64).sum().item()), pmc_key="tpl5"))
     return out
 
 
@@ -745,6 +856,8 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
         shard.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0 and not args.pmc_child:
+        progress("workload resident; warm-up and timed steps")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -752,6 +865,9 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
         for k in range(K):
             step(k)
         torch.cuda.synchronize()
+        if not args.no_lf:          # the stage measurements run under the counters too (pmc_groups knows how often)
+            lf_stage_rooflines(lib, dev, args, sp, stream, rank)
+            tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw)
         return
     t0 = time.perf_counter()
     for k in range(K):
@@ -765,27 +881,32 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
     ms = {k: float(np.mean([a.elapsed_time(b) for a, b in ev[k]])) for k in ev}
     if rank != 0:
         return
-    tr = lambda pat: (traffic.get(pat) or {}).get("bytes")      # noqa: E731
-
-    def issue(pat, launch_ms):
-        # the vector-issue roof of the launch beside its HBM roof: what the instruction stream alone costs (see traffic_note)
-        t = traffic.get(pat) or {}
-        if "valu_slots" not in t:
-            return {}
-        ims = t["valu_slots"] * VALU_SLOT_NS * 1e-6 / N_SIMD
-        return {"issue": {"valu_insts": t["valu_insts"], "valu_slots": t["valu_slots"], "issue_ms": round(ims, 4), "frac_of_launch": round(ims / launch_ms, 3)}}
-    rl_me = roof("me_b64_kernel", mw.alg_bytes, ms["me"], tr("me_b64_kernel"), unit_of_work=f"{F} 4K pictures x {mw.nb} b64 x {mw.n_refs} references",
-                 **issue("me_b64_kernel", ms["me"]))
+    def attach(r, key, kernel):
+        """measured HBM traffic and the vector-issue estimate of one roofline entry (from the PMC child passes)"""
+        t = traffic.get(key) or {}
+        r["traffic"] = t.get("bytes")
+        if t.get("bytes"):
+            r["traffic_over_algorithmic"] = round(t["bytes"] / r["algorithmic_bytes_per_launch"], 2)
+        if "valu_slots" in t:
+            r["issue"] = issue_estimate(kernel, t["valu_insts"], t["valu_slots"], r["launch_ms"])
+        return r
+    rl_me = attach(roof("me_b64_kernel", mw.alg_bytes, ms["me"], unit_of_work=f"{F} 4K pictures x {mw.nb} b64 x {mw.n_refs} references"), "me", "me_b64_kernel<false>")
     rl_all = [rl_me]
     for s in sizes:
         L = tw.launches[s]
-        rl_all.append(roof(f"txfm_kernel<{s[0]}, {s[1]}>", L["alg_bytes"], ms[s], tr(f"txfm_kernel<{s[0]}, {s[1]}>"),
-                           unit_of_work=f"{L['n']} transform blocks of {F} 4K 10-bit pictures", **issue(f"txfm_kernel<{s[0]}, {s[1]}>", ms[s])))
+        rl_all.append(attach(roof(f"txfm_kernel<{s[0]}, {s[1]}>", L["alg_bytes"], ms[s], unit_of_work=f"{L['n']} transform blocks of {F} 4K 10-bit pictures"),
+                             f"txfm{s[0]}", f"txfm_kernel<{s[0]}, {s[1]}>"))
     tx_ms = sum(ms[s] for s in sizes)
     tx_alg = sum(tw.launches[s]["alg_bytes"] for s in sizes)
     if not args.no_lf:
-        rl_all += lf_stage_rooflines(lib, dev, args, sp, stream, rank)
-        rl_all += tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw)
+        progress("stage measurements (in-loop filters, temporal filter, TPL dispenser)")
+        # the dominant kernel of a multi-kernel entry prices its instructions
+        dom = {"dlf": "dlf_pass_kernel<1>", "cdef_search": "cdef_search_kernel", "cdef_apply": "cdef_apply_frame_kernel", "sgr_filter": "sgr_filter_kernel<0>",
+               "sgr_apply": "sgr_filter_kernel<1>", "wiener_stats": "wiener_stats_kernel<7>", "wiener_convolve": "wiener_convolve_kernel",
+               "tf": "tf_refine_kernel<false>", "tpl4": "tpl_kernel<0>", "tpl5": "tpl_kernel<1>"}
+        for r in lf_stage_rooflines(lib, dev, args, sp, stream, rank) + tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
+            key = r.pop("pmc_key")
+            rl_all.append(attach(r, key, dom[key]))
     step_ms = elapsed / K * 1e3
     line = {
         "metric": METRIC,
@@ -816,7 +937,9 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
         "traffic_note": traffic_note,
     }
     if world == 1 and not args.no_cpu_baseline:
+        progress("CPU baselines (reference kernels on the host cores, then the reference encoder)")
         line["cpu_baseline"] = cpu_baseline_headline(mw, W, H)
+    progress("done")
     print(json.dumps(line))
 
 
@@ -889,8 +1012,8 @@ def main():
     # HBM traffic first, while this process has not touched the GPU yet (the profiled child is a separate program)
     traffic, traffic_note = {}, "not measured (--no-pmc, a multi-rank run, or a workload other than 4k10)"
     if args.workload == "4k10" and world == 1 and not args.no_pmc and not args.pmc_child and not launch_only:
-        pats = ["me_b64_kernel"] + [f"txfm_kernel<{s}, {s}>" for s in (64, 32, 16, 8)]
-        traffic, traffic_note = measure_traffic(["--steps", "2", "--warmup", "1", "--frames", str(args.frames), "--no-cpu-baseline", "--no-lf"], pats)
+        child = ["--steps", "2", "--warmup", "1", "--frames", str(args.frames), "--no-cpu-baseline"] + (["--no-lf"] if args.no_lf else [])
+        traffic, traffic_note = measure_traffic(child, pmc_groups())
 
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if launch_only and os.environ.get("SVTAV1_BENCH_FAIL_RANK") == str(rank):

@@ -89,6 +89,16 @@ def main():
             if best:
                 seen.add(ptr)
                 rows.append((ptr, best[1], best[0], want))
+        # pointers the reference assigns outside the SET_ ladders: `if (flags & HAS_<ISA>) ptr = fn;` (e.g. svt_cdef_filter_block_8xn_16,
+        # common_dsp_rtcd.c:800, which svt_cdef_filter_block_avx2 calls: left NULL it crashes every 16-bit CDEF)
+        direct = {}
+        for m in re.finditer(r"if \(flags & HAS_(SSE2|SSSE3|SSE4_1|AVX2|AVX512F)\)\s+(\w+)\s*=\s*(\w+);", text):
+            isa = {"SSE4_1": "SSE41", "AVX512F": "AVX512"}.get(m.group(1), m.group(1))
+            if ISA_RANK[isa] <= 4 and m.group(3) in have and m.group(2) not in seen:
+                direct[m.group(2)] = (m.group(3), isa)
+        for ptr, (fn, isa) in direct.items():
+            seen.add(ptr)
+            rows.append((ptr, fn, isa, isa))
     with open(os.path.join(OUT, "simd_table.inc"), "w") as f:
         f.write("/* generated by oracle/build_simd.py: {pointer, selected function, its ISA, ISA the reference's full x86 build selects} */\n")
         for ptr, fn, isa, want in rows:

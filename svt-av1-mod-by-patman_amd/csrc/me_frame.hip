@@ -1284,6 +1284,9 @@ __device__ int g_me_stop = 99;
 #ifndef SVT_HIP_ME_WGS
 #define SVT_HIP_ME_WGS 8  // workgroups per CU the register allocation aims for (64 VGPRs)
 #endif
+// MCTF: a name tag only (the code is the same): launches whose pictures all run in ME_MCTF mode (the temporal filter's use of
+// this function) show up as me_b64_kernel<true> in profiles, apart from the open-loop launches
+template <bool MCTF>
 __global__ __launch_bounds__(WG_THREADS, SVT_HIP_ME_WGS) void me_b64_kernel(const SvtHipMeFrameJob *__restrict__ jobs) {
     __shared__ MeLds L;
 #ifdef SVT_HIP_ME_PROFILE
@@ -1512,8 +1515,11 @@ extern "C" int32_t svt_hip_me_validate_jobs(const SvtHipMeFrameJob *jobs, uint32
     return SVT_HIP_OK;
 }
 
-static int32_t launch_me(const SvtHipMeFrameJob *d_jobs, uint32_t n_jobs, uint32_t max_b64, hipStream_t st) {
-    hipLaunchKernelGGL(me_b64_kernel, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, st, d_jobs);
+static int32_t launch_me(const SvtHipMeFrameJob *d_jobs, uint32_t n_jobs, uint32_t max_b64, hipStream_t st, bool mctf) {
+    if (mctf)
+        hipLaunchKernelGGL(me_b64_kernel<true>, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, st, d_jobs);
+    else
+        hipLaunchKernelGGL(me_b64_kernel<false>, dim3((max_b64 + 7) / 8 * 8, n_jobs), dim3(WG_THREADS), 0, st, d_jobs);
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }
@@ -1525,7 +1531,7 @@ extern "C" int32_t svt_hip_me_frames_dev(const SvtHipMeFrameJob *d_jobs, uint32_
     }
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
-    return launch_me(d_jobs, n_jobs, max_b64, resolve_stream(stream));
+    return launch_me(d_jobs, n_jobs, max_b64, resolve_stream(stream), false);
 }
 
 extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jobs, void *stream) {
@@ -1540,7 +1546,9 @@ extern "C" int32_t svt_hip_me_frames(const SvtHipMeFrameJob *jobs, uint32_t n_jo
     const SvtHipMeFrameJob *d_jobs = (const SvtHipMeFrameJob *)stage_descriptors(jobs, sizeof(SvtHipMeFrameJob) * n_jobs, st);
     if (!d_jobs)
         return SVT_HIP_ERR_RUNTIME;
-    const int32_t rc = launch_me(d_jobs, n_jobs, max_b64, st);
+    bool mctf = true;  // (host copy of the descriptors: the mode of every picture is known here)
+    for (uint32_t i = 0; i < n_jobs; i++) mctf = mctf && jobs[i].prm.me_mctf;
+    const int32_t rc = launch_me(d_jobs, n_jobs, max_b64, st, mctf);
     stage_commit(st);
     return rc;
 }

@@ -208,3 +208,19 @@ def test_every_batched_path_together(hip, case, lp):
     assert m and int(m.group(1)) > 0, log[-1500:]
     g = E.golden()[case]
     assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.parametrize("case", ["p8_8bit", "p8_10bit", "p5_8bit_lf"])
+def test_x86_intrinsics_table_reproduces_golden(case):
+    """CPU: bench.py's encoder-level CPU baseline is the patched encoder with the reference's own x86 C-intrinsics ladder installed over
+    the C table (SVTAV1_E2E_SIMD=1, tools/e2e/svt_hip_bind_simd.c + oracle/build_simd.py; the build container has no NASM for the real
+    `--asm avx2` build).  The reference pins SIMD == C, so the bitstream must be the C one — which also catches a pointer the table
+    leaves NULL (round 3: svt_cdef_filter_block_8xn_16 is assigned outside the SET_ ladders, common_dsp_rtcd.c:800)."""
+    if " avx2 " not in open("/proc/cpuinfo").read().replace("\n", " "):
+        pytest.skip("host CPU without AVX2")
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=3, env_extra={"SVTAV1_E2E_SIMD": "1"})
+    assert "x86 intrinsics kernels" in log
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}

@@ -59,7 +59,19 @@ static void *open_library(void) {
 static void *g_lib;
 static void *lib_sym(const char *name) { return g_lib ? dlsym(g_lib, name) : NULL; }
 
+/* e2e build only (tools/e2e/svt_hip_bind_simd.c): the reference's x86 intrinsics ladder as an encoder-level CPU baseline */
+int svt_hip_bind_simd_install(void) __attribute__((weak));
+
 int svt_hip_bind_install(char *msg, unsigned msg_len) {
+    const char *simd = getenv("SVTAV1_E2E_SIMD");
+    int n_simd = 0;
+    if (simd && atoi(simd) && svt_hip_bind_simd_install) {
+        n_simd = svt_hip_bind_simd_install();
+        if (atoi(simd) == 1) { /* 2: intrinsics table first, then the HIP library on top (the batched hooks, SVTAV1_HIP_ONLY leaves) */
+            snprintf(msg, msg_len, "no HIP library: SVTAV1_E2E_SIMD=1, %d RTCD pointers now point at the reference's x86 intrinsics kernels", n_simd);
+            return n_simd;
+        }
+    }
     void *h = open_library();
     if (!h) {
         snprintf(msg, msg_len, "cannot load libsvtav1_hip.so: %s", dlerror());
