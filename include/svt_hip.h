@@ -59,6 +59,9 @@ SVT_HIP_API int32_t svt_hip_upload_2d(void *dptr, size_t dpitch, const void *hpt
 SVT_HIP_API int32_t svt_hip_download_2d(void *hptr, size_t hpitch, const void *dptr, size_t dpitch,
                                         size_t width_bytes, size_t height, void *stream);
 SVT_HIP_API int32_t svt_hip_copy(void *d_dst, const void *d_src, size_t bytes, void *stream); /* device to device */
+/* page-locked host memory for staging buffers (transfers from / to it run at the full PCIe rate and truly asynchronously) */
+SVT_HIP_API int32_t svt_hip_host_alloc(void **hptr, size_t bytes);
+SVT_HIP_API int32_t svt_hip_host_free(void *hptr);
 SVT_HIP_API int32_t svt_hip_stream_create(void **stream);
 SVT_HIP_API int32_t svt_hip_stream_destroy(void *stream);
 SVT_HIP_API int32_t svt_hip_stream_sync(void *stream);

@@ -35,7 +35,23 @@ bool ensure_init();
 void *stage_descriptors(const void *host, size_t bytes, hipStream_t st);
 void  stage_commit(hipStream_t st);
 
+// The HIP runtime loads the code object of a translation unit when the first of its kernels is launched (hundreds of milliseconds for
+// the whole library, paid by whichever encoder threads come first: 23 ms per call of the first 35 calls inside the patched encoder).
+// Every .hip file registers one empty kernel; svt_hip_init launches them all, so the cost is paid once, at initialisation.
+typedef void (*WarmupFn)(hipStream_t);
+struct WarmupRegistrar {
+    explicit WarmupRegistrar(WarmupFn fn);
+};
+void run_module_warmups(hipStream_t st);
+
 }  // namespace svthip
+
+#define SVT_HIP_MODULE_WARMUP(tag)                                                                                  \
+    namespace {                                                                                                     \
+    __global__ void svt_hip_warmup_##tag() {}                                                                       \
+    void svt_hip_warmup_launch_##tag(hipStream_t st) { hipLaunchKernelGGL(svt_hip_warmup_##tag, dim3(1), dim3(64), 0, st); } \
+    svthip::WarmupRegistrar svt_hip_warmup_registrar_##tag(svt_hip_warmup_launch_##tag);                             \
+    }
 
 #define SVT_HIP_CHECK(expr)                                                                        \
     do {                                                                                           \

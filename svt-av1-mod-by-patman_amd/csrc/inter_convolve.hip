@@ -134,3 +134,5 @@ SVT_HIP_DEF_JNT(2d, 1, 1)
 SVT_HIP_DEF_JNT(x, 1, 0)
 SVT_HIP_DEF_JNT(y, 0, 1)
 SVT_HIP_DEF_JNT(2d_copy, 0, 0)
+
+SVT_HIP_MODULE_WARMUP(inter_convolve)

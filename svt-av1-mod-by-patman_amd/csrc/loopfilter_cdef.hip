@@ -856,3 +856,5 @@ static uint64_t svt_search_one_dual_hip_impl(int *lev0, int *lev1, int nb_streng
     lev1[nb_strengths] = id == 0xffffffffu ? 0 : start_gi + (int)id % span;
     return res[0];
 }
+
+SVT_HIP_MODULE_WARMUP(loopfilter_cdef)

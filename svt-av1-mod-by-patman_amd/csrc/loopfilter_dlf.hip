@@ -290,3 +290,5 @@ extern "C" int32_t svt_hip_loop_filter_frame(const SvtHipLfFrame *f, void *strea
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }
+
+SVT_HIP_MODULE_WARMUP(loopfilter_dlf)

@@ -141,3 +141,5 @@ extern "C" int32_t svt_hip_restoration_filter_frame(const SvtHipLrPlane *planes,
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }
+
+SVT_HIP_MODULE_WARMUP(loopfilter_lr_frame)

@@ -491,3 +491,5 @@ static void svt_get_proj_subspace_hip_impl(const uint8_t *src8, int width, int h
                 solved);
     xq[0] = solved[0], xq[1] = solved[1];
 }
+
+SVT_HIP_MODULE_WARMUP(loopfilter_sgr)

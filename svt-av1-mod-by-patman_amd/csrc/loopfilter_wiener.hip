@@ -397,3 +397,5 @@ static void svt_av1_highbd_wiener_convolve_add_src_hip_impl(const uint8_t *src, 
     (void)conv_params;
     convolve_tier_a(src, src_stride, dst, dst_stride, filter_x, filter_y, w, h, 1, bd);
 }
+
+SVT_HIP_MODULE_WARMUP(loopfilter_wiener)

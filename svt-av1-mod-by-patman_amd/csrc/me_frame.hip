@@ -1578,3 +1578,5 @@ extern "C" int32_t svt_hip_install_rtcd_me(void **table, uint32_t n_slots) {
             *(void **)table[i] = fn[i];
     return SVT_HIP_OK;
 }
+
+SVT_HIP_MODULE_WARMUP(me_frame)

@@ -317,3 +317,5 @@ static void svt_ext_sad_calculation_8x8_16x16_hip_impl(uint8_t *src, uint32_t sr
         p_best_sad_16x16[0] = total, p_best_mv16x16[0] = mv;
     *p_sad16x16 = total;
 }
+
+SVT_HIP_MODULE_WARMUP(me_kernels)

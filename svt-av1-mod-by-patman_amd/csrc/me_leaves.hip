@@ -224,3 +224,5 @@ static void svt_pme_sad_loop_kernel_hip_impl(const SvtHipMvCostParam *mv_cost_pa
         *best_cost = (uint32_t)(key >> 32);
     }
 }
+
+SVT_HIP_MODULE_WARMUP(me_leaves)

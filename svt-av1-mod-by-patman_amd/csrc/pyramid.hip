@@ -396,3 +396,5 @@ static uint64_t svt_compute_mean_square_values_8x8_hip_impl(uint8_t *input_sampl
     block_stats_host(input_samples, input_stride, 1, input_area_width, input_area_height, 1, r);
     return ((uint64_t)r[1] << 16) / (input_area_width * input_area_height);
 }
+
+SVT_HIP_MODULE_WARMUP(pyramid)

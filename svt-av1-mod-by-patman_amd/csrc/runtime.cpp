@@ -39,28 +39,50 @@ bool ensure_init() {
     return false;
 }
 
-struct TlsStream {
-    hipStream_t s = nullptr;
-    ~TlsStream() {
-        if (s)
-            (void)hipStreamDestroy(s);
-    }
-};
+// The "calling thread's private stream" (stream == NULL in the API): a host such as the encoder has dozens of worker threads, and
+// creating a HIP stream costs milliseconds (a hardware queue) -- 25 ms per first call of a thread inside the patched encoder.  Threads
+// draw from a small pool instead: thread k uses stream k mod POOL.  Two threads that share a stream only wait for each other's work in
+// svt_hip_stream_sync; order inside one thread is kept, which is all the API promises.
+namespace {
+constexpr int     STREAM_POOL = 8;
+hipStream_t       g_pool_streams[STREAM_POOL];
+std::mutex        g_pool_mutex;
+std::atomic<int>  g_next_thread{0};
+}  // namespace
+
+namespace {
+WarmupFn g_warmups[64];
+int      g_n_warmups = 0;
+}  // namespace
+WarmupRegistrar::WarmupRegistrar(WarmupFn fn) {
+    if (g_n_warmups < 64)
+        g_warmups[g_n_warmups++] = fn;
+}
+void run_module_warmups(hipStream_t st) {
+    for (int i = 0; i < g_n_warmups; i++) g_warmups[i](st);
+}
 
 hipStream_t resolve_stream(void *stream) {
     if (stream)
         return (hipStream_t)stream;
-    static thread_local TlsStream t;
-    if (!t.s) {
-        // streams belong to the device that is current when they are created: bind this thread first
-        (void)ensure_init();
-        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) {
-            set_error("cannot create the calling thread's stream");
-            t.s = nullptr;
-            return nullptr;  // the legacy default stream: callers carry on, correct but serialised
+    static thread_local int slot = -1;
+    if (slot < 0)
+        slot = g_next_thread.fetch_add(1) % STREAM_POOL;
+    hipStream_t s = g_pool_streams[slot];
+    if (!s) {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        s = g_pool_streams[slot];
+        if (!s) {
+            // streams belong to the device that is current when they are created: bind this thread first
+            (void)ensure_init();
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+                set_error("cannot create a stream for the calling thread");
+                return nullptr;  // the legacy default stream: callers carry on, correct but serialised
+            }
+            g_pool_streams[slot] = s;
         }
     }
-    return t.s;
+    return s;
 }
 
 namespace {
@@ -258,8 +280,13 @@ int32_t svt_hip_init(int32_t device_ordinal) {
                   prop.gcnArchName);
         return SVT_HIP_ERR_NO_DEVICE;
     }
+    const bool first = g_sticky.load() < 0;
     g_device.store(device_ordinal);
     g_sticky.store(device_ordinal);
+    if (first) {  // load every translation unit's code object now instead of inside the first calls of the host's worker threads
+        run_module_warmups(nullptr);
+        SVT_HIP_CHECK(hipDeviceSynchronize());
+    }
     return SVT_HIP_OK;
 }
 
@@ -316,6 +343,19 @@ int32_t svt_hip_download_2d(void *hptr, size_t hpitch, const void *dptr, size_t 
     if (!ensure_init())
         return SVT_HIP_ERR_NO_DEVICE;
     SVT_HIP_CHECK(hipMemcpy2DAsync(hptr, hpitch, dptr, dpitch, width_bytes, height, hipMemcpyDeviceToHost, resolve_stream(stream)));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_host_alloc(void **hptr, size_t bytes) {
+    if (!hptr)
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    SVT_HIP_CHECK(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return SVT_HIP_OK;
+}
+int32_t svt_hip_host_free(void *hptr) {
+    if (hptr)
+        SVT_HIP_CHECK(hipHostFree(hptr));
     return SVT_HIP_OK;
 }
 int32_t svt_hip_copy(void *d_dst, const void *d_src, size_t bytes, void *stream) {

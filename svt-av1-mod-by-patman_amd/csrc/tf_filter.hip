@@ -182,3 +182,5 @@ extern "C" int32_t svt_hip_tf_normalise_batch(const SvtHipTfBlock *d_blocks, con
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }
+
+SVT_HIP_MODULE_WARMUP(tf_filter)

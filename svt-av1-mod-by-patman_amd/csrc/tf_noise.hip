@@ -134,3 +134,5 @@ extern "C" int32_t svt_estimate_noise_highbd_fp16_hip(const uint16_t *src, int w
 static int32_t svt_estimate_noise_highbd_fp16_hip_impl(const uint16_t *src, int width, int height, int stride, int bd) {
     return tier_a(src, width, height, stride, 1, bd, "svt_estimate_noise_highbd_fp16");
 }
+
+SVT_HIP_MODULE_WARMUP(tf_noise)

@@ -665,3 +665,5 @@ extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void
         rc = svt_hip_tf_normalise_batch(static_blocks, outs, nb * 4, st);
     return rc;
 }
+
+SVT_HIP_MODULE_WARMUP(tf_picture)

@@ -511,3 +511,5 @@ extern "C" uint64_t svt_hip_tpl_workspace_bytes(uint32_t width, uint32_t height)
     return flag_bytes(width, height) + 256;
 }
 extern "C" uint64_t svt_hip_tpl_status_offset(uint32_t width, uint32_t height) { return flag_bytes(width, height); }
+
+SVT_HIP_MODULE_WARMUP(tpl)

@@ -447,3 +447,5 @@ extern "C" void svt_av1_quantize_fp_64x64_hip(QA) { TIER_A_CALL(svt_av1_quantize
 extern "C" void svt_av1_quantize_fp_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int16_t ls) { TIER_A_CALL(svt_av1_quantize_fp_qm, quant_tier_a(SVT_HIP_QUANT_FP, QP_, qm, iqm, ls), (QC_, qm, iqm, ls)); }
 extern "C" void svt_av1_highbd_quantize_fp_hip(QA, int16_t ls) { TIER_A_CALL(svt_av1_highbd_quantize_fp, quant_tier_a(SVT_HIP_QUANT_FP_HBD, QP_, nullptr, nullptr, ls), (QC_, ls)); }
 extern "C" void svt_av1_highbd_quantize_fp_qm_hip(QA, const uint8_t *qm, const uint8_t *iqm, int16_t ls) { TIER_A_CALL(svt_av1_highbd_quantize_fp_qm, quant_tier_a(SVT_HIP_QUANT_FP_HBD, QP_, qm, iqm, ls), (QC_, qm, iqm, ls)); }
+
+SVT_HIP_MODULE_WARMUP(txfm)

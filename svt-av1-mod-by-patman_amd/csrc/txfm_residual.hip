@@ -272,3 +272,5 @@ extern "C" int32_t svt_hip_txfm_distortion_batch(const uint8_t *d_base, const Sv
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }
+
+SVT_HIP_MODULE_WARMUP(txfm_residual)

@@ -15,8 +15,34 @@ HipDev g_hd;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t  g_cv = PTHREAD_COND_INITIALIZER;
 static unsigned long long g_up_bytes, g_down_bytes, g_hits, g_misses, g_hit_bytes, g_stale, g_evicted, g_pictures;
+static unsigned long long g_pool_bytes, g_pool_allocs, g_pool_reuses;
 static size_t             g_budget = (size_t)6144 << 20, g_resident;
 static int                g_verify;
+static int32_t (*p_host_alloc)(void **, size_t);
+
+#include <time.h>
+typedef struct HdTimer {
+    const char        *name;
+    unsigned long long ns, calls;
+} HdTimer;
+static HdTimer g_timers[24];
+uint64_t hd_now_ns(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+void hd_timer_add(const char *name, uint64_t ns) {
+    pthread_mutex_lock(&g_mu);
+    for (int i = 0; i < 24; i++) {
+        if (!g_timers[i].name)
+            g_timers[i].name = name;
+        if (g_timers[i].name == name || strcmp(g_timers[i].name, name) == 0) {
+            g_timers[i].ns += ns, g_timers[i].calls++;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&g_mu);
+}
 
 int hd_env_on(const char *name) {
     const char *e = getenv(name);
@@ -27,8 +53,12 @@ const char *hd_error(void) { return g_hd.last_error ? g_hd.last_error() : "?"; }
 static void report(void) {
     fprintf(stderr,
             "svt_hip_bind_dev: PCIe %.1f MB up / %.1f MB down over %llu pictures; mirrors: %llu hits (%.1f MB not uploaded again), %llu uploads, "
-            "%llu evicted, %llu STALE\n",
-            g_up_bytes / 1048576.0, g_down_bytes / 1048576.0, g_pictures, g_hits, g_hit_bytes / 1048576.0, g_misses, g_evicted, g_stale);
+            "%llu evicted, %llu STALE; device pool %.1f MB in %llu slabs, %llu block reuses\n",
+            g_up_bytes / 1048576.0, g_down_bytes / 1048576.0, g_pictures, g_hits, g_hit_bytes / 1048576.0, g_misses, g_evicted, g_stale,
+            g_pool_bytes / 1048576.0, g_pool_allocs, g_pool_reuses);
+    for (int i = 0; i < 24 && g_timers[i].name; i++)
+        fprintf(stderr, "svt_hip_bind_dev: hook %-22s %6llu calls %9.2f ms total %8.3f ms per call\n", g_timers[i].name, g_timers[i].calls,
+                g_timers[i].ns * 1e-6, g_timers[i].calls ? g_timers[i].ns * 1e-6 / g_timers[i].calls : 0.0);
 }
 
 void svt_hip_bind_dev_setup(void *(*sym)(const char *)) {
@@ -39,6 +69,7 @@ void svt_hip_bind_dev_setup(void *(*sym)(const char *)) {
     g_hd.memset_    = (int32_t(*)(void *, int32_t, size_t, void *))sym("svt_hip_memset");
     g_hd.sync       = (int32_t(*)(void *))sym("svt_hip_stream_sync");
     g_hd.last_error = (const char *(*)(void))sym("svt_hip_last_error");
+    p_host_alloc    = (int32_t(*)(void **, size_t))sym("svt_hip_host_alloc");
     g_hd.ok         = g_hd.malloc_ && g_hd.free_ && g_hd.upload && g_hd.download && g_hd.memset_ && g_hd.sync;
     const char *mb  = getenv("SVTAV1_HIP_MIRROR_MB");
     if (mb)
@@ -58,14 +89,116 @@ int hd_download(void *h, const void *d, size_t n) {
     __atomic_add_fetch(&g_down_bytes, n, __ATOMIC_RELAXED);
     return g_hd.download(h, d, n, NULL);
 }
-int      hd_sync(void) { return g_hd.sync(NULL); }
+int hd_sync(void) { return g_hd.sync(NULL); }
+
+/* Device scratch comes from a recycling pool: hipMalloc / hipFree take hundreds of microseconds and hipFree waits for the whole device,
+ * which serialises every encoder thread that has a kernel in flight -- with a dozen allocations per hook call that was most of a hook's
+ * cost.  Blocks are rounded up to 64 KiB multiples (the sizes repeat from picture to picture) and never go back to the driver. */
+typedef struct PoolBlk {
+    struct PoolBlk *next;
+    uint8_t        *dev;
+    size_t          bytes;
+    int             busy;
+} PoolBlk;
+static PoolBlk        *g_pool;
+static uint8_t        *g_slab;
+static size_t          g_slab_left;
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+
 uint8_t *hd_alloc(size_t n) {
-    void *p = NULL;
-    return g_hd.malloc_(&p, n ? n : 1) == 0 ? (uint8_t *)p : NULL;
+    const size_t want = ((n ? n : 1) + 65535) & ~(size_t)65535;
+    pthread_mutex_lock(&g_pool_mu);
+    PoolBlk *best = NULL;
+    for (PoolBlk *b = g_pool; b; b = b->next)
+        if (!b->busy && b->bytes >= want && b->bytes <= want + (want >> 2) && (!best || b->bytes < best->bytes))
+            best = b;
+    if (best) {
+        best->busy = 1, g_pool_reuses++;
+        pthread_mutex_unlock(&g_pool_mu);
+        return best->dev;
+    }
+    /* a new block: carved from a slab (one hipMalloc per 128 MiB: a hipMalloc per picture plane cost ~8 ms each at start-up) */
+    PoolBlk *b = (PoolBlk *)calloc(1, sizeof(*b));
+    if (!b) {
+        pthread_mutex_unlock(&g_pool_mu);
+        return NULL;
+    }
+    if (g_slab_left < want) {
+        const size_t slab = want > ((size_t)128 << 20) ? want : ((size_t)128 << 20);
+        void        *p    = NULL;
+        if (g_hd.malloc_(&p, slab) != 0) {
+            pthread_mutex_unlock(&g_pool_mu);
+            free(b);
+            return NULL;
+        }
+        g_slab = (uint8_t *)p, g_slab_left = slab, g_pool_bytes += slab, g_pool_allocs++;
+    }
+    b->dev = g_slab, b->bytes = want, b->busy = 1;
+    g_slab += want, g_slab_left -= want;
+    b->next = g_pool, g_pool = b;
+    pthread_mutex_unlock(&g_pool_mu);
+    return b->dev;
 }
 void hd_free(void *d) {
-    if (d)
-        g_hd.free_(d);
+    if (!d)
+        return;
+    pthread_mutex_lock(&g_pool_mu);
+    for (PoolBlk *b = g_pool; b; b = b->next)
+        if (b->dev == (uint8_t *)d) {
+            b->busy = 0;
+            break;
+        }
+    pthread_mutex_unlock(&g_pool_mu);
+}
+
+typedef struct HostBlk {
+    struct HostBlk *next;
+    void           *p;
+    size_t          bytes;
+    int             busy, pinned;
+} HostBlk;
+static HostBlk *g_hpool;
+
+void *hd_host_alloc(size_t n) {
+    const size_t want = ((n ? n : 1) + 65535) & ~(size_t)65535;
+    pthread_mutex_lock(&g_pool_mu);
+    HostBlk *best = NULL;
+    for (HostBlk *b = g_hpool; b; b = b->next)
+        if (!b->busy && b->bytes >= want && b->bytes <= want + (want >> 2) && (!best || b->bytes < best->bytes))
+            best = b;
+    if (best) {
+        best->busy = 1;
+        pthread_mutex_unlock(&g_pool_mu);
+        return best->p;
+    }
+    pthread_mutex_unlock(&g_pool_mu);
+    HostBlk *b = (HostBlk *)calloc(1, sizeof(*b));
+    if (!b)
+        return NULL;
+    if (p_host_alloc && p_host_alloc(&b->p, want) == 0)
+        b->pinned = 1;
+    else
+        b->p = malloc(want);
+    if (!b->p) {
+        free(b);
+        return NULL;
+    }
+    b->bytes = want, b->busy = 1;
+    pthread_mutex_lock(&g_pool_mu);
+    b->next = g_hpool, g_hpool = b;
+    pthread_mutex_unlock(&g_pool_mu);
+    return b->p;
+}
+void hd_host_free(void *h) {
+    if (!h)
+        return;
+    pthread_mutex_lock(&g_pool_mu);
+    for (HostBlk *b = g_hpool; b; b = b->next)
+        if (b->p == h) {
+            b->busy = 0;
+            break;
+        }
+    pthread_mutex_unlock(&g_pool_mu);
 }
 
 /* ---- mirrors ---------------------------------------------------------------------------------------------------------- */

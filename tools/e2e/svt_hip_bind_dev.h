@@ -38,9 +38,12 @@ int         hd_env_on(const char *name); /* getenv(name) is a non-zero number */
 int hd_upload(void *d, const void *h, size_t n);
 int hd_download(void *h, const void *d, size_t n);
 int hd_sync(void);
-/* plain device scratch, not cached */
+/* device scratch from a recycling pool (no hipMalloc / hipFree on the hooks' paths once the sizes of a sequence have been seen) */
 uint8_t *hd_alloc(size_t n);
 void     hd_free(void *d);
+/* page-locked host staging from a recycling pool (falls back to malloc when the library has no svt_hip_host_alloc) */
+void *hd_host_alloc(size_t n);
+void  hd_host_free(void *h);
 
 /* ---- mirrors ---------------------------------------------------------------------------------------------------------- */
 /* content tags: (picture number << 8) | stage.  A buffer's stage changes whenever somebody rewrites it. */
@@ -88,6 +91,10 @@ void    hd_once_done(HdOnce *e, int ok, void *payload);
 int     hd_once_ok(const HdOnce *e);
 void   *hd_once_payload(const HdOnce *e);
 void    hd_once_release(HdOnceTable *t, HdOnce *e, void (*free_payload)(void *));
+
+/* wall-clock spent inside each hook (summed over threads and calls; printed at exit): hd_timer_add(name, hd_now_ns() - t0) */
+uint64_t hd_now_ns(void);
+void     hd_timer_add(const char *name, uint64_t ns);
 
 /* statistics line of the glue at exit (svt_hip_bind_dev.c prints the PCIe totals and the mirror hit rate) */
 void hd_count_picture(void);

@@ -173,7 +173,16 @@ static const SvtHipLfMi *gather_mi(PictureControlSet *pcs, size_t *bytes) {
     return mi;
 }
 
+static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end);
 int svt_hip_bind_dlf_frame(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
+    if (!g_dlf)
+        return 1;
+    const uint64_t t0 = hd_now_ns();
+    const int      rc = dlf_frame_impl(frame_buffer, pcs, plane_start, plane_end);
+    hd_timer_add("dlf_frame", hd_now_ns() - t0);
+    return rc;
+}
+static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
     if (!g_dlf || !covered(pcs) || pcs->ppcs->frm_hdr.delta_lf_params.delta_lf_present || plane_start < 0 || plane_end > 3 || plane_start >= plane_end)
         return 1;
     SequenceControlSet      *scs  = pcs->scs;
@@ -227,7 +236,7 @@ int svt_hip_bind_dlf_frame(EbPictureBufferDesc *frame_buffer, PictureControlSet 
     }
     uint8_t *h_out[3] = {NULL, NULL, NULL};
     for (int p = plane_start; rc == 0 && p < plane_end; p++) {
-        h_out[p] = (uint8_t *)malloc(pl[p].bytes);
+        h_out[p] = (uint8_t *)hd_host_alloc(pl[p].bytes);
         rc       = h_out[p] ? hd_download(h_out[p], d_work[p], pl[p].bytes) : -1;
     }
     rc |= hd_sync();
@@ -235,7 +244,7 @@ int svt_hip_bind_dlf_frame(EbPictureBufferDesc *frame_buffer, PictureControlSet 
         for (int p = plane_start; p < plane_end; p++) memcpy(pl[p].host, h_out[p], pl[p].bytes);
     if (mi_pinned)
         hd_mirror_unpin(h_mi);
-    for (int p = 0; p < 3; p++) hd_free(d_work[p]), free(h_out[p]);
+    for (int p = 0; p < 3; p++) hd_free(d_work[p]), hd_host_free(h_out[p]);
     if (rc != 0) {
         fprintf(stderr, "svt_hip_bind_lf: deblocking of picture %llu stays on the CPU (%s)\n", (unsigned long long)pcs->picture_number, hd_error());
         return 1;
@@ -397,14 +406,27 @@ int svt_hip_bind_cdef_seg(PictureControlSet *pcs, SequenceControlSet *scs, uint3
     HdOnce *once = hd_once_enter(&g_cdef_tab, pcs, pcs->picture_number, pcs->cdef_segments_total_count, &first);
     if (!once)
         return 1;
-    if (first)
-        hd_once_done(once, cdef_search_picture(pcs, scs) == 0, NULL);
+    if (first) {
+        const uint64_t t0 = hd_now_ns();
+        const int      ok = cdef_search_picture(pcs, scs) == 0;
+        hd_timer_add("cdef_search", hd_now_ns() - t0);
+        hd_once_done(once, ok, NULL);
+    }
     const int ok = hd_once_ok(once);
     hd_once_release(&g_cdef_tab, once, NULL);
     return ok ? 0 : 1;
 }
 
+static int cdef_apply_impl(SequenceControlSet *scs, PictureControlSet *pcs);
 int svt_hip_bind_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs) {
+    if (!g_cdef)
+        return 1;
+    const uint64_t t0 = hd_now_ns();
+    const int      rc = cdef_apply_impl(scs, pcs);
+    hd_timer_add("cdef_apply", hd_now_ns() - t0);
+    return rc;
+}
+static int cdef_apply_impl(SequenceControlSet *scs, PictureControlSet *pcs) {
     if (!g_cdef || !covered(pcs) || pcs->ppcs->cdef_ctrls.use_reference_cdef_fs)
         return 1;
     PictureParentControlSet *ppcs    = pcs->ppcs;
@@ -464,14 +486,14 @@ int svt_hip_bind_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs) {
                           (const int32_t *)d_var, NULL);
     }
     for (int p = 0; rc == 0 && p < 3; p++) {
-        h_out[p] = (uint8_t *)malloc(rp[p].bytes);
+        h_out[p] = (uint8_t *)hd_host_alloc(rp[p].bytes);
         rc       = h_out[p] ? hd_download(h_out[p], d_out[p], rp[p].bytes) : -1;
     }
     rc |= hd_sync();
     cdef_planes_release(&cp);
     if (rc == 0)
         for (int p = 0; p < 3; p++) memcpy(rp[p].host, h_out[p], rp[p].bytes);
-    for (int p = 0; p < 3; p++) hd_free(d_out[p]), free(h_out[p]);
+    for (int p = 0; p < 3; p++) hd_free(d_out[p]), hd_host_free(h_out[p]);
     hd_free(dev);
     free(filt), free(fbs), free(h_dir), free(h_var);
     if (rc != 0) {
@@ -632,7 +654,9 @@ int svt_hip_bind_wiener_stats(PictureControlSet *pcs, int plane, int rest_unit_i
         wiener_stats_free(e->st);
         e->st = NULL, e->pcs = pcs, e->picture_number = pcs->picture_number, e->plane = plane, e->state = 1, e->stamp = ++g_wiener_clock;
         pthread_mutex_unlock(&g_wiener_mu);
+        const uint64_t    t0 = hd_now_ns();
         WienerPlaneStats *st = wiener_plane(pcs, plane, wiener_win, dgd, src, dgd_stride, src_stride, highbd, bit_depth);
+        hd_timer_add("wiener_plane", hd_now_ns() - t0);
         pthread_mutex_lock(&g_wiener_mu);
         e->st = st, e->state = st ? 2 : 3;
         pthread_cond_broadcast(&g_wiener_cv);
@@ -651,7 +675,16 @@ int svt_hip_bind_wiener_stats(PictureControlSet *pcs, int plane, int rest_unit_i
     return rc;
 }
 
+static int lr_frame_impl(Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr);
 int svt_hip_bind_lr_frame(Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr) {
+    if (!g_lr)
+        return 1;
+    const uint64_t t0 = hd_now_ns();
+    const int      rc = lr_frame_impl(frame, cm, optimized_lr);
+    hd_timer_add("lr_frame", hd_now_ns() - t0);
+    return rc;
+}
+static int lr_frame_impl(Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr) {
     PictureControlSet *pcs = cm->child_pcs;
     if (!g_lr || !pcs || !covered(pcs))
         return 1;
@@ -726,7 +759,7 @@ int svt_hip_bind_lr_frame(Yv12BufferConfig *frame, Av1Common *cm, int32_t optimi
     /* only the picture area comes back (copy_funs[plane](dst, frame) copies the cropped plane, :1243) */
     for (int k = 0; rc == 0 && k < n_pl; k++) {
         const size_t row = (size_t)pl[k].width << is16;
-        h_out[k]         = (uint8_t *)malloc(row * pl[k].height);
+        h_out[k]         = (uint8_t *)hd_host_alloc(row * pl[k].height);
         rc = h_out[k] ? p_download_2d(h_out[k], row, pl[k].dst, (size_t)pl[k].dst_stride << is16, row, pl[k].height, NULL) : -1;
     }
     rc |= hd_sync();
@@ -737,7 +770,7 @@ int svt_hip_bind_lr_frame(Yv12BufferConfig *frame, Av1Common *cm, int32_t optimi
             const size_t    row = (size_t)pl[k].width << is16;
             for (uint32_t y = 0; y < pl[k].height; y++) memcpy(r->host + r->origin + (((size_t)y * r->stride) << is16), h_out[k] + y * row, row);
         }
-    for (int k = 0; k < 3; k++) hd_free(d_out[k]), hd_free(d_units[k]), hd_free(d_bnd[k]), free(h_out[k]);
+    for (int k = 0; k < 3; k++) hd_free(d_out[k]), hd_free(d_units[k]), hd_free(d_bnd[k]), hd_host_free(h_out[k]);
     if (rc != 0) {
         fprintf(stderr, "svt_hip_bind_lf: restoration of picture %llu stays on the CPU (%s)\n", (unsigned long long)pcs->picture_number, hd_error());
         return 1;

@@ -211,7 +211,9 @@ int svt_hip_bind_me_b64(PictureParentControlSet *pcs, uint32_t b64_index, MeCont
     if (!once)
         return 1;
     if (first) {
-        PicResults *r = compute_picture(pcs, me, full, quarter, sixteenth);
+        const uint64_t t0 = hd_now_ns();
+        PicResults    *r  = compute_picture(pcs, me, full, quarter, sixteenth);
+        hd_timer_add("me_picture", hd_now_ns() - t0);
         if (r)
             __atomic_add_fetch(&g_pictures, 1, __ATOMIC_RELAXED);
         hd_once_done(once, r != NULL, r);

@@ -56,7 +56,16 @@ static int geometry_ok(const EbPictureBufferDesc *f, const EbPictureBufferDesc *
         q->height == f->height >> 1 && s->width == f->width >> 2 && s->height == f->height >> 2;
 }
 
+static int pa_pyramid_impl(PictureParentControlSet *pcs, EbPictureBufferDesc *full, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth);
 int svt_hip_bind_pa_pyramid(PictureParentControlSet *pcs, EbPictureBufferDesc *full, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth) {
+    if (!g_active)
+        return 1;
+    const uint64_t t0 = hd_now_ns();
+    const int      rc = pa_pyramid_impl(pcs, full, quarter, sixteenth);
+    hd_timer_add("pa_pyramid", hd_now_ns() - t0);
+    return rc;
+}
+static int pa_pyramid_impl(PictureParentControlSet *pcs, EbPictureBufferDesc *full, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth) {
     if (!g_active || !(pcs->enable_hme_flag || pcs->tf_enable_hme_flag) || !(pcs->enable_hme_level0_flag || pcs->tf_enable_hme_level0_flag) ||
         !geometry_ok(full, quarter, sixteenth))
         return 1;
@@ -69,7 +78,7 @@ int svt_hip_bind_pa_pyramid(PictureParentControlSet *pcs, EbPictureBufferDesc *f
     /* the decimated planes are produced on the device: their buffers become the mirrors of the host planes */
     uint8_t *d_q = level1 ? hd_mirror_new(quarter->buffer_y, nq, tag) : hd_alloc(nq + 256);
     uint8_t *d_s = hd_mirror_new(sixteenth->buffer_y, ns, tag);
-    uint8_t *h_q = level1 ? (uint8_t *)malloc(nq) : NULL, *h_s = (uint8_t *)malloc(ns);
+    uint8_t *h_q = level1 ? (uint8_t *)hd_host_alloc(nq) : NULL, *h_s = (uint8_t *)hd_host_alloc(ns);
     int      rc  = (d_q && d_s && h_s && (h_q || !level1)) ? 0 : -1;
     if (rc == 0) {
         SvtHipPlane8 pf, pq, ps;
@@ -100,7 +109,7 @@ int svt_hip_bind_pa_pyramid(PictureParentControlSet *pcs, EbPictureBufferDesc *f
             hd_mirror_drop(sixteenth->buffer_y);
         hd_mirror_unpin(sixteenth->buffer_y);
     }
-    free(h_q), free(h_s);
+    hd_host_free(h_q), hd_host_free(h_s);
     if (rc != 0) {
         fprintf(stderr, "svt_hip_bind_pa: pyramid of picture %llu stays on the CPU (%s)\n", (unsigned long long)pcs->picture_number, hd_error());
         return 1;
@@ -110,7 +119,16 @@ int svt_hip_bind_pa_pyramid(PictureParentControlSet *pcs, EbPictureBufferDesc *f
     return 0;
 }
 
+static int pa_variance_impl(SequenceControlSet *scs, PictureParentControlSet *pcs, EbPictureBufferDesc *full);
 int svt_hip_bind_pa_variance(SequenceControlSet *scs, PictureParentControlSet *pcs, EbPictureBufferDesc *full) {
+    if (!g_active)
+        return 1;
+    const uint64_t t0 = hd_now_ns();
+    const int      rc = pa_variance_impl(scs, pcs, full);
+    hd_timer_add("pa_variance", hd_now_ns() - t0);
+    return rc;
+}
+static int pa_variance_impl(SequenceControlSet *scs, PictureParentControlSet *pcs, EbPictureBufferDesc *full) {
     if (!g_active || full->org_x < 64 || full->org_y < 64)
         return 1;
     const uint32_t nb = pcs->b64_total_count;

@@ -230,7 +230,7 @@ static int run_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc *
     if (rc == 0) { /* the filtered centre picture into host staging; into the encoder's planes only when all of it has arrived */
         const int np = job->chroma ? 3 : 1;
         for (int c = 0; rc == 0 && c < np; c++) {
-            h_out[c] = (uint8_t *)malloc(n_out[c]);
+            h_out[c] = (uint8_t *)hd_host_alloc(n_out[c]);
             rc = h_out[c] ? hd_download(h_out[c], is_highbd ? dc.d_hbd[c] : d_out[c], n_out[c]) : -1;
         }
         if (rc == 0)
@@ -245,7 +245,7 @@ static int run_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc *
     }
     release_picture(&dc);
     for (int k = 0; k < n_dr; k++) release_picture(&dr[k]);
-    for (int c = 0; c < 3; c++) hd_free(d_out[c]), free(h_out[c]);
+    for (int c = 0; c < 3; c++) hd_free(d_out[c]), hd_host_free(h_out[c]);
     hd_free(ws);
     if (rc != 0)
         fprintf(stderr, "svt_hip_bind_tf: picture %llu stays on the CPU (%s)\n", (unsigned long long)centre->picture_number, hd_error());
@@ -271,7 +271,9 @@ int svt_hip_bind_tf_picture(PictureParentControlSet **pcs_list, EbPictureBufferD
     }
     if (first) {
         uint32_t  tot[2] = {0, 0};
-        const int rc = run_picture(pcs_list, pics, index_center, ctx, is_highbd, tot);
+        const uint64_t t0 = hd_now_ns();
+        const int      rc = run_picture(pcs_list, pics, index_center, ctx, is_highbd, tot);
+        hd_timer_add("tf_picture", hd_now_ns() - t0);
         /* either way the centre picture changes now: here (GPU) or in the reference's loop right behind this call (CPU) */
         drop_picture_mirrors(centre, pics[index_center]);
         if (rc == 0) {

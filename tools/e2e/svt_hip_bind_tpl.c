@@ -176,7 +176,7 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
         /* everything comes back into host staging first; the status word says whether a dependency wait inside the kernel ran into
          * its bound (the kernel then went on with unsynchronised neighbours: the results are unusable and the CPU loop runs) */
         uint32_t status = 1;
-        h_rec = (uint8_t *)malloc(n_rec);
+        h_rec = (uint8_t *)hd_host_alloc(n_rec);
         rc = h_rec ? (hd_download(h_rec, d_rec, n_rec) | hd_download(h_st, d_st, n_stats) | hd_download(h_sst, d_sst, n_sst) |
                       hd_download(&status, (uint8_t *)job->workspace + p_status_offset(W, H), 4) | hd_sync())
                    : -1;
@@ -250,7 +250,7 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
     else
         hd_count_picture();
     hd_free(dev);
-    free(h_rec), free(h_mv), free(h_cand), free(h_cnt), free(h_sst), free(h_st), free(job);
+    hd_host_free(h_rec), free(h_mv), free(h_cand), free(h_cnt), free(h_sst), free(h_st), free(job);
     return rc != 0;
 }
 
@@ -269,7 +269,10 @@ int svt_hip_bind_tpl_sb(PictureParentControlSet *pcs, int32_t frame_idx, uint32_
         EbPictureBufferDesc *recon = pcs->scs->enc_ctx->mc_flow_rec_picture_buffer[frame_idx];
         if (recon)
             hd_mirror_drop(recon->buffer_y);
-        const int rc = g_active ? run_picture(pcs, frame_idx, qindex) : 1;
+        const uint64_t t0 = hd_now_ns();
+        const int      rc = g_active ? run_picture(pcs, frame_idx, qindex) : 1;
+        if (g_active)
+            hd_timer_add("tpl_picture", hd_now_ns() - t0);
         if (rc == 0)
             __atomic_add_fetch(&g_pictures, 1, __ATOMIC_RELAXED);
         hd_once_done(once, rc == 0, NULL);
