@@ -68,6 +68,10 @@ struct B64State {
     int16_t  stx, sty, stw, sth;  // block of positions whose window is currently staged (full-pel)
     int32_t  staged, restage;
     uint32_t zero_sad, hme_mv_sad;
+    // integer search set-up of every reference, prepared in one pass (lane = reference) when it does not depend on the search results of
+    // another reference (fullpel_prepare_all): centre, window size, whether the centre is probed, the block of positions staged for it
+    int16_t  fp_xc[NL * NR], fp_yc[NL * NR], fp_sw[NL * NR], fp_sh[NL * NR], fp_stx[NL * NR], fp_sty[NL * NR], fp_stw[NL * NR], fp_sth[NL * NR];
+    uint8_t  fp_centre[NL * NR];
     uint32_t first_ref_sad64;        // p_sb_best_sad[0][0][0] (read by later references, :1359)
     uint64_t me_sad_sum[NL][NR];     // sum of the 64 best 8x8 SADs per reference (me_prune_ref, :1605-1611)
 };
@@ -995,14 +999,69 @@ __device__ void centre_prune_lane0(LDS &L, const Ctx &c) {
     }
 }
 
-// integer_search_b64 (motion_estimation.c:1249-1586) for one reference; all threads.  `store`: write the winners to the
-// output arrays and accumulate the 8x8 SAD sum (false when the reference is only evaluated for first_ref_sad64).
+// Parts 1 and 2 of integer_search_b64 (below) for ALL references at once, lane = reference: with me_early_exit_th != 0 they read only
+// the parameters, the HME results and the zero-vector SAD of their own reference (no check_00_center SADs, no first-reference rule),
+// so five single-lane passes between barriers become one pass of five lanes.  Caller: uniform `p.me_early_exit_th != 0`.
 template <class LDS>
-__device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store) {
+__device__ void fullpel_prepare_all(LDS &L, const Ctx &c) {
+    ME_CTX_LOCALS(c);
+    const int16_t W = (int16_t)aw, H = (int16_t)ah, pad = 63;
+    const int16_t ox_b = (int16_t)org_x, oy_b = (int16_t)org_y;
+    if ((int)tid < nref) {
+        const int f = (int)tid, li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0;
+        uint16_t  dist = pic_dist(p, li, ri);
+        int16_t   xc = S.sr[li][ri].hme_sc_x, yc = S.sr[li][ri].hme_sc_y;
+        int16_t   sw = (int16_t)p.me_sa_min.width, sh_ = (int16_t)p.me_sa_min.height;
+        if (!p.me_mctf)  // motion_estimation.c:1302
+            dist = scaled_dist(dist);
+        sw  = (int16_t)MINV((sw * dist), p.me_sa_max.width);
+        sh_ = (int16_t)MINV((sh_ * dist), p.me_sa_max.height);
+        if (p.mv_sa_adj_enabled && (!p.mv_sa_adj_nearest_ref_only || ri == 0)) {
+            if (ABSV(xc) > p.mv_sa_adj_mv_size_th) sw = (int16_t)(sw * p.mv_sa_adj_sa_multiplier);
+            if (ABSV(yc) > p.mv_sa_adj_mv_size_th) sh_ = (int16_t)(sh_ * p.mv_sa_adj_sa_multiplier);
+        }
+        sw  = (int16_t)((MAXV(1u, ((uint32_t)sw / S.reduce_div[li][ri])) + 7) & ~0x07u);
+        sh_ = (int16_t)MAXV(3u, ((uint32_t)sh_ / S.reduce_div[li][ri]));
+        if (S.zz_sad[li][ri] < (p.me_early_exit_th / 6))
+            sw = sh_ = 1;
+        const int g = li * NR + ri;
+        S.fp_xc[g] = xc, S.fp_yc[g] = yc, S.fp_sw[g] = sw, S.fp_sh[g] = sh_;
+        const int centre = p.me_8x8_var_enabled && (sw * sh_ > 24);
+        S.fp_centre[g] = (uint8_t)centre;
+        if (centre) {  // the block of positions staged for the centre probe and, if it fits, the search (see part 2 below)
+            int16_t cw_ = sw, chh = sh_, cx0, cy0;
+            clamp_me_window(xc, yc, ox_b, oy_b, W, H, pad, &cw_, &chh, &cx0, &cy0);
+            int x0 = MINV((int)xc, (int)cx0), x1 = MAXV((int)xc + 1, (int)cx0 + (cw_ > 0 ? cw_ : 0));
+            int y0 = MINV((int)yc, (int)cy0), y1 = MAXV((int)yc + 1, (int)cy0 + (chh > 0 ? chh : 0));
+            x0 -= (x0 - (int)xc) & 3;
+            if (x1 - x0 > (int)FP_TILE_W || (uint32_t)(y1 - y0 + 63) * fp_pitch((uint32_t)(x1 - x0)) > LDS::WIN_DW)
+                x0 = xc, x1 = xc + 1, y0 = yc, y1 = yc + 1;
+            S.fp_stx[g] = (int16_t)x0, S.fp_sty[g] = (int16_t)y0, S.fp_stw[g] = (int16_t)(x1 - x0), S.fp_sth[g] = (int16_t)(y1 - y0);
+        }
+    }
+    __syncthreads();
+}
+
+// integer_search_b64 (motion_estimation.c:1249-1586) for one reference; all threads.  `store`: write the winners to the
+// output arrays and accumulate the 8x8 SAD sum (false when the reference is only evaluated for first_ref_sad64).  `prepared`:
+// parts 1 and 2 come from fullpel_prepare_all.
+template <class LDS>
+__device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store, bool prepared) {
     ME_CTX_LOCALS(c);
     const int16_t W = (int16_t)aw, H = (int16_t)ah, pad = 63;
     const int16_t ox_b = (int16_t)org_x, oy_b = (int16_t)org_y;
     const SvtHipPlane8 &rp = job.ref[li][ri].full;
+    if (prepared) {
+        if (tid == 0) {
+            const int g = li * NR + ri;
+            S.xc = S.fp_xc[g], S.yc = S.fp_yc[g], S.sw = S.fp_sw[g], S.sh = S.fp_sh[g];
+            S.need_zero_sad = 0, S.need_hme_sad = 0;
+            S.do_centre = S.fp_centre[g], S.staged = S.fp_centre[g];
+            S.stx = S.fp_stx[g], S.sty = S.fp_sty[g], S.stw = S.fp_stw[g], S.sth = S.fp_sth[g];
+        }
+        for (uint32_t pu = tid; pu < 85; pu += blockDim.x) L.bestkey[pu] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
+        __syncthreads();
+    } else {
     // part 1: search area from settings + HME results
     if (tid == 0) {
         uint16_t dist = pic_dist(p, li, ri);
@@ -1094,6 +1153,7 @@ __device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store) {
     }
     for (uint32_t pu = tid; pu < 85; pu += blockDim.x) L.bestkey[pu] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
     __syncthreads();
+    }
     if (S.do_centre) {
         fp_stage(L, plane_at(rp, ox_b + S.stx, oy_b + S.sty), rp.stride, (uint32_t)S.stw, (uint32_t)S.sth);
         fp_search(L, fp_pitch((uint32_t)S.stw), (uint32_t)(S.xc - S.stx), (uint32_t)(S.yc - S.sty), 1, 1, 0, 1, me_sub);
@@ -1380,11 +1440,15 @@ __global__ __launch_bounds__(WG_THREADS, SVT_HIP_ME_WGS) void me_b64_kernel(cons
     // ME_MCTF (the temporal filter's use of this function): a block whose first reference already matches well keeps its HME
     // vector and skips the full-pel search (:3179-3183); no pruning, candidates or distortion statistics (:3173, 3196)
     const bool tf_exit = p.me_mctf && S.sr[0][0].hme_sad < p.tf_me_exit_th;  // uniform: LDS value written before the last barrier
-    if (!tf_exit)
+    if (!tf_exit) {
+        const bool prepared = p.me_early_exit_th != 0;  // uniform
+        if (prepared)
+            fullpel_prepare_all(L, c);
         for (int li = 0; li < nlists; ++li)
             for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
                 if (S.sr[li][ri].do_ref)  // uniform
-                    fullpel_ref(L, c, li, ri, true);
+                    fullpel_ref(L, c, li, ri, true, prepared);
+    }
     ME_PHASE(7);
     ME_STOP(7);
     if (p.me_mctf) {

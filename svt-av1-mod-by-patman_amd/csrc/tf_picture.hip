@@ -282,7 +282,7 @@ template <bool S16>
 __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const RefineRef *__restrict__ refs, uint32_t *__restrict__ tot) {
     __shared__ Lds              L;
     __shared__ SvtHipTfB64State st;
-    const RefineRef     R = refs[blockIdx.y];
+    const RefineRef    &R = refs[blockIdx.y];  // a by-value copy went to scratch memory: its plane arrays are indexed at run time
     const uint32_t      b = blockIdx.x;
     const int           tid = threadIdx.x, ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64;
     const SvtHipTfCtrls &c = a.ctrls;
@@ -315,23 +315,27 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
             use64 = ((x - y) * 100) / y < use64_th;
         }
     }
-    uint64_t err32[4] = {0, 0, 0, 0};
-    int      mv32x[4] = {0, 0, 0, 0}, mv32y[4] = {0, 0, 0, 0};
+    // the 32x32 results live in the block's state record in LDS (st.err32 / mv32_*), not in run-time-indexed local arrays: those went
+    // to scratch memory (120 B per lane)
     if (!use64) {
         uint64_t sum32 = 0;
         for (int i = 0; i < 4; i++) {
-            err32[i] = 0x7fffffff;
-            mv32x[i] = (int16_t)(mvx_of(best_mv[1 + i]) << 3), mv32y[i] = (int16_t)(mvy_of(best_mv[1 + i]) << 3);
-            subpel_search<S16, 32>(L, s, (i & 1) * 32, (i >> 1) * 32, k6432, err32[i], mv32x[i], mv32y[i]);
-            sum32 += err32[i];
+            uint64_t e  = 0x7fffffff;
+            int      mx = (int16_t)(mvx_of(best_mv[1 + i]) << 3), my = (int16_t)(mvy_of(best_mv[1 + i]) << 3);
+            subpel_search<S16, 32>(L, s, (i & 1) * 32, (i >> 1) * 32, k6432, e, mx, my);
+            sum32 += e;
+            if (tid == 0)
+                st.err32[i] = e, st.mv32_x[i] = (int16_t)mx, st.mv32_y[i] = (int16_t)my;
         }
         if (err64 * 14 < sum32 * 16 && err64 < (1u << 18))
             use64 = true;
+        __syncthreads();  // st.err32 of lane 0 -> every lane
     }
     if (!use64) {
         for (int i = 0; i < 4; i++) {
-            const int lx = (i & 1) * 32, ly = (i >> 1) * 32;
-            if (err32[i] < c.pred_error_32x32_th)
+            const int      lx = (i & 1) * 32, ly = (i >> 1) * 32;
+            const uint64_t e32 = st.err32[i];
+            if (e32 < c.pred_error_32x32_th)
                 continue;  // split flag stays 0
             // tf_16x16_sub_pel_search (always the regular 8-tap kernel), derive_tf_32x32_block_split_flag without 8x8
             int64_t sum16 = 0;
@@ -345,14 +349,12 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
                     st.err16[q] = e, st.mv16_x[q] = (int16_t)mx, st.mv16_y[q] = (int16_t)my;
             }
             if (tid == 0)
-                st.split32[i] = !((int)err32[i] * 14 < (int)sum16 * 16);
+                st.split32[i] = !((int)e32 * 14 < (int)sum16 * 16);
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0)
         st.err64 = err64, st.mv64_x = (int16_t)mv64x, st.mv64_y = (int16_t)mv64y, st.use_64x64 = use64;
-        for (int i = 0; i < 4; i++) st.err32[i] = err32[i], st.mv32_x[i] = (int16_t)mv32x[i], st.mv32_y[i] = (int16_t)mv32y[i];
-    }
     __syncthreads();
     for (int i = tid; i < (int)(sizeof(st) / 4); i += 256) ((uint32_t *)&R.state[b])[i] = ((const uint32_t *)&st)[i];
     // ---- descriptors of the final predictions (sharp kernel, the filter's bit depth): 16 luma + 16 + 16 chroma slots
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void tf_blocks_kernel(RefineArgs a, const Refi
         }
         return;
     }
-    const RefineRef   R = refs[blockIdx.y];
+    const RefineRef  &R = refs[blockIdx.y];
     SvtHipTfB64State *st = &R.state[b];
     const int is16 = a.bit_depth > 8, ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64;
     if (st->use_64x64) {  // uniform over the workgroup

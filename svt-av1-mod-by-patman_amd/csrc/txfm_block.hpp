@@ -32,13 +32,16 @@ constexpr int pow2floor(int v) {
     while (p * 2 <= v) p *= 2;
     return p;
 }
+#ifndef SVT_HIP_TX64_WAVES
+#define SVT_HIP_TX64_WAVES 1  // waves per SIMD the 64-point kernels are compiled for (1: no cap, 211 VGPRs = 2 waves)
+#endif
 template <int W, int H>
 struct Geo {
     static constexpr int L  = cmax(W, H);
     static constexpr int PW = W + 1;
     static constexpr int NT = cmax(1, 64 / L);  // one wave per workgroup: its barriers cost nothing and waves never wait for each other
     static constexpr int IW = cmin(W, 32), IH = cmin(H, 32);
-    static constexpr int MINW = L == 32 ? 3 : (L == 8 ? 8 : 1);  // waves per SIMD the register allocation aims for: 3 for the 32-wide kernels (150 VGPRs, no scratch: 2.86 TB/s; at 4 waves / 128 VGPRs they spill 104 B per lane: 2.31 TB/s); 8 for the 8-wide ones (64 VGPRs, 12 B of scratch: +4 %); the 16-wide take what they need (96 VGPRs, 5 waves: capped at 80 they spill 64 B and lose 15 %)
+    static constexpr int MINW = L == 32 ? 3 : (L == 8 ? 8 : (L == 64 ? SVT_HIP_TX64_WAVES : 1));  // waves per SIMD the register allocation aims for: 3 for the 32-wide kernels (150 VGPRs, no scratch: 2.86 TB/s; at 4 waves / 128 VGPRs they spill 104 B per lane: 2.31 TB/s); 8 for the 8-wide ones (64 VGPRs, 12 B of scratch: +4 %); the 16-wide take what they need (96 VGPRs, 5 waves: capped at 80 they spill 64 B and lose 15 %)
     static constexpr int WI = clog2(W) - 2, HI = clog2(H) - 2;
     static constexpr bool RECT = (W == 2 * H) || (H == 2 * W);
 };

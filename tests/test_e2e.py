@@ -197,9 +197,10 @@ def test_batched_in_loop_filters_bitstream_md5(hip, case, lp, wiener):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,lp", [("p8_10bit", 3), ("p6_10bit_lf", 4), ("p10_10bit_ragged", 3)])
 def test_every_batched_path_together(hip, case, lp):
-    """GPU: picture analysis, open-loop ME, temporal filter, TPL dispenser, deblocking, CDEF, restoration — every whole-picture entry
-    point that is wired, together, sharing the device-resident picture mirrors (each hit compared with the host buffer)."""
-    env = dict(LF_ENV, SVTAV1_HIP_TIERB_ME="1", SVTAV1_HIP_TIERB_TF="1", SVTAV1_HIP_TIERB_TPL="1", SVTAV1_HIP_ONLY="__none__")
+    """GPU: picture analysis, open-loop ME, temporal filter, TPL dispenser, the transform-type search's batches, deblocking, CDEF,
+    restoration — every batched entry point that is wired, together, sharing the device-resident picture mirrors (each hit compared with
+    the host buffer)."""
+    env = dict(LF_ENV, SVTAV1_HIP_TIERB_ME="1", SVTAV1_HIP_TIERB_TF="1", SVTAV1_HIP_TIERB_TPL="1", SVTAV1_HIP_TIERB_TXT="1", SVTAV1_HIP_ONLY="__none__")
     with tempfile.TemporaryDirectory() as d:
         md5, log = E.encode(case, d, "hip", lp=lp, env_extra=env)
     E.assert_hip_ran_clean(log)
@@ -224,3 +225,24 @@ def test_x86_intrinsics_table_reproduces_golden(case):
     assert "x86 intrinsics kernels" in log
     g = E.golden()[case]
     assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}
+
+
+@needs_app
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,lp", [("p12_8bit", 1), ("p8_8bit", 2), ("p8_10bit", 2), ("p5_8bit_lf", 3), ("p3_8bit_lf", 2)])
+def test_batched_txt_bitstream_md5(hip, case, lp):
+    """GPU, the transform batches inside the real encoder (the last stage of row h): tx_type_search hands the
+    forward transforms of every transform type it can reach for a transform block to ONE svt_hip_txfm_quant_batch call
+    (tools/e2e/svt_hip_bind_txt.c) and takes the coefficients from it instead of calling svt_aom_estimate_transform per type.
+    Presets 3 and 5 search up to 16 types per block, 8 and 12 mostly DCT_DCT alone.  Same bitstream."""
+    env = {"SVTAV1_HIP_TIERB_TXT": "1", "SVTAV1_HIP_ONLY": "__none__"}
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra=env)
+    E.assert_hip_ran_clean(log)
+    assert "stays on the CPU" not in log, log[-1500:]
+    m = re.search(r"svt_hip_bind_txt: (\d+) transform blocks / (\d+) forward transforms through svt_hip_txfm_quant_batch, (\d+) of them used", log)
+    assert m and int(m.group(1)) > 0 and int(m.group(3)) > 0, log[-1500:]
+    if case in ("p5_8bit_lf", "p3_8bit_lf"):
+        assert int(m.group(2)) > int(m.group(1)), "no block searched more than one transform type"
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched transform-type search {m.groups()}\n{log[-1500:]}"

@@ -181,6 +181,43 @@ def patch_pic_analysis_process(t):
     return edit(t, old, new)
 
 
+def patch_product_coding_loop(t):
+    """Step 3a: the forward transforms of all transform types tx_type_search can reach for one transform block, in ONE batch in front of
+    the loop; inside the loop the reference's svt_aom_estimate_transform call runs only for a type the batch does not hold."""
+    t = edit(t, '#include "full_loop.h"\n', '#include "full_loop.h"\n#include "svt_hip_bind.h"\n')
+    old = ("    int          tx_type_tot_group     = get_tx_type_group(ctx, cand_bf, only_dct_dct);\n"
+           "    for (int tx_type_group_idx = 0; tx_type_group_idx < tx_type_tot_group; ++tx_type_group_idx) {\n"
+           "        uint32_t best_tx_non_coeff = 64 * 64;\n")
+    new = ("    int          tx_type_tot_group     = get_tx_type_group(ctx, cand_bf, only_dct_dct);\n"
+           "    void        *hip_txt               = NULL;\n"
+           "    if (!tx_search_skip_flag) { /* the types the loop below can reach (its static filters) */\n"
+           "        uint32_t hip_mask = 0;\n"
+           "        for (int g = 0; g < tx_type_tot_group; ++g)\n"
+           "            for (int i = 0; i < TX_TYPES; ++i) {\n"
+           "                const int tt = pcs->ppcs->sc_class1 ? tx_type_group_sc[g][i] : tx_type_group[g][i];\n"
+           "                if (tt == INVALID_TX_TYPE)\n"
+           "                    break;\n"
+           "                if (tt != DCT_DCT && (only_dct_dct || av1_ext_tx_used[tx_set_type][tt] == 0))\n"
+           "                    continue;\n"
+           "                hip_mask |= 1u << tt;\n"
+           "            }\n"
+           "        hip_txt = svt_hip_bind_txt_prepare(&(((int16_t *)cand_bf->residual->buffer_y)[ctx->blk_geom->tx_org_x[is_inter][ctx->tx_depth][ctx->txb_itr] +\n"
+           "                                               ctx->blk_geom->tx_org_y[is_inter][ctx->tx_depth][ctx->txb_itr] * cand_bf->residual->stride_y]),\n"
+           "                                           cand_bf->residual->stride_y, tx_size, ctx->hbd_md ? EB_TEN_BIT : EB_EIGHT_BIT, pf_shape, hip_mask);\n"
+           "    }\n"
+           "    for (int tx_type_group_idx = 0; tx_type_group_idx < tx_type_tot_group; ++tx_type_group_idx) {\n"
+           "        uint32_t best_tx_non_coeff = 64 * 64;\n")
+    t = edit(t, old, new)
+    old = ("                // Y: T Q i_q\n"
+           "                svt_aom_estimate_transform(&(((int16_t *)cand_bf->residual->buffer_y)[txb_origin_index]),\n")
+    new = ("                // Y: T Q i_q\n"
+           "                if (svt_hip_bind_txt_take(hip_txt, tx_type, &(((int32_t *)ctx->tx_coeffs->buffer_y)[ctx->txb_1d_offset]), &ctx->three_quad_energy))\n"
+           "                svt_aom_estimate_transform(&(((int16_t *)cand_bf->residual->buffer_y)[txb_origin_index]),\n")
+    assert t.count(old) >= 1
+    i = t.index(old, t.index("static void tx_type_search("))
+    return t[:i] + new + t[i + len(old):]
+
+
 def main():
     pieces = []
     for rel, fn in (("Source/Lib/Globals/enc_settings.c", patch_enc_settings),
@@ -189,6 +226,7 @@ def main():
                     ("Source/Lib/Codec/temporal_filtering.c", patch_temporal_filtering),
                     ("Source/Lib/Codec/src_ops_process.c", patch_src_ops_process),
                     ("Source/Lib/Codec/pic_analysis_process.c", patch_pic_analysis_process),
+                    ("Source/Lib/Codec/product_coding_loop.c", patch_product_coding_loop),
                     ("Source/Lib/Codec/deblocking_filter.c", patch_deblocking_filter),
                     ("Source/Lib/Codec/coding_loop.c", patch_coding_loop),
                     ("Source/Lib/Codec/dlf_process.c", patch_dlf_process),

@@ -112,6 +112,7 @@ int svt_hip_bind_install(char *msg, unsigned msg_len) {
     svt_hip_bind_tf_setup(lib_sym); /* Step 6b: whole-picture temporal filter (SVTAV1_HIP_TIERB_TF=1) */
     svt_hip_bind_tpl_setup(lib_sym); /* Step 3c: whole-picture TPL dispenser (SVTAV1_HIP_TIERB_TPL=1) */
     svt_hip_bind_pa_setup(lib_sym);  /* Step 2a: pyramid + block variances of the picture-analysis kernel (SVTAV1_HIP_TIERB_PA=1) */
+    svt_hip_bind_txt_setup(lib_sym); /* Step 3a: the transform-type search's forward transforms as one batch per block (SVTAV1_HIP_TIERB_TXT=1) */
     svt_hip_bind_lf_setup(lib_sym);  /* Step 4: deblocking / CDEF / restoration of whole pictures (SVTAV1_HIP_TIERB_DLF / _CDEF / _LR=1) */
     snprintf(msg, msg_len, "%u of %u RTCD pointers now point at HIP leaves", done, n_all);
     return (int)done;

@@ -67,4 +67,10 @@ int  svt_hip_bind_wiener_stats(struct PictureControlSet *pcs, int plane, int res
 int  svt_hip_bind_lr_frame(struct Yv12BufferConfig *frame, struct Av1Common *cm, int32_t optimized_lr);
 void svt_hip_bind_lf_setup(void *(*sym)(const char *));
 
+/* Step 3a (svt_hip_bind_txt.c): the forward transforms of every transform type tx_type_search can reach for one transform block through
+ * ONE svt_hip_txfm_quant_batch call.  prepare returns NULL when declined; take returns 0 when it filled the coefficients in. */
+void *svt_hip_bind_txt_prepare(const int16_t *residual, uint32_t stride, int tx_size, int bit_depth, int pf_shape, uint32_t type_mask);
+int   svt_hip_bind_txt_take(void *cache, int tx_type, int32_t *coeff, uint64_t *three_quad_energy);
+void  svt_hip_bind_txt_setup(void *(*sym)(const char *));
+
 #endif
