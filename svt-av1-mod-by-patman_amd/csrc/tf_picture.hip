@@ -261,6 +261,7 @@ __device__ void fill_block(const RefineArgs &a, uint32_t b, int q, const uint8_t
     const int is16 = a.bit_depth > 8, lx = (q & 1) * 32, ly = (q >> 1) * 32;
     const int ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64;
     memset(&t, 0, sizeof(t));
+#pragma unroll
     for (int p = 0; p < 3; p++) {
         const int       ss = p ? 1 : 0, ps = p ? 32 : 64;
         const size_t    stride = p ? a.centre.stride_c : a.centre.stride;
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(256) void tf_blocks_kernel(RefineArgs a, const Refi
             static_blocks[(size_t)b * 4 + tid] = t;
             SvtHipTfOut o;
             memset(&o, 0, sizeof(o));
+#pragma unroll
             for (int p = 0; p < 3; p++) o.dst[p] = (void *)t.src[p], o.dst_stride[p] = t.src_stride[p];
             outs[(size_t)b * 4 + tid] = o;
         }
@@ -502,6 +504,7 @@ __global__ __launch_bounds__(256) void tf_blocks_kernel(RefineArgs a, const Refi
         fill_block(a, b, tid, R.pred, t);
         t.split = st->split32[tid];
         if (t.split) {
+#pragma unroll
             for (int k = 0; k < 4; k++) t.block_error[k] = st->err16[tid * 4 + k], t.mv_x[k] = st->mv16_x[tid * 4 + k], t.mv_y[k] = st->mv16_y[tid * 4 + k];
         } else {
             t.block_error[0] = st->err32[tid], t.mv_x[0] = st->mv32_x[tid], t.mv_y[0] = st->mv32_y[tid];
