@@ -40,7 +40,7 @@ __device__ const int16_t TF_KERNELS[3][16][8] = {
      {0, 0, 0, 64, 64, 0, 0, 0}, {0, 0, 0, 56, 72, 0, 0, 0}, {0, 0, 0, 48, 80, 0, 0, 0}, {0, 0, 0, 40, 88, 0, 0, 0},
      {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 24, 104, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}, {0, 0, 0, 8, 120, 0, 0, 0}}};
 enum { K_REGULAR = 0, K_SHARP = 1, K_BILINEAR = 2 };
-constexpr int WIN_MARGIN = 10, WP = 64 + 2 * WIN_MARGIN + 1 /* odd pitch */, IM_ROWS = 64 + 14;
+constexpr int WIN_MARGIN = 10;
 constexpr int DESC_PER_B64 = 48;
 
 struct PicPlanes {  // one picture of the window; every pointer at sample (0,0) of its plane
@@ -87,13 +87,27 @@ __device__ __forceinline__ void clamp_mv(int32_t mi_rows, int32_t mi_cols, int b
     row = (int16_t)clampi((int16_t)(mvy * m), to_top * m - spel_top, to_bottom * m + spel_bottom);
 }
 
+constexpr int WIN_ELEMS = 4 * (32 + 2 * WIN_MARGIN) * (32 + 2 * WIN_MARGIN);  // four 32x32 windows >= one 64x64 window, four 16x16 windows
+constexpr int MAX_ITEMS = 32;                                                  // four blocks x eight candidates of a round
+struct Blk {  // one square block of a search stage
+    uint64_t best;      // best distortion so far
+    int32_t  mvx, mvy;  // its vector (1/8 sample) = the centre of the next round
+    int16_t  lx, ly;    // block origin inside the 64x64 block
+    int16_t  wx, wy;    // window origin relative to the 64x64 block's origin
+    uint32_t done;      // best == 0 or below the early-exit threshold: every later candidate is skipped
+};
+struct Item {  // one candidate position of a round
+    int16_t px, py;  // block sample (0,0) of the candidate in window coordinates
+    int16_t mvx, mvy;
+    uint8_t sx, sy, blk, on;
+};
 struct Lds {
     uint16_t src[64 * 64];
-    uint16_t win[(64 + 2 * WIN_MARGIN) * WP];
-    int16_t  im[IM_ROWS * 64];
-    int64_t  red_sum[4];
-    uint64_t red_sse[4];
-    uint64_t dist;
+    uint16_t win[WIN_ELEMS];
+    alignas(16) int16_t taps[2][16][8];  // regular, bilinear
+    Item     item[MAX_ITEMS];
+    uint64_t dist[MAX_ITEMS];
+    Blk      blk[4];
 };
 
 struct SearchCtx {
@@ -110,146 +124,230 @@ __device__ __forceinline__ uint32_t ldg(const void *p, ptrdiff_t i) {
     return ((const __attribute__((address_space(1))) uint8_t *)p)[i];
 }
 
-// distortion of ONE candidate vector from the staged window: prediction (svt_inter_predictor semantics, round_0 = 3,
-// round_1 = 11) against the source, fn_ptr->vf / vf_hbd_10 over every (1 << vshift)-th row.  Returns the same value on every lane.
-template <int bsize, int NT>
-__device__ uint64_t eval_position_t(Lds &L, const SearchCtx &s, int lx, int ly, int kernel, int col, int row, int wx0, int wy0,
-                                    int tstep_log2, int vshift) {
-    constexpr int K0 = NT == 2 ? 3 : 0;  // the taps that can be non-zero: 3, 4 of the bilinear kernel, all 8 otherwise
-    const int tid = threadIdx.x, sx = col & 15, sy = row & 15, bd = s.bd;
-    const int px = s.ox + lx + (col >> 4) - wx0, py = s.oy + ly + (row >> 4) - wy0;  // block sample (0,0) in window coordinates
-    const int tstep = 1 << tstep_log2, rows_out = bsize >> vshift;
-    // the taps are uniform: read them once into scalar registers (a tap loop with a run-time range re-read the table from global
-    // memory for every tap of every sample and waited for it)
-    int32_t fx[NT], fy[NT];
+// ---- the sub-pel searches (tf_64x64 / tf_32x32 / tf_16x16_sub_pel_search -> tf_subpel_search, temporal_filtering.c:1531-2104)
+//
+// One search = a centre position and up to three refinement rounds (half, quarter, eighth of a sample) of 4 or 8 candidate vectors
+// around the best one so far.  The reference walks the candidates one after the other and skips a candidate when the best distortion
+// so far is zero or below the early-exit threshold; a candidate's distortion itself does not depend on its predecessors.  So all
+// candidates of a round — of ALL blocks of the stage (one 64x64, four 32x32, the four 16x16 of a 32x32) — are evaluated side by
+// side as `items`, and a replay applies the reference's skip / take rules to the distortions in the reference's order (both skip
+// tests are monotone in the best distortion, so a block that meets one at the start of a round is left out for good).
+//
+// An item is evaluated by W lanes of ONE wave (W = block width: a wave carries 64 / W items), without a workgroup barrier: a lane
+// owns a column of the block and streams down the rows of the staged reference window; the horizontal filter of a row is NT / 2
+// v_dot2_i32_i16 over one unaligned LDS read of the NT samples, its result enters a register ring of row PAIRS, and the vertical
+// filter of an output row is NT / 2 v_dot2_i32_i16 over that ring — no intermediate plane in LDS.  The 2-D form is used for every
+// position of a mixed wave: with the unit kernel of phase 0 on one axis it returns exactly what svt_av1_(highbd_)convolve_x_sr /
+// _y_sr / the plain copy return (round_0 = 3, round_1 = 11: the offsets cancel and rnd(rnd(s, 3), 4), rnd(s, 7) fall out); waves
+// whose items all lack one axis take the cheaper 1-D / copy loops.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b), c, false);
+}
+// NT consecutive 16-bit samples from LDS as NT / 2 packed pairs; the address is 2-byte aligned only (gfx950 reads unaligned LDS data)
+template <int NT>
+__device__ __forceinline__ void lds_pairs(const uint16_t *p, uint32_t (&v)[NT / 2]) {
+    __builtin_memcpy(v, p, NT * 2);
+}
+// the NT non-zero taps of a phase as packed pairs in tap order (bilinear: taps 3 and 4 straddle two dwords of the 8-tap row)
+template <int NT>
+__device__ __forceinline__ void tap_pairs(const int16_t *row8, uint32_t (&f)[NT / 2]) {
+    uint32_t d[4];
+    __builtin_memcpy(d, row8, 16);
+    if (NT == 8) {
 #pragma unroll
-    for (int k = 0; k < NT; k++) {
-        fx[k] = __builtin_amdgcn_readfirstlane((int)TF_KERNELS[kernel][sx][K0 + k]);
-        fy[k] = __builtin_amdgcn_readfirstlane((int)TF_KERNELS[kernel][sy][K0 + k]);
+        for (int i = 0; i < NT / 2; i++) f[i] = d[i];
+    } else {
+        f[0] = (d[1] >> 16) | (d[2] << 16);
     }
-    constexpr int  lb = bsize == 64 ? 6 : (bsize == 32 ? 5 : 4);  // compile-time block size: index arithmetic and trip counts fold
-    // a thread owns column c and every RS-th row from r0: all LDS offsets advance by constants (no multiply per sample and tap)
-    constexpr int  RS = 256 >> lb;
-    const int      c = tid & (bsize - 1), r0 = tid >> lb;
-    if (sx && sy) {  // svt_av1_[highbd_]convolve_2d_sr_c: horizontal pass over rows -3*tstep .. bsize-1 + 4*tstep
-        const int im_rows = bsize + 7 * tstep;
-        int       woff = (py + r0 - 3 * tstep) * WP + px + c - 3 + K0, ioff = (r0 << lb) + c;
-        for (int r = r0; r < im_rows; r += RS, woff += RS * WP, ioff += RS << lb) {
-            int32_t acc = 1 << (bd + 7 - 1);
+}
+
+template <int W>
+struct Geo {
+    static constexpr int WD = W + 2 * WIN_MARGIN;      // window width = height = pitch
+    static constexpr int WDP = WD > 64 ? 128 : 64;      // the staging loop's row length (a power of two)
+    static constexpr int G = 64 / W;                    // items per wave
+    static constexpr int LB = W == 64 ? 6 : (W == 32 ? 5 : 4);
+};
+
+// evaluate the item of this lane's group (valid == false: an idle group); returns the distortion on every lane of the group
+template <bool S16, int W, int NT>
+__device__ uint64_t eval_item(const Lds &L, const Item &it, bool valid, int kidx, int bd, bool centre, int sss) {
+    constexpr int WD = Geo<W>::WD, LB = Geo<W>::LB, K0 = (8 - NT) / 2;
+    const int     lane = threadIdx.x & 63, c = lane & (W - 1);
+    const int     vshift = sss, rstep = centre ? 1 << sss : 1, n_out = W >> vshift, hi = (1 << bd) - 1;
+    const bool    has_h = __ballot(valid && it.sx) != 0, has_v = __ballot(valid && it.sy) != 0;  // uniform over the wave
+    const Blk    &B = L.blk[it.blk];
+    const int win0 = it.blk * (WD * WD) + it.py * WD + it.px + c;  // block sample (c, 0) of the candidate in L.win
+    const int src0 = B.ly * 64 + B.lx + c;
+    uint32_t fx[NT / 2], fy[NT / 2];
+    tap_pairs<NT>(L.taps[kidx][it.sx], fx);
+    tap_pairs<NT>(L.taps[kidx][it.sy], fy);
+    int32_t  sum = 0;
+    uint32_t sse = 0;
+    if (!has_v) {
+        // rows o = i << vshift straight from the window: copy or horizontal filter
+        int wo = win0 - 3 + K0, so = src0;
+        for (int i = 0; i < n_out; i++, wo += WD << vshift, so += 64 << vshift) {
+            int32_t p;
+            if (has_h) {
+                uint32_t x[NT / 2];
+                lds_pairs<NT>(&L.win[wo], x);
+                int32_t acc = 4;
 #pragma unroll
-            for (int k = 0; k < NT; k++) acc += fx[k] * (int32_t)L.win[woff + k];
-            L.im[ioff] = (int16_t)(uint16_t)rnd(acc, 3);
+                for (int k = 0; k < NT / 2; k++) acc = dot2(x[k], fx[k], acc);
+                p = ((acc >> 3) + 8) >> 4;
+                p = p < 0 ? 0 : (p > hi ? hi : p);
+            } else {
+                p = L.win[wo + 3 - K0];
+            }
+            const int32_t d = p - (int32_t)L.src[so];
+            sum += d, sse += (uint32_t)(d * d);
         }
-        __syncthreads();
-    }
-    // a lane sees at most 16 samples (64 x 64 over 256 lanes) of |difference| < 2^10 (8 / 10-bit): the sums of a whole wave fit 32 bits
-    int32_t   sum = 0;
-    uint32_t  sse = 0;
-    const int rstep = RS << vshift, istep = tstep << lb, wstep = tstep * WP;  // rows per iteration; tap steps in `im` / the window
-    int       ioff = ((r0 << vshift) << lb) + c + K0 * istep;                    // first tap of the 2-D vertical pass
-    int       woff = (py + (r0 << vshift)) * WP + px + c;                          // block sample (c, r) in the window
-    int       soff = (ly + (r0 << vshift)) * 64 + lx + c;
-    for (int ro = r0; ro < rows_out; ro += RS, ioff += rstep << lb, woff += rstep * WP, soff += rstep * 64) {
-        int32_t p;
-        if (sx && sy) {
-            const int offset_bits = bd + 2 * 7 - 3;
-            int32_t   v = 1 << offset_bits;
+    } else {
+        // stream of window rows py + (K0 - 3 + j) * rstep; output row o = (j - NT + 1) * rstep once NT rows are in the ring
+        const int       n = centre ? n_out + NT - 1 : ((n_out - 1) << vshift) + NT, emit_mask = centre ? 0 : (1 << vshift) - 1;
+        int             wo = win0 + (K0 - 3) * rstep * WD - 3 + K0, so = src0 - (NT - 1) * rstep * 64;
+        const int32_t   c0 = (1 << (bd + 6)) + 4;             // horizontal: offset + rounding of >> 3
+        const int32_t   c1 = 1024 - (1 << (bd + 10));         // vertical: rounding of >> 11 and the offsets of both passes
+        uint32_t        ring[NT], prev = 0;
 #pragma unroll
-            for (int k = 0; k < NT; k++) v += fy[k] * (int32_t)L.im[ioff + k * istep];
-            int32_t res = rnd(v, 11) - ((1 << (offset_bits - 11)) + (1 << (offset_bits - 11 - 1)));
-            if (!s.is16)
-                res = (int16_t)res;
-            p = res;
-        } else if (sx) {  // x_sr
-            int32_t v = 0;
+        for (int u = 0; u < NT; u++) ring[u] = 0;
+        for (int jb = 0; jb < n; jb += NT) {
 #pragma unroll
-            for (int k = 0; k < NT; k++) v += fx[k] * (int32_t)L.win[woff - 3 + K0 + k];
-            p = rnd(rnd(v, 3), 4);
-        } else if (sy) {  // y_sr
-            int32_t v = 0;
+            for (int u = 0; u < NT; u++) {
+                const int j = jb + u;
+                if (j < n) {
+                    uint32_t h;
+                    if (has_h) {
+                        uint32_t x[NT / 2];
+                        lds_pairs<NT>(&L.win[wo], x);
+                        int32_t acc = c0;
 #pragma unroll
-            for (int k = 0; k < NT; k++) v += fy[k] * (int32_t)L.win[woff + (K0 + k - 3) * wstep];
-            p = rnd(v, 7);
-        } else {
-            p = L.win[woff];
+                        for (int k = 0; k < NT / 2; k++) acc = dot2(x[k], fx[k], acc);
+                        h = (uint32_t)(acc >> 3);
+                    } else {
+                        h = L.win[wo + 3 - K0];
+                    }
+                    ring[u] = (h << 16) | prev, prev = h;
+                    if (j >= NT - 1 && ((j - (NT - 1)) & emit_mask) == 0) {
+                        int32_t acc = has_h ? c1 : 64;
+#pragma unroll
+                        for (int k = 0; k < NT / 2; k++) acc = dot2(ring[(u + 2 + 2 * k) % NT], fy[k], acc);
+                        int32_t p = has_h ? acc >> 11 : acc >> 7;
+                        p = p < 0 ? 0 : (p > hi ? hi : p);
+                        const int32_t d = p - (int32_t)L.src[so];
+                        sum += d, sse += (uint32_t)(d * d);
+                    }
+                    wo += rstep * WD, so += rstep * 64;
+                }
+            }
         }
-        const int32_t hi = (1 << bd) - 1;
-        p = (sx || sy) ? (p < 0 ? 0 : (p > hi ? hi : p)) : p;
-        const int32_t d = p - (int32_t)L.src[soff];
-        sum += d, sse += (uint32_t)(d * d);
     }
+    // sums over the W lanes of the group (a lane holds at most 64 samples of |difference| < 2^10: 2^26 per lane; a 64x64 block of a
+    // 10-bit picture can pass 2^32 in total)
+    uint64_t tsse = sse;
+    int32_t  tsum = sum;
+    if (S16 && W == 64) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64), sse += __shfl_xor(sse, off, 64);
-    __syncthreads();  // the previous position's result has been read by everybody
-    if ((tid & 63) == 0)
-        L.red_sum[tid >> 6] = (int64_t)sum, L.red_sse[tid >> 6] = (uint64_t)sse;
-    __syncthreads();
-    const int64_t  tsum = L.red_sum[0] + L.red_sum[1] + L.red_sum[2] + L.red_sum[3];
-    const uint64_t tsse = L.red_sse[0] + L.red_sse[1] + L.red_sse[2] + L.red_sse[3];
-    const int      ln   = 2 * lb - vshift;  // n = bsize * rows_out is a power of two and the squares are not negative: / n is a shift
-    uint64_t       var;
-    if (!s.is16) {  // svt_aom_variance*_c
-        const int32_t s32 = (int32_t)tsum;
-        var = (uint32_t)((uint32_t)tsse - (uint32_t)(((int64_t)s32 * s32) >> ln));
+        for (int off = W / 2; off > 0; off >>= 1) tsum += __shfl_xor(tsum, off, 64), tsse += __shfl_xor(tsse, off, 64);
+    } else {
+        uint32_t e = sse;
+#pragma unroll
+        for (int off = W / 2; off > 0; off >>= 1) tsum += __shfl_xor(tsum, off, 64), e += __shfl_xor(e, off, 64);
+        tsse = e;
+    }
+    const int ln = 2 * LB - vshift;  // n = W * (W >> vshift) samples: a power of two, and the squares are not negative: / n is a shift
+    uint64_t  var;
+    if (!S16) {  // svt_aom_variance*_c
+        var = (uint32_t)((uint32_t)tsse - (uint32_t)(((int64_t)tsum * tsum) >> ln));
     } else {  // svt_aom_highbd_10_variance*_c
         const uint32_t e = (uint32_t)((tsse + 8) >> 4);
-        const int32_t  m = (int32_t)((tsum + 2) >> 2);
+        const int32_t  m = (int32_t)(((int64_t)tsum + 2) >> 2);
         const int64_t  v = (int64_t)e - (((int64_t)m * m) >> ln);
         var = v >= 0 ? (uint32_t)v : 0;
     }
     return var << vshift;
 }
 
-template <int bsize>
-__device__ __forceinline__ uint64_t eval_position(Lds &L, const SearchCtx &s, int lx, int ly, int kernel, int col, int row, int wx0, int wy0,
-                                                  int tstep_log2, int vshift) {
-    return kernel == K_BILINEAR ? eval_position_t<bsize, 2>(L, s, lx, ly, kernel, col, row, wx0, wy0, tstep_log2, vshift)
-                                : eval_position_t<bsize, 8>(L, s, lx, ly, kernel, col, row, wx0, wy0, tstep_log2, vshift);
-}
-
-// tf_subpel_search of one square block; best / bx / by are uniform over the workgroup
-template <bool S16, int bsize>
-__device__ void subpel_search(Lds &L, const SearchCtx &s, int lx, int ly, int kernel, uint64_t &best, int &bx, int &by) {
+// tf_subpel_search of the nblk (1 or 4) square blocks of width W described by L.blk[]: in  .best / .mvx / .mvy / .lx / .ly,
+// out .best / .mvx / .mvy.  Called by the whole workgroup; the results are visible to every lane on return.
+template <bool S16, int W, int NT>
+__device__ void search_blocks(Lds &L, const SearchCtx &s, int nblk, int kernel) {
+    constexpr int WD = Geo<W>::WD, WDP = Geo<W>::WDP, G = Geo<W>::G;
     const SvtHipTfCtrls &c = s.a->ctrls;
-    const int tid = threadIdx.x;
-    // window around the (clamped) starting vector
-    int col0, row0;
-    clamp_mv(s.a->mi_rows, s.a->mi_cols, bsize, bsize, bx, by, 0, s.ox + lx, s.oy + ly, bsize, col0, row0);
-    const int wx0 = s.ox + lx + (col0 >> 4) - WIN_MARGIN, wy0 = s.oy + ly + (row0 >> 4) - WIN_MARGIN, wd = bsize + 2 * WIN_MARGIN;
-    __syncthreads();  // the previous search is done with the window
-    for (int i = tid; i < wd * wd; i += 256) {
-        const int r = i / wd, cc = i - r * wd;
-        // the margin rows / columns nobody reads may lie outside the padded plane: keep the address inside it
-        int64_t idx = (int64_t)(wy0 + r) * s.ref_stride + wx0 + cc;
-        idx         = idx < s.a->idx_min ? s.a->idx_min : (idx > s.a->idx_max ? s.a->idx_max : idx);
-        L.win[r * WP + cc] = (uint16_t)ldg<S16>(s.ref0, (ptrdiff_t)idx);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lbn = nblk == 4 ? 2 : 0;
+    const int kidx = kernel == K_BILINEAR ? 1 : 0;
+    __syncthreads();  // L.blk[] is set up; the previous search is done with the windows
+    if (tid < nblk) {  // window around the (clamped) starting vector
+        Blk &B = L.blk[tid];
+        int  col0, row0;
+        clamp_mv(s.a->mi_rows, s.a->mi_cols, W, W, B.mvx, B.mvy, 0, s.ox + B.lx, s.oy + B.ly, W, col0, row0);
+        B.wx = (int16_t)(B.lx + (col0 >> 4) - WIN_MARGIN), B.wy = (int16_t)(B.ly + (row0 >> 4) - WIN_MARGIN), B.done = 0;
     }
     __syncthreads();
-    const int modes[3] = {c.half_pel_mode, c.quarter_pel_mode, c.eight_pel_mode};
-    for (int round = -1; round < 3; round++) {
-        if (round >= 0 && !modes[round])
-            continue;
-        const int mode = round < 0 ? c.half_pel_mode : modes[round], step = round < 0 ? 0 : (4 >> round);
-        const int cx = bx, cy = by;
-        for (int i = -1; i <= 1; i++)
-            for (int j = -1; j <= 1; j++) {
-                const int xd = i * step, yd = j * step;
-                if (round < 0 ? (i || j) : (!i && !j))
-                    continue;
-                if (mode >= 2 && xd != 0 && yd != 0)  // svt_check_position
-                    continue;
-                if (best == 0)
-                    continue;
-                if (c.subpel_early_exit_th && best < (((uint64_t)(bsize * bsize) * c.subpel_early_exit_th) << s.is16))
-                    continue;
-                const int mvx = (int16_t)(cx + xd), mvy = (int16_t)(cy + yd);
-                int       col, row;
-                clamp_mv(s.a->mi_rows, s.a->mi_cols, bsize, bsize, mvx, mvy, 0, s.ox + lx, s.oy + ly, bsize, col, row);
-                const int      tl = (xd == 0 && yd == 0) ? c.sub_sampling_shift : 0;
-                const uint64_t d  = eval_position<bsize>(L, s, lx, ly, kernel, col, row, wx0, wy0, tl, c.sub_sampling_shift);
-                if (d < best)
-                    best = d, bx = mvx, by = mvy;
+    {
+        // the margin rows / columns nobody reads may lie outside the padded plane: keep the address inside it
+        const int32_t lo = (int32_t)s.a->idx_min, hi = (int32_t)s.a->idx_max;
+        for (int i = tid; i < nblk * WD * WDP; i += 256) {
+            const int cc = i & (WDP - 1), rr = i / WDP, b = rr / WD, r = rr - b * WD;
+            if (cc < WD) {
+                const Blk &B = L.blk[b];
+                int32_t idx = (s.oy + B.wy + r) * (int32_t)s.ref_stride + s.ox + B.wx + cc;
+                idx         = idx < lo ? lo : (idx > hi ? hi : idx);
+                L.win[b * (WD * WD) + r * WD + cc] = (uint16_t)ldg<S16>(s.ref0, (ptrdiff_t)idx);
             }
+        }
+    }
+    for (int round = -1; round < 3; round++) {
+        const int mode = round <= 0 ? c.half_pel_mode : (round == 1 ? c.quarter_pel_mode : c.eight_pel_mode);
+        if (round >= 0 && !mode)
+            continue;
+        const int step = round < 0 ? 0 : (4 >> round);
+        // the candidates in the reference's order (i = x outer, j = y inner over -1 .. 1; mode >= 2: svt_check_position drops the diagonals)
+        const int nc = round < 0 ? 1 : (mode >= 2 ? 4 : 8), nitems = nc << lbn;
+        if (tid < nitems) {
+            const int  k = tid >> lbn, b = tid & (nblk - 1), q = round < 0 ? 4 : (mode >= 2 ? 2 * k + 1 : (k < 4 ? k : k + 1));
+            const int  xd = (q / 3 - 1) * step, yd = (q % 3 - 1) * step;
+            const Blk &B = L.blk[b];
+            Item       it;
+            it.mvx = (int16_t)(B.mvx + xd), it.mvy = (int16_t)(B.mvy + yd);
+            int col, row;
+            clamp_mv(s.a->mi_rows, s.a->mi_cols, W, W, it.mvx, it.mvy, 0, s.ox + B.lx, s.oy + B.ly, W, col, row);
+            it.px = (int16_t)(B.lx + (col >> 4) - B.wx), it.py = (int16_t)(B.ly + (row >> 4) - B.wy);
+            it.sx = (uint8_t)(col & 15), it.sy = (uint8_t)(row & 15), it.blk = (uint8_t)b, it.on = !B.done;
+            L.item[tid] = it;
+        }
+        __syncthreads();  // items (and, in the first round, the windows)
+        for (int base = wave * G; base < nitems; base += 4 * G) {
+            const int  idx = base + lane / W;
+            const bool valid = idx < nitems && L.item[idx < nitems ? idx : 0].on;
+            if (__ballot(valid) == 0)
+                continue;
+            const Item     it = L.item[valid ? idx : 0];
+            const uint64_t d  = eval_item<S16, W, NT>(L, it, valid, kidx, s.bd, round < 0, c.sub_sampling_shift);
+            if (valid && (lane & (W - 1)) == 0)
+                L.dist[idx] = d;
+        }
+        __syncthreads();
+        if (tid < nblk) {  // the reference's walk over the candidates of this round
+            Blk           &B = L.blk[tid];
+            uint64_t       best = B.best;
+            int            bx = B.mvx, by = B.mvy;
+            const uint64_t bound = c.subpel_early_exit_th ? (((uint64_t)(W * W) * c.subpel_early_exit_th) << s.is16) : 0;
+            if (!B.done) {
+                for (int k = 0; k < nc; k++) {
+                    const int t = (k << lbn) + tid;
+                    if (best == 0 || best < bound)
+                        continue;
+                    const uint64_t d = L.dist[t];
+                    if (d < best)
+                        best = d, bx = L.item[t].mvx, by = L.item[t].mvy;
+                }
+            }
+            B.best = best, B.mvx = bx, B.mvy = by, B.done = best == 0 || best < bound;
+        }
+        __syncthreads();
     }
 }
 
@@ -293,18 +391,26 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
     const void *src0 = S16 ? (const void *)a.centre.y16 : (const void *)a.centre.y8;
     for (int i = tid; i < 64 * 64; i += 256) L.src[i] = (uint16_t)ldg<S16>(src0, (ptrdiff_t)(oy + (i >> 6)) * a.centre.stride + ox + (i & 63));
     for (int i = tid; i < (int)(sizeof(st) / 4); i += 256) ((uint32_t *)&st)[i] = 0;
+    L.taps[tid >> 7][(tid >> 3) & 15][tid & 7] = TF_KERNELS[(tid >> 7) ? K_BILINEAR : K_REGULAR][(tid >> 3) & 15][tid & 7];
     const SvtHipMeSearchResult sr = R.sr[(size_t)b * 8];
     const uint32_t *best_mv = R.best_mv + (size_t)b * 8 * 85, *best_sad = R.best_sad + (size_t)b * 8 * 85;
     if (tid == 0 && tot)
         atomicAdd(&tot[abs((int)sr.hme_sc_x) > abs((int)sr.hme_sc_y) ? 0 : 1], 1u);
     // svt_aom_motion_estimation_b64 leaves after HME when the HME distortion is below tf_me_exit_th (motion_estimation.c:3179)
     const int use64_th = sr.hme_sad < a.tf_me_exit_th ? 255 : c.use_pred_64x64_only_th;
-    const int k6432 = c.use_2tap ? K_BILINEAR : K_REGULAR;
     // ---- tf_64x64_sub_pel_search
-    uint64_t err64 = 0x7fffffff;
-    int      mv64x = (int16_t)((use64_th == 255 ? sr.hme_sc_x : mvx_of(best_mv[0])) << 3);
-    int      mv64y = (int16_t)((use64_th == 255 ? sr.hme_sc_y : mvy_of(best_mv[0])) << 3);
-    subpel_search<S16, 64>(L, s, 0, 0, k6432, err64, mv64x, mv64y);
+    if (tid == 0) {
+        Blk &B = L.blk[0];
+        B.best = 0x7fffffff, B.lx = B.ly = 0;
+        B.mvx = (int16_t)((use64_th == 255 ? sr.hme_sc_x : mvx_of(best_mv[0])) << 3);
+        B.mvy = (int16_t)((use64_th == 255 ? sr.hme_sc_y : mvy_of(best_mv[0])) << 3);
+    }
+    if (c.use_2tap)
+        search_blocks<S16, 64, 2>(L, s, 1, K_BILINEAR);
+    else
+        search_blocks<S16, 64, 8>(L, s, 1, K_REGULAR);
+    const uint64_t err64 = L.blk[0].best;
+    const int      mv64x = L.blk[0].mvx, mv64y = L.blk[0].mvy;
     bool use64 = false;
     if (use64_th) {
         if (use64_th == 255) {
@@ -316,41 +422,44 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
             use64 = ((x - y) * 100) / y < use64_th;
         }
     }
-    // the 32x32 results live in the block's state record in LDS (st.err32 / mv32_*), not in run-time-indexed local arrays: those went
-    // to scratch memory (120 B per lane)
-    if (!use64) {
-        uint64_t sum32 = 0;
-        for (int i = 0; i < 4; i++) {
-            uint64_t e  = 0x7fffffff;
-            int      mx = (int16_t)(mvx_of(best_mv[1 + i]) << 3), my = (int16_t)(mvy_of(best_mv[1 + i]) << 3);
-            subpel_search<S16, 32>(L, s, (i & 1) * 32, (i >> 1) * 32, k6432, e, mx, my);
-            sum32 += e;
-            if (tid == 0)
-                st.err32[i] = e, st.mv32_x[i] = (int16_t)mx, st.mv32_y[i] = (int16_t)my;
+    if (!use64) {  // ---- tf_32x32_sub_pel_search: the four blocks side by side
+        __syncthreads();  // everybody has read the 64x64 result
+        if (tid < 4) {
+            Blk &B = L.blk[tid];
+            B.best = 0x7fffffff, B.lx = (int16_t)((tid & 1) * 32), B.ly = (int16_t)((tid >> 1) * 32);
+            B.mvx = (int16_t)(mvx_of(best_mv[1 + tid]) << 3), B.mvy = (int16_t)(mvy_of(best_mv[1 + tid]) << 3);
         }
+        if (c.use_2tap)
+            search_blocks<S16, 32, 2>(L, s, 4, K_BILINEAR);
+        else
+            search_blocks<S16, 32, 8>(L, s, 4, K_REGULAR);
+        uint64_t sum32 = 0;
+        for (int i = 0; i < 4; i++) sum32 += L.blk[i].best;
+        if (tid < 4)
+            st.err32[tid] = L.blk[tid].best, st.mv32_x[tid] = (int16_t)L.blk[tid].mvx, st.mv32_y[tid] = (int16_t)L.blk[tid].mvy;
         if (err64 * 14 < sum32 * 16 && err64 < (1u << 18))
             use64 = true;
-        __syncthreads();  // st.err32 of lane 0 -> every lane
+        __syncthreads();  // st.err32 -> every lane; L.blk[] may be rewritten
     }
     if (!use64) {
         for (int i = 0; i < 4; i++) {
-            const int      lx = (i & 1) * 32, ly = (i >> 1) * 32;
             const uint64_t e32 = st.err32[i];
             if (e32 < c.pred_error_32x32_th)
                 continue;  // split flag stays 0
-            // tf_16x16_sub_pel_search (always the regular 8-tap kernel), derive_tf_32x32_block_split_flag without 8x8
-            int64_t sum16 = 0;
-            for (int k = 0; k < 4; k++) {
-                const int q  = i * 4 + k;
-                uint64_t  e  = 0x7fffffff;
-                int       mx = (int16_t)(mvx_of(best_mv[5 + q]) << 3), my = (int16_t)(mvy_of(best_mv[5 + q]) << 3);
-                subpel_search<S16, 16>(L, s, lx + (k & 1) * 16, ly + (k >> 1) * 16, K_REGULAR, e, mx, my);
-                sum16 += (int)e;
-                if (tid == 0)
-                    st.err16[q] = e, st.mv16_x[q] = (int16_t)mx, st.mv16_y[q] = (int16_t)my;
+            // tf_16x16_sub_pel_search (always the regular 8-tap kernel) of the four 16x16 blocks, derive_tf_32x32_block_split_flag without 8x8
+            if (tid < 4) {
+                Blk &B = L.blk[tid];
+                B.best = 0x7fffffff, B.lx = (int16_t)((i & 1) * 32 + (tid & 1) * 16), B.ly = (int16_t)((i >> 1) * 32 + (tid >> 1) * 16);
+                B.mvx = (int16_t)(mvx_of(best_mv[5 + i * 4 + tid]) << 3), B.mvy = (int16_t)(mvy_of(best_mv[5 + i * 4 + tid]) << 3);
             }
+            search_blocks<S16, 16, 8>(L, s, 4, K_REGULAR);
+            int64_t sum16 = 0;
+            for (int k = 0; k < 4; k++) sum16 += (int)L.blk[k].best;
+            if (tid < 4)
+                st.err16[i * 4 + tid] = L.blk[tid].best, st.mv16_x[i * 4 + tid] = (int16_t)L.blk[tid].mvx, st.mv16_y[i * 4 + tid] = (int16_t)L.blk[tid].mvy;
             if (tid == 0)
                 st.split32[i] = !((int)e32 * 14 < (int)sum16 * 16);
+            __syncthreads();  // L.blk[] is rewritten by the next 32x32 block
         }
     }
     __syncthreads();
