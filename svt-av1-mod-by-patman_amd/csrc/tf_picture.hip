@@ -103,7 +103,7 @@ struct Item {  // one candidate position of a round
 };
 struct Lds {
     uint16_t src[64 * 64];
-    uint16_t win[WIN_ELEMS];
+    alignas(4) uint16_t win[WIN_ELEMS];
     alignas(16) int16_t taps[2][16][8];  // regular, bilinear
     Item     item[MAX_ITEMS];
     uint64_t dist[MAX_ITEMS];
@@ -135,7 +135,7 @@ __device__ __forceinline__ uint32_t ldg(const void *p, ptrdiff_t i) {
 //
 // An item is evaluated by W lanes of ONE wave (W = block width: a wave carries 64 / W items), without a workgroup barrier: a lane
 // owns a column of the block and streams down the rows of the staged reference window; the horizontal filter of a row is NT / 2
-// v_dot2_i32_i16 over one unaligned LDS read of the NT samples, its result enters a register ring of row PAIRS, and the vertical
+// v_dot2_i32_i16 over the NT samples of the row (aligned dword reads, funnel-shifted by the lane's parity), its result enters a register ring of row PAIRS, and the vertical
 // filter of an output row is NT / 2 v_dot2_i32_i16 over that ring — no intermediate plane in LDS.  The 2-D form is used for every
 // position of a mixed wave: with the unit kernel of phase 0 on one axis it returns exactly what svt_av1_(highbd_)convolve_x_sr /
 // _y_sr / the plain copy return (round_0 = 3, round_1 = 11: the offsets cancel and rnd(rnd(s, 3), 4), rnd(s, 7) fall out); waves
@@ -144,10 +144,17 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b), c, false);
 }
-// NT consecutive 16-bit samples from LDS as NT / 2 packed pairs; the address is 2-byte aligned only (gfx950 reads unaligned LDS data)
+// NT consecutive 16-bit samples of L.win from element e on, as NT / 2 packed pairs.  An LDS access that is not naturally aligned
+// is executed one lane per cycle on gfx950 (tools/ubench/lds_unaligned.hip: 65 cycles per wave-instruction whatever its width,
+// against 5 - 7 aligned), so the lane reads the aligned dwords around its samples and funnel-shifts them by its parity.
 template <int NT>
-__device__ __forceinline__ void lds_pairs(const uint16_t *p, uint32_t (&v)[NT / 2]) {
-    __builtin_memcpy(v, p, NT * 2);
+__device__ __forceinline__ void lds_pairs(const uint16_t *win, int e, uint32_t sh, uint32_t (&v)[NT / 2]) {
+    const uint32_t *q = (const uint32_t *)win + (e >> 1);
+    uint32_t        d[NT / 2 + 1];
+#pragma unroll
+    for (int k = 0; k <= NT / 2; k++) d[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < NT / 2; k++) v[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
 }
 // the NT non-zero taps of a phase as packed pairs in tap order (bilinear: taps 3 and 4 straddle two dwords of the 8-tap row)
 template <int NT>
@@ -185,6 +192,7 @@ __device__ uint64_t eval_item(const Lds &L, const Item &it, bool valid, int kidx
     tap_pairs<NT>(L.taps[kidx][it.sy], fy);
     int32_t  sum = 0;
     uint32_t sse = 0;
+    const uint32_t psh = ((win0 - 3 + K0) & 1) * 16;  // the pitch is even: the parity of a lane's first sample is the same in every row
     if (!has_v) {
         // rows o = i << vshift straight from the window: copy or horizontal filter
         int wo = win0 - 3 + K0, so = src0;
@@ -192,7 +200,7 @@ __device__ uint64_t eval_item(const Lds &L, const Item &it, bool valid, int kidx
             int32_t p;
             if (has_h) {
                 uint32_t x[NT / 2];
-                lds_pairs<NT>(&L.win[wo], x);
+                lds_pairs<NT>(L.win, wo, psh, x);
                 int32_t acc = 4;
 #pragma unroll
                 for (int k = 0; k < NT / 2; k++) acc = dot2(x[k], fx[k], acc);
@@ -221,7 +229,7 @@ __device__ uint64_t eval_item(const Lds &L, const Item &it, bool valid, int kidx
                     uint32_t h;
                     if (has_h) {
                         uint32_t x[NT / 2];
-                        lds_pairs<NT>(&L.win[wo], x);
+                        lds_pairs<NT>(L.win, wo, psh, x);
                         int32_t acc = c0;
 #pragma unroll
                         for (int k = 0; k < NT / 2; k++) acc = dot2(x[k], fx[k], acc);
