@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdint>
 constexpr int IT = 2048;
-template <int WIDTH, int STEP, int OFF>
+typedef unsigned v4 __attribute__((ext_vector_type(4)));
+typedef unsigned v2 __attribute__((ext_vector_type(2)));
+template <int WIDTH, int STEP, int OFF, int ACTIVE = 64>
 __global__ __launch_bounds__(256) void k(unsigned *out, int rows) {
     __shared__ __attribute__((aligned(16))) uint8_t buf[16384];
     for (int i = threadIdx.x; i < 16384; i += 256) buf[i] = (uint8_t)(i * 7);
@@ -14,9 +16,19 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int rows) {
     const int lane = threadIdx.x & 63;
     unsigned  acc = 0;
     int       off = lane * STEP + OFF;
+    if (lane >= ACTIVE)
+        return;
     for (int i = 0; i < IT; i++) {
         const uint8_t *p = buf + off;
-        if (WIDTH == 16) {
+        if (WIDTH == -16) {
+            v4 v = {acc, acc, acc, acc};
+            asm volatile("ds_write_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : : "v"((unsigned)(uintptr_t)p), "v"(v) : "memory");
+            acc += i;
+        } else if (WIDTH == -8) {
+            v2 v = {acc, acc};
+            asm volatile("ds_write_b64 %0, %1\n s_waitcnt lgkmcnt(0)" : : "v"((unsigned)(uintptr_t)p), "v"(v) : "memory");
+            acc += i;
+        } else if (WIDTH == 16) {
             uint4 v;
             asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
             acc += v.x ^ v.w;
@@ -37,14 +49,14 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int rows) {
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
-template <int WIDTH, int STEP, int OFF> void run(const char *name, unsigned *d) {
+template <int WIDTH, int STEP, int OFF, int ACTIVE = 64> void run(const char *name, unsigned *d) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     const int blocks = 256 * 4;  // 4 workgroups of 4 waves per CU: 4 waves per SIMD
     const int rows = 256;        // keeps the alignment class of every lane
-    hipLaunchKernelGGL((k<WIDTH, STEP, OFF>), dim3(blocks), dim3(256), 0, 0, d, rows);
+    hipLaunchKernelGGL((k<WIDTH, STEP, OFF, ACTIVE>), dim3(blocks), dim3(256), 0, 0, d, rows);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<WIDTH, STEP, OFF>), dim3(blocks), dim3(256), 0, 0, d, rows);
+    hipLaunchKernelGGL((k<WIDTH, STEP, OFF, ACTIVE>), dim3(blocks), dim3(256), 0, 0, d, rows);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -67,6 +79,17 @@ int main() {
     run<4, 4, 0>("b32, lane stride 4 B, aligned", d);
     run<4, 2, 0>("b32, lane stride 2 B (overlapping), 2 B aligned", d);
     run<4, 1, 0>("b32, lane stride 1 B (overlapping), any alignment", d);
+    run<16, 16, 4>("b128, lane stride 16 B (disjoint), 4 B aligned", d);
+    run<16, 16, 8>("b128, lane stride 16 B (disjoint), 8 B aligned", d);
+    run<8, 8, 4>("b64, lane stride 8 B (disjoint), 4 B aligned", d);
+    run<16, 16, 4, 1>("b128, 4 B aligned, ONE active lane", d);
+    run<16, 16, 4, 8>("b128, 4 B aligned, 8 active lanes", d);
+    run<-16, 16, 0>("write b128, lane stride 16 B, aligned", d);
+    run<-16, 16, 4>("write b128, lane stride 16 B, 4 B aligned", d);
+    run<-16, 16, 8>("write b128, lane stride 16 B, 8 B aligned", d);
+    run<-8, 8, 0>("write b64, lane stride 8 B, aligned", d);
+    run<-8, 8, 4>("write b64, lane stride 8 B, 4 B aligned", d);
+    run<-16, 16, 4, 4>("write b128, 4 B aligned, 4 active lanes", d);
     run<2, 2, 0>("u16, lane stride 2 B", d);
     run<2, 1, 0>("u16, lane stride 1 B, any alignment", d);
     return 0;
