@@ -1,7 +1,8 @@
 // lds_unaligned.hip — what an LDS read costs on gfx950 by width and alignment, when every lane reads a window that overlaps its
 // neighbour's (lane c reads bytes [c * STEP + OFF, + WIDTH)): the access pattern of a per-lane FIR filter over a row in LDS.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/lds_unaligned.hip -o tools/ubench/lds_unaligned.bin && tools/ubench/lds_unaligned.bin
-// Prints ns per wave-instruction per CU with 4 waves per SIMD issuing nothing else (the LDS pipe is the only busy unit).
+// Prints ns per wave-instruction per CU with 4 waves per SIMD, four accesses in flight per wave, nothing else issued (the LDS
+// pipe is the only busy unit).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -18,34 +19,53 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int rows) {
     int       off = lane * STEP + OFF;
     if (lane >= ACTIVE)
         return;
-    for (int i = 0; i < IT; i++) {
-        const uint8_t *p = buf + off;
+    for (int i = 0; i < IT; i += 4) {  // four accesses in flight per wave: the LDS pipe, not its latency, is what is measured
+        const unsigned a0 = (unsigned)(uintptr_t)(buf + off), a1 = (unsigned)(uintptr_t)(buf + ((off + rows) & 8191)),
+                       a2 = (unsigned)(uintptr_t)(buf + ((off + 2 * rows) & 8191)), a3 = (unsigned)(uintptr_t)(buf + ((off + 3 * rows) & 8191));
         if (WIDTH == -16) {
             v4 v = {acc, acc, acc, acc};
-            asm volatile("ds_write_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : : "v"((unsigned)(uintptr_t)p), "v"(v) : "memory");
+            asm volatile("ds_write_b128 %0, %4\n ds_write_b128 %1, %4\n ds_write_b128 %2, %4\n ds_write_b128 %3, %4\n s_waitcnt lgkmcnt(0)"
+                         :
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(v)
+                         : "memory");
             acc += i;
         } else if (WIDTH == -8) {
             v2 v = {acc, acc};
-            asm volatile("ds_write_b64 %0, %1\n s_waitcnt lgkmcnt(0)" : : "v"((unsigned)(uintptr_t)p), "v"(v) : "memory");
+            asm volatile("ds_write_b64 %0, %4\n ds_write_b64 %1, %4\n ds_write_b64 %2, %4\n ds_write_b64 %3, %4\n s_waitcnt lgkmcnt(0)"
+                         :
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(v)
+                         : "memory");
             acc += i;
         } else if (WIDTH == 16) {
-            uint4 v;
-            asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
-            acc += v.x ^ v.w;
+            v4 v0, v1, v2, v3;
+            asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %6\n ds_read_b128 %3, %7\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                         : "memory");
+            acc += v0.x ^ v1.y ^ v2.z ^ v3.w;
         } else if (WIDTH == 8) {
-            uint2 v;
-            asm volatile("ds_read_b64 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
-            acc += v.x ^ v.y;
+            v2 v0, v1, v2, v3;
+            asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %5\n ds_read_b64 %2, %6\n ds_read_b64 %3, %7\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                         : "memory");
+            acc += v0.x ^ v1.y ^ v2.x ^ v3.y;
         } else if (WIDTH == 4) {
-            unsigned v;
-            asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
-            acc += v;
+            unsigned v0, v1, v2, v3;
+            asm volatile("ds_read_b32 %0, %4\n ds_read_b32 %1, %5\n ds_read_b32 %2, %6\n ds_read_b32 %3, %7\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                         : "memory");
+            acc += v0 ^ v1 ^ v2 ^ v3;
         } else {
-            unsigned v;
-            asm volatile("ds_read_u16 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
-            acc += v;
+            unsigned v0, v1, v2, v3;
+            asm volatile("ds_read_u16 %0, %4\n ds_read_u16 %1, %5\n ds_read_u16 %2, %6\n ds_read_u16 %3, %7\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                         : "memory");
+            acc += v0 ^ v1 ^ v2 ^ v3;
         }
-        off = (off + rows) & 8191;
+        off = (off + 4 * rows) & 8191;
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
