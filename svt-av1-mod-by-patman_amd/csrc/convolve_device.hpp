@@ -1,6 +1,6 @@
 // convolve_device.hpp — one 64 x 64 tile of one predicted block (the body of convolve_sr_kernel, inter_convolve.hip) as a device
 // function, shared with the temporal filter's prediction kernel (tf_picture.hip).  All 256 threads of the workgroup call it;
-// `in` / `im` are the workgroup's LDS buffers ((TILE + 7) * IP uint16 and (TILE + 7) * TILE int16).
+// `in` / `im` are the workgroup's LDS buffers ((TILE + 7) * IP + CONV_IN_SLACK uint16, 4-byte aligned, and (TILE + 7) * TILE int16).
 #pragma once
 #include <cstdint>
 
@@ -39,6 +39,26 @@ __device__ __forceinline__ void comp_out(const SvtHipConvolveDesc &d, int y, int
     }
 }
 
+// acc + sum of f[k] * in[e + k], k = 0 .. 7, the taps as four packed pairs.  The eight samples start at a 2-byte aligned address, and a
+// DS access that is not naturally aligned is executed one lane per cycle on gfx950 (tools/ubench/lds_unaligned.hip: 65 cycles per
+// wave-instruction) — which is what the compiler makes of eight adjacent 16-bit reads (one ds_read_b128), since the target allows
+// unaligned DS access.  So: the five aligned dwords around the samples, funnel-shifted by the parity of e, and four v_dot2_i32_i16
+// (samples < 2^15, taps are int16: the sum is the same integer).  Reads one dword past in[e + 7] when e is even: `in` is declared with
+// CONV_IN_SLACK spare elements.
+constexpr int CONV_IN_SLACK = 2;
+typedef short conv_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t hsum8(const uint16_t *in, int e, const uint32_t (&fp)[4], int32_t acc) {
+    const uint32_t *q  = (const uint32_t *)in + (e >> 1);
+    const uint32_t  sh = (uint32_t)(e & 1) * 16;
+    uint32_t        d[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(conv_i16x2, __builtin_amdgcn_alignbit(d[k + 1], d[k], sh)), __builtin_bit_cast(conv_i16x2, fp[k]), acc, false);
+    return acc;
+}
+
 // tile: index of the T x T tile inside the block (row-major); a tile beyond the block returns at once.  NT threads call it together
 // (the whole workgroup); in / im: (T + 7) * P uint16 and (T + 7) * T int16 of LDS.
 template <int NT, int T, int P>
@@ -61,6 +81,9 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
         fx[k] = __builtin_amdgcn_readfirstlane(k < tx ? (int)d.filter_x[k] : 0);
         fy[k] = __builtin_amdgcn_readfirstlane(k < ty ? (int)d.filter_y[k] : 0);
     }
+    uint32_t fxp[4];  // the horizontal taps as packed pairs
+#pragma unroll
+    for (int k = 0; k < 4; k++) fxp[k] = ((uint32_t)fx[2 * k] & 0xffffu) | ((uint32_t)fx[2 * k + 1] << 16);
     const int ew = tw + (tx ? tx - 1 : 0), eh = th + (ty ? ty - 1 : 0);  // staged extent
     for (int idx = threadIdx.x; idx < eh * ew; idx += NT) {
         const int r = idx / ew, c = idx - r * ew;
@@ -74,7 +97,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
             for (int idx = threadIdx.x; idx < eh * tw; idx += NT) {
                 const int r = idx / tw, c = idx - r * tw;
                 int32_t   sum = 1 << (bd + FILTER_BITS - 1);
-                _Pragma("unroll") for (int k = 0; k < 8; k++) sum += fx[k] * (int32_t)in[r * P + c + k];
+                sum = hsum8(in, r * P + c, fxp, sum);
                 im[r * T + c] = (int16_t)(uint16_t)rnd(sum, r0);
             }
             __syncthreads();
@@ -93,7 +116,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
                 res = rnd(res, r1) + round_offset;
             } else if (tx) {
                 res = 0;
-                _Pragma("unroll") for (int k = 0; k < 8; k++) res += fx[k] * (int32_t)in[r * P + c + k];
+                res = hsum8(in, r * P + c, fxp, res);
                 res = (1 << (FILTER_BITS - r1)) * rnd(res, r0) + round_offset;
             } else {
                 res = (uint16_t)((uint16_t)((int32_t)in[r * P + c] << round_bits) + (uint16_t)round_offset);
@@ -114,7 +137,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
         for (int idx = threadIdx.x; idx < th * tw; idx += NT) {
             const int r = idx / tw, c = idx - r * tw;
             int32_t   res = 0;
-            _Pragma("unroll") for (int k = 0; k < 8; k++) res += fx[k] * (int32_t)in[r * P + c + k];
+            res = hsum8(in, r * P + c, fxp, res);
             stpx(d.dst, (size_t)(y0 + r) * d.dst_stride + x0 + c, is16, rnd(rnd(res, r0), bits), bd);
         }
         return;
@@ -132,7 +155,7 @@ __device__ __forceinline__ void convolve_tile_t(const SvtHipConvolveDesc &d, con
     for (int idx = threadIdx.x; idx < eh * tw; idx += NT) {
         const int r = idx / tw, c = idx - r * tw;
         int32_t   sum = 1 << (bd + FILTER_BITS - 1);
-        _Pragma("unroll") for (int k = 0; k < 8; k++) sum += fx[k] * (int32_t)in[r * P + c + k];
+        sum = hsum8(in, r * P + c, fxp, sum);
         im[r * T + c] = (int16_t)(uint16_t)rnd(sum, r0);
     }
     __syncthreads();

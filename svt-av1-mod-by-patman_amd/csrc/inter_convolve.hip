@@ -17,7 +17,7 @@ using namespace svthip::conv;
 namespace {
 
 __global__ __launch_bounds__(256) void convolve_sr_kernel(const SvtHipConvolveDesc *__restrict__ descs) {
-    __shared__ uint16_t in[(TILE + 7) * IP];
+    __shared__ alignas(4) uint16_t in[(TILE + 7) * IP + CONV_IN_SLACK];
     __shared__ int16_t  im[(TILE + 7) * TILE];
     const SvtHipConvolveDesc d = descs[blockIdx.x];
     convolve_tile(d, (int)blockIdx.y, in, im);

@@ -42,7 +42,7 @@ constexpr int SGR_NT = 512;
 template <int MODE>
 __global__ __launch_bounds__(SGR_NT) void sgr_filter_kernel(SgrGeom g, int ep, int32_t *__restrict__ flt0, int32_t *__restrict__ flt1,
                                                          uint32_t flt_stride, void *__restrict__ dst, uint32_t dst_stride, int xq0, int xq1) {
-    __shared__ uint16_t tile[70 * TP];
+    __shared__ alignas(4) uint16_t tile[70 * TP];
     __shared__ int32_t  Am[66 * AP], Bm[66 * AP];
     const int tid = threadIdx.x;
     const int j0 = blockIdx.x * g.pu_w, i0 = blockIdx.y * g.pu_h;

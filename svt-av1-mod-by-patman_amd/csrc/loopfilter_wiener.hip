@@ -228,7 +228,7 @@ struct Taps {
 };
 __global__ __launch_bounds__(256) void wiener_convolve_kernel(const void *__restrict__ src, uint32_t src_stride, void *__restrict__ dst,
                                                               uint32_t dst_stride, int w, int h, Taps f, int is16, int bd, int r0, int r1) {
-    __shared__ uint16_t in[(64 + 7) * lr::WIENER_IP];
+    __shared__ alignas(4) uint16_t in[(64 + 7) * lr::WIENER_IP + lr::WIENER_IN_SLACK];
     __shared__ uint16_t tmp[(64 + 7) * 64];
     constexpr int IP = lr::WIENER_IP;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;

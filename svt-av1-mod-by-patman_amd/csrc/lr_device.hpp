@@ -29,14 +29,30 @@ __device__ __forceinline__ int32_t ldpx(const void *p, size_t idx, int is16) {
 
 // A / B of one map position from the LDS tile (restoration.c:709-770 / 842-903); (i, j) relative to the unit, r = 1 | 2
 template <int R> __device__ __forceinline__ void ab_at(const uint16_t *tile, int i, int j, uint32_t s, int bd, int32_t &A, int32_t &B) {
-    uint32_t sum = 0, ssq = 0;
+    // box sums over (2R + 1)^2 samples.  A lane's 2R + 1 samples of a row start at a 2-byte aligned address; read as adjacent 16-bit
+    // values they become one unaligned ds_read_b64, which gfx950 executes one lane per cycle (tools/ubench/lds_unaligned.hip).  So: the
+    // R + 1 aligned dwords that hold them, funnel-shifted by the lane's parity (the pitch is even: one parity for all rows), the odd
+    // sample masked; sum and sum of squares by v_dot2_u32_u16.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const int      e0 = (i + 3 - R) * TP + j + 3 - R;
+    const uint32_t sh = (uint32_t)(e0 & 1) * 16;
+    const u16x2    ones = {1, 1};
+    uint32_t       sum = 0, ssq = 0;
 #pragma unroll
-    for (int dy = -R; dy <= R; dy++)
+    for (int dy = 0; dy <= 2 * R; dy++) {
+        const uint32_t *q = (const uint32_t *)tile + ((e0 + dy * TP) >> 1);
+        uint32_t        d[R + 1];
 #pragma unroll
-        for (int dx = -R; dx <= R; dx++) {
-            const uint32_t v = tile[(i + 3 + dy) * TP + j + 3 + dx];
-            sum += v, ssq += v * v;
+        for (int k = 0; k <= R; k++) d[k] = q[k];
+#pragma unroll
+        for (int k = 0; k <= R; k++) {
+            uint32_t pr = __builtin_amdgcn_alignbit(d[k < R ? k + 1 : k], d[k], sh);
+            if (k == R)
+                pr &= 0xffffu;
+            const u16x2 v = __builtin_bit_cast(u16x2, pr);
+            sum = __builtin_amdgcn_udot2(v, ones, sum, false), ssq = __builtin_amdgcn_udot2(v, v, ssq, false);
         }
+    }
     constexpr uint32_t n = (2 * R + 1) * (2 * R + 1), one_by_n = (4096 + n / 2) / n;  // svt_aom_eb_one_by_x[n - 1]
     const uint32_t a = (ssq + ((1u << (2 * (bd - 8))) >> 1)) >> (2 * (bd - 8)), b = (sum + ((1u << (bd - 8)) >> 1)) >> (bd - 8);
     const uint32_t p = (a * n < b * b) ? 0u : a * n - b * b;
@@ -130,19 +146,36 @@ __device__ __forceinline__ void sgr_tile_filter(const uint16_t *tile, int32_t *A
     }
 }
 
-// Separable 7-tap Wiener filter of one tw x th (<= 64 x 64) unit: `in` = LDS tile of (th + 7) x (tw + 7) samples, pitch IP, sample
+// Separable 7-tap Wiener filter of one tw x th (<= 64 x 64) unit: `in` = LDS tile of (th + 7) x (tw + 7) samples (4-byte aligned, WIENER_IN_SLACK readable elements behind it), pitch IP, sample
 // (0,0) at [3][3]; `tmp` = (th + 7) x 64 uint16 LDS scratch.  svt_av1_(highbd_)wiener_convolve_add_src (convolve.c:57-200).
-constexpr int WIENER_IP = 64 + 8;
+constexpr int WIENER_IP = 64 + 8, WIENER_IN_SLACK = 2;  // the horizontal pass reads one dword past the last sample of a row
+typedef short lr_i16x2 __attribute__((ext_vector_type(2)));
 template <int NT>
 __device__ __forceinline__ void wiener_tile_filter(const uint16_t *in, uint16_t *tmp, int tid, int tw, int th, int x0, int y0, const int16_t *fx,
                                                    const int16_t *fy, int bd, int r0, int r1, int is16, void *__restrict__ dst, uint32_t dst_stride) {
     constexpr int IP = WIENER_IP;
     const int limit = (1 << (bd + 1 + 7 - r0)) - 1;
-    for (int idx = tid; idx < (th + 7) * tw; idx += NT) {
-        const int r = idx / tw, c = idx - r * tw;
-        int32_t   sum = ((int32_t)in[r * IP + c + 3] << 7) + (1 << (bd + 7 - 1));
+    // the seven horizontal taps (+ 128 on the centre one: the "add_src" term) as four packed pairs, the 8th coefficient is zero by
+    // construction.  The seven samples of a lane start at a 2-byte aligned address: adjacent 16-bit reads become ONE unaligned
+    // ds_read_b64 / b128, which gfx950 executes one lane per cycle (tools/ubench/lds_unaligned.hip) — read the aligned dwords around
+    // them and funnel-shift by the lane's parity instead; v_dot2_i32_i16 does two taps per instruction.
+    uint32_t fxp[4];
 #pragma unroll
-        for (int k = 0; k < 7; k++) sum += (int32_t)in[r * IP + c + k] * fx[k];  // the 8th coefficient is zero by construction
+    for (int k = 0; k < 4; k++) {
+        const int32_t lo = fx[2 * k] + (2 * k == 3 ? 128 : 0), hi2 = 2 * k + 1 < 7 ? fx[2 * k + 1] + (2 * k + 1 == 3 ? 128 : 0) : 0;
+        fxp[k] = __builtin_amdgcn_readfirstlane((int32_t)(((uint32_t)lo & 0xffffu) | ((uint32_t)hi2 << 16)));
+    }
+    for (int idx = tid; idx < (th + 7) * tw; idx += NT) {
+        const int r = idx / tw, c = idx - r * tw, e = r * IP + c;
+        const uint32_t *q  = (const uint32_t *)in + (e >> 1);
+        const uint32_t  sh = (uint32_t)(e & 1) * 16;
+        uint32_t        d[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) d[k] = q[k];
+        int32_t sum = 1 << (bd + 7 - 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(lr_i16x2, __builtin_amdgcn_alignbit(d[k + 1], d[k], sh)), __builtin_bit_cast(lr_i16x2, fxp[k]), sum, false);
         const int32_t v = (sum + ((1 << r0) >> 1)) >> r0;
         tmp[r * 64 + c] = (uint16_t)(v < 0 ? 0 : (v > limit ? limit : v));
     }

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
 // would find an empty slot: 2.3 ms per reference picture at 4K.)
 constexpr int SMALL_T = 16, SMALL_P = SMALL_T + 8;
 __global__ __launch_bounds__(256) void tf_predict_kernel(const RefineRef *__restrict__ refs) {
-    __shared__ uint16_t in[(conv::TILE + 7) * conv::IP];
+    __shared__ alignas(4) uint16_t in[(conv::TILE + 7) * conv::IP + conv::CONV_IN_SLACK];
     __shared__ int16_t  im[(conv::TILE + 7) * conv::TILE];
     const SvtHipConvolveDesc *descs = refs[blockIdx.y].desc + (size_t)blockIdx.x * DESC_PER_B64;
     // which slots are this kernel's: every wave looks at all 48 widths at once (walking the slots one dependent descriptor load
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void tf_predict_kernel(const RefineRef *__rest
 }
 constexpr int SMALL_SPLIT = 4;  // one-wave workgroups per 64x64 block: its small slots are dealt round-robin to them
 __global__ __launch_bounds__(64) void tf_predict_small_kernel(const RefineRef *__restrict__ refs) {
-    __shared__ uint16_t in[(SMALL_T + 7) * SMALL_P];
+    __shared__ alignas(4) uint16_t in[(SMALL_T + 7) * SMALL_P + conv::CONV_IN_SLACK];
     __shared__ int16_t  im[(SMALL_T + 7) * SMALL_T];
     const SvtHipConvolveDesc *descs = refs[blockIdx.y].desc + (size_t)(blockIdx.x / SMALL_SPLIT) * DESC_PER_B64;
     const int      lane = threadIdx.x, part = blockIdx.x % SMALL_SPLIT;
