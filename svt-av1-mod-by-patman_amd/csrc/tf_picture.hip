@@ -781,10 +781,11 @@ extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void
     hipLaunchKernelGGL(tf_blocks_kernel, dim3(nb, job->n_refs + 1), dim3(256), 0, st, a, d_refs, job->n_refs, static_blocks, outs);
     SVT_HIP_CHECK(hipGetLastError());
     stage_commit(st);
-    rc = svt_hip_tf_central_batch(static_blocks, nb * 4, st);
-    for (uint32_t r = 0; r < job->n_refs && rc == SVT_HIP_OK; r++) rc = svt_hip_tf_accumulate_batch(refs[r].blocks, nb * 4, st);
-    if (rc == SVT_HIP_OK)
-        rc = svt_hip_tf_normalise_batch(static_blocks, outs, nb * 4, st);
+    {  // central + the accumulation over every reference + normalise: one launch, accumulators in registers
+        const SvtHipTfBlock *lists[SVT_HIP_TF_MAX_REFS];
+        for (uint32_t r = 0; r < job->n_refs; r++) lists[r] = refs[r].blocks;
+        rc = svt_hip_tf_filter_blocks(lists, job->n_refs, static_blocks, outs, nb * 4, st);
+    }
     return rc;
 }
 

@@ -3,7 +3,7 @@
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_stage
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_stage -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-pmc --no-cpu-baseline > $REPO/gpurun_out/r2/kt_stage.log 2>&1 || echo "failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_stage -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-pmc --no-cpu-baseline > $REPO/gpurun_out/r3/kt_stage.log 2>&1 || echo "failed"
 f=$(find /tmp/kt_stage -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
