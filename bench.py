@@ -764,8 +764,9 @@ def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
     tf_sum = int(mw.dpyr[c].full.t.to(torch.int64).sum().item())
     mw.dpyr[c].full.t.copy_(luma0)
     P = W * H
-    # per reference: centre + reference pyramids through ME, sub-pel windows, prediction written + read, accumulators; once: normalise
-    alg = 4 * (1.3125 * 2 * P + 2 * P + 1.5 * P * (1 + 1 + 6 + 6)) + 1.5 * P * (6 + 1 + 1)
+    # per reference: centre + reference pyramids through ME, sub-pel windows, prediction written + read; once: the source read and the
+    # filtered picture written (the accumulators live in registers since round 3: 12 bytes per sample and reference less than before)
+    alg = 4 * (1.3125 * 2 * P + 2 * P + 1.5 * P * (1 + 1)) + 1.5 * P * (1 + 1)
     out.append(roof("svt_hip_tf_filter_picture (ME_MCTF + sub-pel + predict + accumulate, 4 refs, luma + chroma)", alg, ms,
                     unit_of_work="one 4K 8-bit 4:2:0 picture against 4 reference pictures", result_checksum=tf_sum, pmc_key="tf"))
     del ws

@@ -66,11 +66,12 @@ SVT_HIP_API int32_t svt_hip_tf_normalise_batch(const SvtHipTfBlock *d_blocks, co
 /* The three steps above for a whole window in ONE launch: central, accumulate over the n_refs reference pictures (d_ref_blocks: a HOST
  * array of n_refs device arrays of n_blocks records, block i of every array describing the same 32x32 block; only pred / pred_stride /
  * decay_factor_fp16 / block_error / mv_* / mv_dist_th / split / zz_based are read from them), normalise into d_out.  The source, the
- * geometry and chroma / bit depth come from d_static_blocks[i].  accum[] / count[] are neither read nor written: the accumulators
+ * chroma flag / bit depth come from d_static_blocks[i]; ss_x / ss_y (0 or 1) are the chroma sub-sampling of EVERY block of the call (the
+ * records' own ss_x / ss_y are not read).  accum[] / count[] are neither read nor written: the accumulators
  * stay in registers (temporal_filtering.c:3253-3301 per block: apply_filtering_central, the filter per reference, the normalisation).
  * d_out may alias the source planes (the temporal filter works in place): a block is read before it is written, by the same workgroup. */
 SVT_HIP_API int32_t svt_hip_tf_filter_blocks(const SvtHipTfBlock *const *d_ref_blocks, uint32_t n_refs, const SvtHipTfBlock *d_static_blocks,
-                                             const SvtHipTfOut *d_out, uint32_t n_blocks, void *stream);
+                                             const SvtHipTfOut *d_out, uint32_t n_blocks, uint32_t ss_x, uint32_t ss_y, void *stream);
 
 /* ---- whole-picture driver: produce_temporally_filtered_pic (temporal_filtering.c:2752-3308) -------------------------------
  * The block loop of the reference, for ONE centre picture against its window of reference pictures, device-resident:

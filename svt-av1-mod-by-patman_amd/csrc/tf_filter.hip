@@ -139,20 +139,22 @@ __global__ __launch_bounds__(256) void tf_normalise_kernel(const SvtHipTfBlock *
 struct TfRefLists {
     const SvtHipTfBlock *p[SVT_HIP_TF_MAX_REFS];
 };
+// KC: samples of a chroma plane per thread (1 for 4:2:0 — 16 x 16 = one per thread —, 4 for anything else)
+template <int KC>
 __global__ __launch_bounds__(256) void tf_filter_blocks_kernel(TfRefLists lists, uint32_t n_refs, const SvtHipTfBlock *__restrict__ statics,
-                                                               const SvtHipTfOut *__restrict__ outs) {
+                                                               const SvtHipTfOut *__restrict__ outs, uint32_t ss_x, uint32_t ss_y) {
     __shared__ SvtHipTfBlock b, sb;  // the current reference's record; the reference-independent one
-    __shared__ uint32_t      qsum[3][4], luma_err[4], weight[3][4];
+    __shared__ uint32_t      qsum[3][4], weight[3][4];
     for (uint32_t i = threadIdx.x; i < sizeof(SvtHipTfBlock) / 4; i += 256) ((uint32_t *)&sb)[i] = ((const uint32_t *)&statics[blockIdx.x])[i];
     __syncthreads();
     const int      is16 = sb.is_16bit, shift = is16 ? (sb.bit_depth - 8) * 2 : 0, npl = sb.chroma ? 3 : 1;
-    const uint32_t cw = 32u >> sb.ss_x, ch = 32u >> sb.ss_y;
+    const uint32_t cw = 32u >> ss_x, ch = 32u >> ss_y;
     uint32_t       acc[3][4], sv[3][4], cnt[3][4];
 #pragma unroll
     for (int pl = 0; pl < 3; pl++) {
         const uint32_t bw = pl ? cw : 32u, bh = pl ? ch : 32u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < (pl ? KC : 4); k++) {
             const uint32_t i = threadIdx.x + k * 256;
             acc[pl][k] = sv[pl][k] = cnt[pl][k] = 0;
             if (pl < npl && i < bw * bh) {
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void tf_filter_blocks_kernel(TfRefLists lists,
             const uint32_t bw = pl ? cw : 32u, bh = pl ? ch : 32u, hw = bw >> 1, hh = bh >> 1;
             uint32_t       part[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < (pl ? KC : 4); k++) {
                 const uint32_t i = threadIdx.x + k * 256;
                 pv[pl][k]        = 0;
                 if (pl < npl && i < bw * bh) {
@@ -197,8 +199,9 @@ __global__ __launch_bounds__(256) void tf_filter_blocks_kernel(TfRefLists lists,
             }
         }
         __syncthreads();
-        if (threadIdx.x < 4) {  // one lane per quadrant, luma first: the weights (temporal_filtering.c:1009-1099), as in tf_accumulate_kernel
-            const int      q = threadIdx.x, k = b.split ? q : 0;
+        if (threadIdx.x < 12 && (int)(threadIdx.x >> 2) < npl) {  // one lane per (plane, quadrant): the weights (temporal_filtering.c:1009-1099), as
+                                                                    // in tf_accumulate_kernel; a chroma lane derives the luma window error itself
+            const int      q = threadIdx.x & 3, pl = threadIdx.x >> 2, k = b.split ? q : 0;
             const uint32_t th0 = (uint32_t)(((int)b.mv_dist_th << 16) / 10), dist_th = th0 > (1u << 16) ? th0 : (1u << 16);
             const int32_t  col = b.mv_x[k], row = b.mv_y[k];
             const uint32_t dist = sqrt_fast(((uint32_t)(col * col + row * row)) << 8);
@@ -206,27 +209,23 @@ __global__ __launch_bounds__(256) void tf_filter_blocks_kernel(TfRefLists lists,
             d_factor                = d_factor > (1u << 8) ? d_factor : (1u << 8);
             const uint32_t blk_err = b.split ? (uint32_t)(is16 ? b.block_error[q] >> 4 : b.block_error[q])
                                              : (uint32_t)(b.block_error[0] >> (is16 ? 6 : 2));
-            for (int pl = 0; pl < npl; pl++) {
-                const uint32_t hw = (pl ? cw : 32u) >> 1, hh = (pl ? ch : 32u) >> 1;
-                if (b.zz_based) {
-                    const uint32_t den = (b.decay_factor_fp16[pl] >> 10) > 1 ? (b.decay_factor_fp16[pl] >> 10) : 1;
-                    uint32_t       sd  = (blk_err << 2) / den;
-                    sd                 = sd < 7 * 16 ? sd : 7 * 16;
-                    weight[pl][q]      = (d_exp_fp16[sd] * 1000u) >> 17;
-                } else {
-                    const uint32_t decay = b.split ? b.decay_factor_fp16[pl] : b.decay_factor_fp16[pl] << 1;
-                    uint32_t       win   = ((((qsum[pl][q] >> shift) << 4) / hw) << 4) / hh;
-                    if (pl)
-                        win = (win * 5 + luma_err[q]) / 6;
-                    else
-                        luma_err[q] = win;
-                    const uint32_t combined = (win * 5 + blk_err) / 6;
-                    const uint64_t avg_err  = (uint64_t)((combined >> 3) * (d_factor >> 3));
-                    const uint32_t den      = (decay >> 10) > 1 ? (decay >> 10) : 1;
-                    uint32_t       sd       = (uint32_t)(avg_err / den);
-                    sd                      = sd < 7 * 16 ? sd : 7 * 16;
-                    weight[pl][q]           = (d_exp_fp16[sd] * 1000u) >> 16;
-                }
+            const uint32_t hw = (pl ? cw : 32u) >> 1, hh = (pl ? ch : 32u) >> 1;
+            if (b.zz_based) {
+                const uint32_t den = (b.decay_factor_fp16[pl] >> 10) > 1 ? (b.decay_factor_fp16[pl] >> 10) : 1;
+                uint32_t       sd  = (blk_err << 2) / den;
+                sd                 = sd < 7 * 16 ? sd : 7 * 16;
+                weight[pl][q]      = (d_exp_fp16[sd] * 1000u) >> 17;
+            } else {
+                const uint32_t decay = b.split ? b.decay_factor_fp16[pl] : b.decay_factor_fp16[pl] << 1;
+                uint32_t       win   = ((((qsum[pl][q] >> shift) << 4) / hw) << 4) / hh;
+                if (pl)
+                    win = (win * 5 + ((((qsum[0][q] >> shift) << 4) / 16u) << 4) / 16u) / 6;  // the luma quadrant is 16 x 16
+                const uint32_t combined = (win * 5 + blk_err) / 6;
+                const uint64_t avg_err  = (uint64_t)((combined >> 3) * (d_factor >> 3));
+                const uint32_t den      = (decay >> 10) > 1 ? (decay >> 10) : 1;
+                uint32_t       sd       = (uint32_t)(avg_err / den);
+                sd                      = sd < 7 * 16 ? sd : 7 * 16;
+                weight[pl][q]           = (d_exp_fp16[sd] * 1000u) >> 16;
             }
         }
         __syncthreads();
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(256) void tf_filter_blocks_kernel(TfRefLists lists,
         for (int pl = 0; pl < 3; pl++) {
             const uint32_t bw = pl ? cw : 32u, bh = pl ? ch : 32u;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < (pl ? KC : 4); k++) {
                 const uint32_t i = threadIdx.x + k * 256;
                 if (pl < npl && i < bw * bh) {
                     const uint32_t r = i / bw, c = i - r * bw, w = weight[pl][(r >= bh / 2 ? 2u : 0u) + (c >= bw / 2 ? 1u : 0u)];
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(256) void tf_filter_blocks_kernel(TfRefLists lists,
     for (int pl = 0; pl < 3; pl++) {
         const uint32_t bw = pl ? cw : 32u, bh = pl ? ch : 32u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < (pl ? KC : 4); k++) {
             const uint32_t i = threadIdx.x + k * 256;
             if (pl < npl && i < bw * bh) {
                 const uint32_t r = i / bw, c = i - r * bw, n = cnt[pl][k], v = n ? (acc[pl][k] + (n >> 1)) / n : 0;
@@ -314,11 +313,11 @@ extern "C" int32_t svt_hip_tf_normalise_batch(const SvtHipTfBlock *d_blocks, con
 }
 
 extern "C" int32_t svt_hip_tf_filter_blocks(const SvtHipTfBlock *const *d_ref_blocks, uint32_t n_refs, const SvtHipTfBlock *d_static_blocks,
-                                            const SvtHipTfOut *d_out, uint32_t n_blocks, void *stream) {
+                                            const SvtHipTfOut *d_out, uint32_t n_blocks, uint32_t ss_x, uint32_t ss_y, void *stream) {
     const int32_t rc = ready(d_static_blocks, n_blocks, "svt_hip_tf_filter_blocks");
     if (rc != SVT_HIP_OK)
         return rc;
-    if (!d_out || n_refs > SVT_HIP_TF_MAX_REFS || (n_refs && !d_ref_blocks)) {
+    if (!d_out || n_refs > SVT_HIP_TF_MAX_REFS || (n_refs && !d_ref_blocks) || ss_x > 1 || ss_y > 1) {
         set_error("svt_hip_tf_filter_blocks: bad argument");
         return SVT_HIP_ERR_BAD_PARAMETER;
     }
@@ -331,7 +330,10 @@ extern "C" int32_t svt_hip_tf_filter_blocks(const SvtHipTfBlock *const *d_ref_bl
         }
         lists.p[r] = d_ref_blocks[r];
     }
-    hipLaunchKernelGGL(tf_filter_blocks_kernel, dim3(n_blocks), dim3(256), 0, resolve_stream(stream), lists, n_refs, d_static_blocks, d_out);
+    if (ss_x && ss_y)
+        hipLaunchKernelGGL(tf_filter_blocks_kernel<1>, dim3(n_blocks), dim3(256), 0, resolve_stream(stream), lists, n_refs, d_static_blocks, d_out, ss_x, ss_y);
+    else
+        hipLaunchKernelGGL(tf_filter_blocks_kernel<4>, dim3(n_blocks), dim3(256), 0, resolve_stream(stream), lists, n_refs, d_static_blocks, d_out, ss_x, ss_y);
     SVT_HIP_CHECK(hipGetLastError());
     return SVT_HIP_OK;
 }

@@ -784,7 +784,7 @@ extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void
     {  // central + the accumulation over every reference + normalise: one launch, accumulators in registers
         const SvtHipTfBlock *lists[SVT_HIP_TF_MAX_REFS];
         for (uint32_t r = 0; r < job->n_refs; r++) lists[r] = refs[r].blocks;
-        rc = svt_hip_tf_filter_blocks(lists, job->n_refs, static_blocks, outs, nb * 4, st);
+        rc = svt_hip_tf_filter_blocks(lists, job->n_refs, static_blocks, outs, nb * 4, 1, 1, st);
     }
     return rc;
 }

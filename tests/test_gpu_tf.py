@@ -131,20 +131,20 @@ def test_central_accumulate_normalise_chain(hip, orc, bd):
             assert np.array_equal(got, outs_h[3 * i + pl]), ("pixels", i, pl)
 
 
-@pytest.mark.parametrize("bd", [8, 10])
-def test_filter_blocks_one_launch(hip, orc, bd):
+@pytest.mark.parametrize("bd,ss", [(8, 1), (10, 1), (8, 0), (10, 0)])
+def test_filter_blocks_one_launch(hip, orc, bd, ss):
     """svt_hip_tf_filter_blocks — central + every reference + normalise in one launch, accumulators in registers — writes the pixels the
     three-step chain of the oracle writes (zero, one and four reference pictures)."""
     n_blk = 24
     dt = np.uint16 if bd > 8 else np.uint8
     for n_ref in (0, 1, 4):
-        base = [F.block_case(t, bd, seed=31) for t in range(n_blk)]
+        base = [F.block_case(t, bd, seed=31, ss=ss) for t in range(n_blk)]
         dev = DevBlocks(hip, base)                                              # static records: source, geometry
         for b, _ in base:
             orc.orc_tf_central(C.byref(b))
         lists, keep = [], []
         for r in range(n_ref):
-            preds = [F.block_case(t, bd, seed=40 + r) for t in range(n_blk)]
+            preds = [F.block_case(t, bd, seed=40 + r, ss=ss) for t in range(n_blk)]
             descs = []
             for i, ((b, a), (pb, pa)) in enumerate(zip(base, preds)):
                 for pl in range(3):
@@ -169,7 +169,7 @@ def test_filter_blocks_one_launch(hip, orc, bd):
         for i in range(n_blk):
             oh, od = abi.TfOut(), abi.TfOut()
             for pl in range(3):
-                n = 32 if pl == 0 else 16
+                n = 32 if pl == 0 else 32 >> ss
                 hbuf = np.zeros((n, n + 6), dt)
                 dbuf = device.DeviceBuffer(hip, hbuf.nbytes)
                 dbuf.fill(0)
@@ -180,15 +180,15 @@ def test_filter_blocks_one_launch(hip, orc, bd):
         dout = device.DeviceBuffer(hip, C.sizeof(oarr))
         dout.upload(np.frombuffer(oarr, np.uint8))
         ptrs = (V * max(n_ref, 1))(*[V(d.ptr) for d in lists])
-        device.check(hip, hip.svt_hip_tf_filter_blocks(ptrs, n_ref, V(dev.ddesc.ptr), V(dout.ptr), n_blk, None), "svt_hip_tf_filter_blocks")
+        device.check(hip, hip.svt_hip_tf_filter_blocks(ptrs, n_ref, V(dev.ddesc.ptr), V(dout.ptr), n_blk, ss, ss, None), "svt_hip_tf_filter_blocks")
         device.check(hip, hip.svt_hip_stream_sync(None), "sync")
         for i, (b, a) in enumerate(base):
             orc.orc_tf_normalise(C.byref(b), C.byref(odesc_h[i]))
             for pl in range(3 if b.chroma else 1):
                 got = outs_d[3 * i + pl].download(dt, outs_h[3 * i + pl].shape)
                 assert np.array_equal(got, outs_h[3 * i + pl]), ("pixels", n_ref, i, pl)
-    assert hip.svt_hip_tf_filter_blocks(None, 1, V(dev.ddesc.ptr), V(dout.ptr), n_blk, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
-    assert hip.svt_hip_tf_filter_blocks(ptrs, 33, V(dev.ddesc.ptr), V(dout.ptr), n_blk, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+    assert hip.svt_hip_tf_filter_blocks(None, 1, V(dev.ddesc.ptr), V(dout.ptr), n_blk, ss, ss, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+    assert hip.svt_hip_tf_filter_blocks(ptrs, 33, V(dev.ddesc.ptr), V(dout.ptr), n_blk, ss, ss, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
 
 
 def test_noise_estimate(hip, orc):

@@ -8,13 +8,12 @@ from svtav1_hip import abi
 PITCH = 64          # the reference's prediction / accumulator blocks are 64x64 (BW x BH) per b64
 
 
-def block_case(trial, bd, seed=0):
+def block_case(trial, bd, seed=0, ss=1):
     """One 32x32 block against one reference prediction: arrays + the flat parameter block (host pointers)."""
     rng = np.random.default_rng(9100 + trial * 7 + bd + seed)
     is16 = bd > 8
     dt = np.uint16 if is16 else np.uint8
     hi = (1 << bd) - 1
-    ss = 1
     arrs = {}
     strides_src = [96, 52, 52]
     noise = (1, 3, 8, 20, 60)[trial % 5] * (1 << (bd - 8))
