@@ -711,7 +711,7 @@ def pmc_groups():
     g.update({"dlf": (["dlf_pass_kernel"], 1), "cdef_search": (["cdef_search_kernel"], 1), "cdef_apply": (["cdef_apply_frame_kernel", "cdef_apply_kernel"], 1),
               "sgr_filter": (["sgr_filter_kernel<0>"], 1), "sgr_apply": (["sgr_filter_kernel<1>"], 1),
               "wiener_stats": (["wiener_stats_kernel", "wiener_finalize_kernel"], 1), "wiener_convolve": (["wiener_convolve_kernel"], 1),
-              "tf": (["me_b64_kernel<true>", "tf_refine_kernel", "tf_blocks_kernel", "tf_predict", "tf_accumulate_kernel", "tf_central_kernel", "tf_normalise_kernel"], 1),
+              "tf": (["me_b64_kernel<true>", "tf_refine_kernel", "tf_blocks_kernel", "tf_predict", "tf_filter_blocks_kernel", "tf_accumulate_kernel", "tf_central_kernel", "tf_normalise_kernel"], 1),
               "tpl4": (["tpl_kernel<0>"], 1), "tpl5": (["tpl_kernel<1>"], 1)})
     return g
 
