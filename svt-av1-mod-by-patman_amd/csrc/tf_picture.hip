@@ -5,13 +5,11 @@
 // sharp-filter predictions (tf_64x64 / tf_32x32_inter_prediction :2226-2576, run by inter_convolve.hip),
 // convert_64x64_info_to_32x32_info (:2661-2728) and the SvtHipTfBlock records the accumulate stage (tf_filter.hip) consumes.
 //
-// tf_refine_kernel: one workgroup per (reference picture, 64x64 block).  The source block lives in LDS for the whole search;
-// each square sub-block search stages ONE reference window (block + 10 samples each side: the 7/8-sample drift of the three
-// refinement rounds, the 8-tap margin and the doubled row step of the sub-sampled centre position) and evaluates every
-// candidate position from it: horizontal pass -> int16 intermediate in LDS -> vertical pass -> difference to the source ->
-// sum / sum of squares by wave shuffles.  The search itself is sequential in the reference (a position is skipped when the best
-// distortion so far is zero or below the early-exit threshold); every lane carries the same best distortion / vector, so the
-// control flow stays uniform and the skip rules are applied exactly as written.
+// tf_refine_kernel: one workgroup per (reference picture, 64x64 block).  The source block lives in LDS for the whole search; each
+// stage (the 64x64 block, the four 32x32, the four 16x16 of a 32x32) stages one reference window per block (block + 10 samples each
+// side: the 7/8-sample drift of the three refinement rounds, the 8-tap margin and the doubled row step of the sub-sampled centre
+// position) and evaluates the candidates of a refinement round of all its blocks side by side, each by the lanes of one wave —
+// see "the sub-pel searches" below.
 #include <cstdio>
 #include <cstring>
 
