@@ -43,8 +43,11 @@ bool ensure_init() {
 // creating a HIP stream costs milliseconds (a hardware queue) -- 25 ms per first call of a thread inside the patched encoder.  Threads
 // draw from a small pool instead: thread k uses stream k mod POOL.  Two threads that share a stream only wait for each other's work in
 // svt_hip_stream_sync; order inside one thread is kept, which is all the API promises.
+#ifndef SVT_HIP_STREAM_POOL
+#define SVT_HIP_STREAM_POOL 8
+#endif
 namespace {
-constexpr int     STREAM_POOL = 8;
+constexpr int     STREAM_POOL = SVT_HIP_STREAM_POOL;
 hipStream_t       g_pool_streams[STREAM_POOL];
 std::mutex        g_pool_mutex;
 std::atomic<int>  g_next_thread{0};
@@ -283,7 +286,15 @@ int32_t svt_hip_init(int32_t device_ordinal) {
     const bool first = g_sticky.load() < 0;
     g_device.store(device_ordinal);
     g_sticky.store(device_ordinal);
-    if (first) {  // load every translation unit's code object now instead of inside the first calls of the host's worker threads
+    if (first) {  // load every translation unit's code object now instead of inside the first calls of the host's worker threads,
+                  // and create the stream pool here: a worker thread's first call created its slot's stream under the pool lock, and the
+                  // six picture-analysis threads of the encoder, all starting at once, paid 16 ms each for it
+        {
+            std::lock_guard<std::mutex> pk(g_pool_mutex);
+            for (int i = 0; i < STREAM_POOL; i++)
+                if (!g_pool_streams[i] && hipStreamCreateWithFlags(&g_pool_streams[i], hipStreamNonBlocking) != hipSuccess)
+                    g_pool_streams[i] = nullptr;  // created on demand by resolve_stream
+        }
         run_module_warmups(nullptr);
         SVT_HIP_CHECK(hipDeviceSynchronize());
     }

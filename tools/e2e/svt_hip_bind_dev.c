@@ -31,7 +31,7 @@ uint64_t hd_now_ns(void) {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
-void hd_timer_add(const char *name, uint64_t ns) {
+void hd_timer_add(const char *name, uint64_t ns) { /* takes g_mu: never call it with g_mu held */
     pthread_mutex_lock(&g_mu);
     for (int i = 0; i < 24; i++) {
         if (!g_timers[i].name)
@@ -81,9 +81,24 @@ void svt_hip_bind_dev_setup(void *(*sym)(const char *)) {
 
 void hd_count_picture(void) { __atomic_add_fetch(&g_pictures, 1, __ATOMIC_RELAXED); }
 
+/* The encoder's buffers are pageable memory: hipMemcpyAsync from them ran at 0.5 GB/s here (2.4 MB of a 1080p luma plane: 4.7 ms, most
+ * of the picture-analysis hook).  Through a pinned staging block from the pool (a memcpy at memory speed + a DMA) the same upload takes
+ * 0.3 ms.  The staged copy is complete on return (the block goes back to the pool). */
+#define HD_STAGE_MIN ((size_t)16 << 10)
 int hd_upload(void *d, const void *h, size_t n) {
     __atomic_add_fetch(&g_up_bytes, n, __ATOMIC_RELAXED);
-    return g_hd.upload(d, h, n, NULL);
+    static int no_staging = -1;
+    if (no_staging < 0)
+        no_staging = hd_env_on("SVTAV1_HIP_NO_STAGING");
+    if (n < HD_STAGE_MIN || no_staging)
+        return g_hd.upload(d, h, n, NULL);
+    void *st = hd_host_alloc(n);
+    if (!st)
+        return g_hd.upload(d, h, n, NULL);
+    memcpy(st, h, n);
+    const int rc = g_hd.upload(d, st, n, NULL) | g_hd.sync(NULL);
+    hd_host_free(st);
+    return rc;
 }
 int hd_download(void *h, const void *d, size_t n) {
     __atomic_add_fetch(&g_down_bytes, n, __ATOMIC_RELAXED);

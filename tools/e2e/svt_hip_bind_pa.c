@@ -72,14 +72,19 @@ static int pa_pyramid_impl(PictureParentControlSet *pcs, EbPictureBufferDesc *fu
     const int      level1 = pcs->enable_hme_level1_flag || pcs->tf_enable_hme_level1_flag;
     const uint64_t tag    = HD_TAG(pcs->picture_number, HD_ST_FILTERED);
     const size_t   nq = plane_bytes(quarter), ns = plane_bytes(sixteenth);
+    const uint64_t t_a = hd_now_ns();
     uint8_t       *d_f = hd_mirror_get(full->buffer_y, plane_bytes(full), tag);
     if (!d_f)
         return 1;
+    hd_timer_add("pa_pyramid.1_source_mirror", hd_now_ns() - t_a);
+    const uint64_t t_b = hd_now_ns();
     /* the decimated planes are produced on the device: their buffers become the mirrors of the host planes */
     uint8_t *d_q = level1 ? hd_mirror_new(quarter->buffer_y, nq, tag) : hd_alloc(nq + 256);
     uint8_t *d_s = hd_mirror_new(sixteenth->buffer_y, ns, tag);
     uint8_t *h_q = level1 ? (uint8_t *)hd_host_alloc(nq) : NULL, *h_s = (uint8_t *)hd_host_alloc(ns);
     int      rc  = (d_q && d_s && h_s && (h_q || !level1)) ? 0 : -1;
+    hd_timer_add("pa_pyramid.2_alloc", hd_now_ns() - t_b);
+    const uint64_t t_c = hd_now_ns();
     if (rc == 0) {
         SvtHipPlane8 pf, pq, ps;
         plane_of(&pf, full, d_f), plane_of(&pq, quarter, d_q), plane_of(&ps, sixteenth, d_s);
@@ -91,11 +96,14 @@ static int pa_pyramid_impl(PictureParentControlSet *pcs, EbPictureBufferDesc *fu
             rc = (level1 ? hd_download(h_q, d_q, nq) : 0) | hd_download(h_s, d_s, ns);
     }
     rc |= hd_sync();
+    hd_timer_add("pa_pyramid.3_upload_kernel_download", hd_now_ns() - t_c);
+    const uint64_t t_d = hd_now_ns();
     if (rc == 0) {
         if (level1)
             memcpy(quarter->buffer_y, h_q, nq);
         memcpy(sixteenth->buffer_y, h_s, ns);
     }
+    hd_timer_add("pa_pyramid.4_copy_out", hd_now_ns() - t_d);
     hd_mirror_unpin(full->buffer_y);
     if (level1 && d_q) {
         if (rc != 0)
