@@ -95,7 +95,12 @@ typedef struct SvtHipTfCtrls {      /* the TfControls fields (definitions.h:120-
     uint8_t  use_pred_64x64_only_th; /* 0 off, 255 always 64x64, else tf_use_64x64_pred's deviation threshold */
     uint8_t  subpel_early_exit_th;
     uint8_t  use_8bit_subpel;        /* bit depth > 8: the sub-pel searches run on the 8-bit planes */
-    uint8_t  use_zz_based_filter, enable_8x8_pred, pad_[6];
+    uint8_t  use_zz_based_filter, enable_8x8_pred;
+    uint8_t  low_delay;              /* 1: produce_temporally_filtered_pic_ld (temporal_filtering.c:3310-3660, pred_structure LOW_DELAY_B): no
+                                      * motion search — every 64x64 block is predicted from the co-located block (vector 0) and filtered as
+                                      * four un-split 32x32 blocks whose error is their variance against the source; the ME parameters, the
+                                      * sub-pel controls and tot_blks are not used */
+    uint8_t  pad_[5];
     uint64_t pred_error_32x32_th;
 } SvtHipTfCtrls;
 

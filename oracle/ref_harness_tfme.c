@@ -127,7 +127,9 @@ __attribute__((visibility("default"))) int ref_tf_picture(const SvtHipTfPictureJ
     memset(&mectx, 0, sizeof(mectx));
     mectx.me_ctx = me;
 
-    const EbErrorType rc = produce_temporally_filtered_pic(list, pics, 0, &mectx, noise_log1p_fp16, 0, job->bit_depth > 8);
+    /* svt_av1_init_temporal_filtering picks the variant by the prediction structure (temporal_filtering.c:4046-4062) */
+    const EbErrorType rc = job->ctrls.low_delay ? produce_temporally_filtered_pic_ld(list, pics, 0, &mectx, noise_log1p_fp16, 0, job->bit_depth > 8)
+                                                : produce_temporally_filtered_pic(list, pics, 0, &mectx, noise_log1p_fp16, 0, job->bit_depth > 8);
     for (int p = 0; p < 3; p++) decay_out[p] = me->tf_decay_factor_fp16[p];
     tot[0] = me->tf_tot_horz_blks, tot[1] = me->tf_tot_vert_blks;
     free(centre->stationary_block_present_sb), free(centre->rc_me_allow_gm), free(centre->b64_geom);

@@ -181,6 +181,12 @@ static void refine_b64(const SvtHipTfPictureJob *job, const SvtHipTfPic *ref, in
     s.src_stride = (int32_t)cf->stride, s.ref_stride = (int32_t)rf->stride;
     s.is16 = s16, s.bd = s16 ? job->bit_depth : 8, s.ox = ox, s.oy = oy, s.tmp = tmp;
     memset(st, 0, sizeof(*st));
+    int use64 = 0;
+    if (c->low_delay) { /* produce_temporally_filtered_pic_ld (temporal_filtering.c:3533-3620): tf_64x64_mv = 0, tf_64x64_inter_prediction,
+                         * the four 32x32 variances, no split */
+        st->use_64x64 = 1, use64 = 1;
+        goto low_delay;
+    }
     /* svt_aom_motion_estimation_b64 leaves after HME when the HME distortion is below tf_me_exit_th (motion_estimation.c:3179) */
     const int use64_th = (sr->hme_sad < job->me.tf_me_exit_th) ? 255 : c->use_pred_64x64_only_th;
     const int k6432 = c->use_2tap ? K_BILINEAR : K_REGULAR;
@@ -189,7 +195,6 @@ static void refine_b64(const SvtHipTfPictureJob *job, const SvtHipTfPic *ref, in
     st->mv64_x = (int16_t)((use64_th == 255 ? sr->hme_sc_x : mv_x_of(best_mv[0])) << 3);
     st->mv64_y = (int16_t)((use64_th == 255 ? sr->hme_sc_y : mv_y_of(best_mv[0])) << 3);
     subpel_search(&s, 64, 0, 0, k6432, &st->err64, &st->mv64_x, &st->mv64_y);
-    int use64 = 0;
     if (use64_th) {
         if (use64_th == 255)
             use64 = 1;
@@ -212,6 +217,7 @@ static void refine_b64(const SvtHipTfPictureJob *job, const SvtHipTfPic *ref, in
             use64 = 1;
     }
     st->use_64x64 = (uint8_t)use64;
+low_delay:
     if (use64) {
         final_prediction(job, &s.g, ref, pred, ox, oy, 0, 0, 64, st->mv64_x, st->mv64_y);
         /* convert_64x64_info_to_32x32_info: measured on the pictures the FILTER works on */
@@ -305,13 +311,13 @@ ORC_API int32_t orc_tf_filter_picture(const SvtHipTfPictureJob *job, SvtHipTfB64
         mj->prm.picture_number = job->centre.picture_number, mj->prm.ref_picture_number[0][0] = job->ref[r].picture_number;
         mj->src = job->centre.pyr, mj->ref[0][0] = job->ref[r].pyr;
         mj->out.best_sad = best_sad, mj->out.best_mv = best_mv, mj->out.search_results = sr;
-        int32_t rc = orc_me_frame_range(mj, 0, nb);
+        int32_t rc = job->ctrls.low_delay ? 0 : orc_me_frame_range(mj, 0, nb); /* the low-delay variant has no motion search */
         if (rc)
             return rc;
         for (uint32_t b = 0; b < nb; b++) {
             const int ox = (int)(b % bw) * 64, oy = (int)(b / bw) * 64;
             const SvtHipMeSearchResult *s0 = sr + (size_t)b * 8;
-            if (tot)
+            if (tot && !job->ctrls.low_delay)
                 tot[abs(s0->hme_sc_x) > abs(s0->hme_sc_y) ? 0 : 1]++;
             SvtHipTfB64State st;
             refine_b64(job, &job->ref[r], ox, oy, best_mv + (size_t)b * 8 * 85, best_sad + (size_t)b * 8 * 85, s0, predp, tmp, &st);

@@ -549,6 +549,34 @@ __global__ __launch_bounds__(64) void tf_predict_small_kernel(const RefineRef *_
     }
 }
 
+// produce_temporally_filtered_pic_ld (temporal_filtering.c:3533-3560): no motion search — tf_64x64_mv = 0 and tf_64x64_inter_prediction
+// of the co-located block, which at a zero vector is a copy of the reference picture's samples (luma 64x64, chroma 32x32 each, the depth
+// the filter works on).  Writes the prediction and the state record (use_64x64 = 1, vector 0); tf_blocks_kernel then measures the four
+// 32x32 variances exactly as for a searched 64x64 block.
+__global__ __launch_bounds__(256) void tf_low_delay_kernel(RefineArgs a, const RefineRef *__restrict__ refs) {
+    const RefineRef &R = refs[blockIdx.y];
+    const uint32_t   b = blockIdx.x;
+    const int        tid = threadIdx.x, ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64, is16 = a.bit_depth > 8;
+    for (int i = tid; i < (int)(sizeof(SvtHipTfB64State) / 4); i += 256) ((uint32_t *)&R.state[b])[i] = 0;
+    __syncthreads();
+    if (tid == 0)
+        R.state[b].use_64x64 = 1;
+    for (int p = 0; p < (a.chroma ? 3 : 1); p++) {
+        const int       ss = p ? 1 : 0, n = 64 >> ss;
+        const uint32_t  stride = p ? R.pic.stride_c : R.pic.stride;
+        const void     *src = is16 ? (const void *)(p ? R.pic.c16[p - 1] : R.pic.y16) : (const void *)(p ? R.pic.c8[p - 1] : R.pic.y8);
+        uint8_t        *dst = R.pred + ((((size_t)b * 3 + p) * 4096) << is16);
+        for (int i = tid; i < n * n; i += 256) {
+            const int      r = i / n, c = i - r * n;
+            const uint32_t v = is16 ? ldg<true>(src, (ptrdiff_t)((oy >> ss) + r) * stride + (ox >> ss) + c) : ldg<false>(src, (ptrdiff_t)((oy >> ss) + r) * stride + (ox >> ss) + c);
+            if (is16)
+                ((uint16_t *)dst)[r * n + c] = (uint16_t)v;
+            else
+                dst[r * n + c] = (uint8_t)v;
+        }
+    }
+}
+
 // after the predictions: convert_64x64_info_to_32x32_info for the blocks predicted as one 64x64, and the four SvtHipTfBlock
 // records of every block.  blockIdx.y == n_refs writes the reference-independent records used by the central / normalise
 // launches (and their SvtHipTfOut).
@@ -750,7 +778,8 @@ extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void
         refs[r].desc = (SvtHipConvolveDesc *)(ws + l.desc + l.per_ref_desc * r);
         refs[r].blocks = (SvtHipTfBlock *)(ws + l.blocks + l.per_ref_blocks * r);
     }
-    int32_t rc = svt_hip_me_frames(mj, job->n_refs, st);
+    const bool low_delay = job->ctrls.low_delay != 0;
+    int32_t    rc = low_delay ? (int32_t)SVT_HIP_OK : svt_hip_me_frames(mj, job->n_refs, st);  // the low-delay variant has no motion search
     delete[] mj;
     if (rc != SVT_HIP_OK)
         return rc;
@@ -768,13 +797,17 @@ extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void
     SvtHipTfBlock *static_blocks = (SvtHipTfBlock *)(ws + l.static_blocks);
     SvtHipTfOut   *outs = (SvtHipTfOut *)(ws + l.outs);
     const bool     s16 = is16 && !job->ctrls.use_8bit_subpel;
-    if (s16)
-        hipLaunchKernelGGL(tf_refine_kernel<true>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
-    else
-        hipLaunchKernelGGL(tf_refine_kernel<false>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
-    SVT_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(tf_predict_kernel, dim3(nb, job->n_refs), dim3(256), 0, st, d_refs);
-    hipLaunchKernelGGL(tf_predict_small_kernel, dim3(nb * SMALL_SPLIT, job->n_refs), dim3(64), 0, st, d_refs);
+    if (low_delay) {
+        hipLaunchKernelGGL(tf_low_delay_kernel, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs);
+    } else {
+        if (s16)
+            hipLaunchKernelGGL(tf_refine_kernel<true>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
+        else
+            hipLaunchKernelGGL(tf_refine_kernel<false>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
+        SVT_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(tf_predict_kernel, dim3(nb, job->n_refs), dim3(256), 0, st, d_refs);
+        hipLaunchKernelGGL(tf_predict_small_kernel, dim3(nb * SMALL_SPLIT, job->n_refs), dim3(64), 0, st, d_refs);
+    }
     SVT_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(tf_blocks_kernel, dim3(nb, job->n_refs + 1), dim3(256), 0, st, a, d_refs, job->n_refs, static_blocks, outs);
     SVT_HIP_CHECK(hipGetLastError());

@@ -289,7 +289,8 @@ TF_MAX_REFS = 32
 class TfCtrls(C.Structure):              # SvtHipTfCtrls
     _fields_ = [("half_pel_mode", C.c_uint8), ("quarter_pel_mode", C.c_uint8), ("eight_pel_mode", C.c_uint8), ("use_2tap", C.c_uint8),
                 ("sub_sampling_shift", C.c_uint8), ("use_pred_64x64_only_th", C.c_uint8), ("subpel_early_exit_th", C.c_uint8),
-                ("use_8bit_subpel", C.c_uint8), ("use_zz_based_filter", C.c_uint8), ("enable_8x8_pred", C.c_uint8), ("pad_", C.c_uint8 * 6),
+                ("use_8bit_subpel", C.c_uint8), ("use_zz_based_filter", C.c_uint8), ("enable_8x8_pred", C.c_uint8), ("low_delay", C.c_uint8),
+                ("pad_", C.c_uint8 * 5),
                 ("pred_error_32x32_th", C.c_uint64)]
 
 

@@ -38,7 +38,13 @@ LF_CASES = {
     "p6_10bit_lf": (256, 192, 7, 10, 6),   # BASELINE.json configs[3]'s preset
     "p3_8bit_lf": (192, 128, 3, 8, 3),
 }
-ALL_CASES = dict(CASES, **TIER_B_CASES, **LF_CASES)
+# low-delay prediction structure (`--pred-struct 1`): the temporal filter runs produce_temporally_filtered_pic_ld
+LD_CASES = {
+    "p8_8bit_ld": (1280, 720, 7, 8, 8),    # the low-delay temporal filter needs >= 720p (derive_tf_params, enc_handle.c:3307-3314)
+    "p8_10bit_ld": (1280, 720, 6, 10, 8),
+}
+EXTRA_ARGS = {"p8_8bit_ld": ["--pred-struct", "1"], "p8_10bit_ld": ["--pred-struct", "1"]}
+ALL_CASES = dict(CASES, **TIER_B_CASES, **LF_CASES, **LD_CASES)
 
 
 def have_app():
@@ -73,7 +79,7 @@ def encode(case, workdir, asm, lp=1, env_extra=None, timeout=900):
         if os.path.exists(p):
             os.remove(p)
     cmd = [APP, "-i", clip, "-w", str(w), "-h", str(h), "--fps", "30", "-n", str(n), "--preset", str(preset),
-           "--lp", str(lp), "--asm", asm, "--input-depth", str(bd), "-b", ivf, "-o", rec]
+           "--lp", str(lp), "--asm", asm, "--input-depth", str(bd), "-b", ivf, "-o", rec] + EXTRA_ARGS.get(case, [])
     # SVTAV1_HIP_MIRROR_VERIFY: every hit of the glue's device-resident picture mirrors is compared with the host buffer
     env = dict(os.environ, SVTAV1_HIP_LIB=HIP_LIB, SVTAV1_HIP_MIRROR_VERIFY="1")
     env.update(env_extra or {})

@@ -93,6 +93,23 @@ def test_batched_tf_bitstream_md5(hip, case, lp):
 
 @needs_app
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,lp", [("p8_8bit_ld", 4), ("p8_10bit_ld", 4)])
+def test_batched_tf_low_delay_bitstream_md5(hip, case, lp):
+    """GPU: the low-delay prediction structure (`--pred-struct 1`) runs produce_temporally_filtered_pic_ld — co-located predictions, no
+    motion search — which the patch hands to svt_hip_tf_filter_picture with ctrls.low_delay = 1 (tools/e2e/svt_hip_bind_tf.c); every
+    other batched open-loop stage on as well.  Same bitstream."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_PA": "1",
+                                                               "SVTAV1_HIP_TIERB_TPL": "1", "SVTAV1_HIP_ONLY": "__none__"})
+    E.assert_hip_ran_clean(log)
+    m = re.search(r"svt_hip_bind_tf: (\d+) pictures through svt_hip_tf_filter_picture \((\d+) of them the low-delay variant\)", log)
+    assert m and int(m.group(2)) >= 1, "the low-delay temporal filter did not run on the GPU:\n" + log[-2000:]
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched low-delay temporal filter\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,lp", [("p8_8bit", 1), ("p8_8bit", 4), ("p8_10bit", 2), ("p12_8bit", 2)])
 def test_batched_tpl_bitstream_md5(hip, case, lp):
     """GPU, Tier B inside the real encoder: with SVTAV1_HIP_TIERB_TPL=1 svt_aom_tpl_disp_kernel hands every
@@ -136,6 +153,18 @@ def test_batched_paths_ragged_clip(hip, case, lp):
     assert "stays on the CPU" not in log and "falls back" not in log
     g = E.golden()[case]
     assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.parametrize("case", list(E.LD_CASES))
+def test_c_path_reproduces_golden_low_delay(case):
+    """CPU: the low-delay goldens (`--pred-struct 1`, 720p: the smallest size at which the reference filters in that mode), and the
+    clips do reach produce_temporally_filtered_pic_ld."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "c", lp=4, env_extra={"SVTAV1_E2E_TRACE_TF_LD": "1"})
+    assert "produce_temporally_filtered_pic_ld reached" in log
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}
 
 
 @needs_app

@@ -30,6 +30,10 @@ CASES = [
     ("subpel16_lvl1_10bit", "subpel16", 128, 128, 1, 10, "m6_360p_tl0", LVL1),
     ("static_lvl8_10bit", "static", 128, 64, 2, 10, "m8_360p_tl0", dict(LVL8, chroma=1)),
     ("fastpan_lvl8b_10bit", "fastpan", 144, 80, 2, 10, "m8_360p_tl0", dict(LVL8, use_pred_64x64_only_th=0, me_exit_th=0, use_8bit_subpel=0, chroma=1)),
+    # produce_temporally_filtered_pic_ld (pred_structure LOW_DELAY_B): co-located prediction, no search
+    ("pan_ld_8bit", "pan", 192, 128, 2, 8, "m8_360p_tl0", dict(LVL6, low_delay=1)),
+    ("static_ld_sub_10bit", "static", 144, 80, 3, 10, "m8_360p_tl0", dict(LVL8, low_delay=1, chroma=1)),
+    ("blocks_ld_10bit", "blocks", 128, 128, 1, 10, "m6_360p_tl0", dict(LVL1, low_delay=1)),
 ]
 NOISE_LOG1P_FP16 = (3 << 16) // 4, (1 << 16) // 2, (1 << 16) // 2
 QP = 35
@@ -137,7 +141,7 @@ def make_job(pics, w, h, bd, key, ctl, decay=(0, 0, 0), ptrs=None):
     for k in ("half_pel_mode", "quarter_pel_mode", "eight_pel_mode", "use_2tap", "sub_sampling_shift", "use_pred_64x64_only_th",
               "subpel_early_exit_th", "use_8bit_subpel", "pred_error_32x32_th"):
         setattr(job.ctrls, k, ctl[k])
-    job.ctrls.use_zz_based_filter = ctl.get("use_zz_based_filter", 0)
+    job.ctrls.use_zz_based_filter, job.ctrls.low_delay = ctl.get("use_zz_based_filter", 0), ctl.get("low_delay", 0)
     for i in range(3):
         job.decay_factor_fp16[i] = decay[i]
     job.mv_dist_th = min(450, max(64, min(h, w) - 150))

@@ -57,12 +57,14 @@ def patch_me_process(t):
 
 
 def patch_temporal_filtering(t):
-    """Step 6b: the whole-picture temporal filter in front of the block loop of produce_temporally_filtered_pic (the first of the
-    two identical loop heads: the second belongs to the low-delay variant)."""
+    """Step 6b: the whole-picture temporal filter in front of the block loops of produce_temporally_filtered_pic and of its low-delay
+    variant (two identical loop heads, in this order)."""
     t = edit(t, '#include "temporal_filtering.h"\n', '#include "temporal_filtering.h"\n#include "svt_hip_bind.h"\n')
     old = "    for (uint32_t blk_row = y_b64_start_idx; blk_row < y_b64_end_idx; blk_row++) {\n"
     assert t.count(old) == 2
     i = t.index(old)
+    j = t.index(old, i + 1)  # produce_temporally_filtered_pic_ld: its decay factors are computed above the loop as well
+    t = t[:j] + "    if (svt_hip_bind_tf_picture_ld(pcs_list, list_input_picture_ptr, index_center, ctx, is_highbd))\n" + t[j:]
     return t[:i] + "    if (svt_hip_bind_tf_picture(pcs_list, list_input_picture_ptr, index_center, ctx, is_highbd))\n" + t[i:]
 
 

@@ -30,9 +30,12 @@ int  svt_hip_bind_me_b64(struct PictureParentControlSet *pcs, uint32_t b64_index
                          struct EbPictureBufferDesc *quarter, struct EbPictureBufferDesc *sixteenth);
 void svt_hip_bind_me_setup(void *(*sym)(const char *));
 
-/* Step 6b (svt_hip_bind_tf.c): the block loop of produce_temporally_filtered_pic through svt_hip_tf_filter_picture.  Returns 0
- * when the picture has been filtered on the GPU (the caller skips its loop), 1 when the caller must run its own loop. */
+/* Step 6b (svt_hip_bind_tf.c): the block loop of produce_temporally_filtered_pic — _ld: of produce_temporally_filtered_pic_ld — through
+ * svt_hip_tf_filter_picture.  Returns 0 when the picture has been filtered on the GPU (the caller skips its loop), 1 when the caller must
+ * run its own loop. */
 int  svt_hip_bind_tf_picture(struct PictureParentControlSet **pcs_list, struct EbPictureBufferDesc **pics, int index_center,
+                             struct MeContext *ctx, int is_highbd);
+int  svt_hip_bind_tf_picture_ld(struct PictureParentControlSet **pcs_list, struct EbPictureBufferDesc **pics, int index_center,
                              struct MeContext *ctx, int is_highbd);
 void svt_hip_bind_tf_setup(void *(*sym)(const char *));
 

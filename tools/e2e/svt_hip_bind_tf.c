@@ -30,11 +30,14 @@
 static int32_t (*p_tf_picture)(const SvtHipTfPictureJob *, void *);
 static uint64_t (*p_tf_ws_bytes)(uint32_t, uint32_t, uint32_t);
 static int           g_active;
-static unsigned long g_pictures;
+static unsigned long g_pictures, g_pictures_ld;
+static __thread int  t_low_delay; /* the variant the calling thread is in (svt_hip_bind_tf_picture_ld) */
 
 void svt_hip_bind_me_params(SvtHipMeParams *out, const PictureParentControlSet *pcs, const MeContext *me); /* svt_hip_bind_me.c */
 
-static void report(void) { fprintf(stderr, "svt_hip_bind_tf: %lu pictures through svt_hip_tf_filter_picture\n", g_pictures); }
+static void report(void) {
+    fprintf(stderr, "svt_hip_bind_tf: %lu pictures through svt_hip_tf_filter_picture (%lu of them the low-delay variant)\n", g_pictures, g_pictures_ld);
+}
 
 void svt_hip_bind_tf_setup(void *(*sym)(const char *)) {
     p_tf_picture  = (int32_t(*)(const SvtHipTfPictureJob *, void *))sym("svt_hip_tf_filter_picture");
@@ -174,6 +177,7 @@ static int run_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc *
     job->ctrls.use_pred_64x64_only_th = tc->use_pred_64x64_only_th, job->ctrls.subpel_early_exit_th = tc->subpel_early_exit_th;
     job->ctrls.use_8bit_subpel = tc->use_8bit_subpel, job->ctrls.use_zz_based_filter = tc->use_zz_based_filter;
     job->ctrls.pred_error_32x32_th = tc->pred_error_32x32_th;
+    job->ctrls.low_delay           = (uint8_t)t_low_delay;
     for (int p = 0; p < 3; p++) job->decay_factor_fp16[p] = ctx->tf_decay_factor_fp16[p];
     job->mv_dist_th = ctx->tf_mv_dist_th, job->chroma = ctx->tf_chroma, job->bit_depth = is_highbd ? 10 : 8;
     job->mi_rows = (uint32_t)centre->av1_cm->mi_rows, job->mi_cols = (uint32_t)centre->av1_cm->mi_cols, job->n_refs = (uint32_t)n;
@@ -256,7 +260,24 @@ static int run_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc *
 }
 
 /* Returns 0 when the picture has been filtered on the GPU (the caller skips its block loop), 1 when the caller must run it. */
+static int tf_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc **pics, int index_center, MeContext *ctx, int is_highbd);
 int svt_hip_bind_tf_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc **pics, int index_center, MeContext *ctx, int is_highbd) {
+    t_low_delay = 0;
+    return tf_picture(pcs_list, pics, index_center, ctx, is_highbd);
+}
+/* the same in front of the block loop of produce_temporally_filtered_pic_ld (pred_structure LOW_DELAY_B): co-located predictions, no search */
+int svt_hip_bind_tf_picture_ld(PictureParentControlSet **pcs_list, EbPictureBufferDesc **pics, int index_center, MeContext *ctx, int is_highbd) {
+    static int traced = -1; /* SVTAV1_E2E_TRACE_TF_LD=1: says once that the encoder reached this variant (tests, also without a GPU) */
+    if (traced < 0)
+        traced = getenv("SVTAV1_E2E_TRACE_TF_LD") != NULL;
+    if (traced == 1 && __atomic_exchange_n(&traced, 2, __ATOMIC_RELAXED) == 1)
+        fprintf(stderr, "svt_hip_bind_tf: produce_temporally_filtered_pic_ld reached (picture %llu)\n", (unsigned long long)pcs_list[index_center]->picture_number);
+    t_low_delay = 1;
+    const int rc = tf_picture(pcs_list, pics, index_center, ctx, is_highbd);
+    t_low_delay  = 0;
+    return rc;
+}
+static int tf_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc **pics, int index_center, MeContext *ctx, int is_highbd) {
     PictureParentControlSet *centre = pcs_list[index_center];
     if (!g_active) {
         if (g_hd.ok)
@@ -280,6 +301,8 @@ int svt_hip_bind_tf_picture(PictureParentControlSet **pcs_list, EbPictureBufferD
             /* tf_tot_*_blks of the whole picture go to this segment's context (the caller adds every segment's into the pcs) */
             ctx->tf_tot_horz_blks += tot[0], ctx->tf_tot_vert_blks += tot[1];
             __atomic_add_fetch(&g_pictures, 1, __ATOMIC_RELAXED);
+            if (t_low_delay)
+                __atomic_add_fetch(&g_pictures_ld, 1, __ATOMIC_RELAXED);
         }
         hd_once_done(once, rc == 0, NULL);
     }
