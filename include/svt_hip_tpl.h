@@ -96,7 +96,13 @@ typedef struct SvtHipTplFrameJob {
                                   * agent-scope acquire = buffer_inv sc1); it is not a release / acquire pair of the C++ model. */
     /* quants_8bit / deq_8bit of the picture's qindex: [0] DC, [1] AC */
     int16_t  round_fp[2], quant_fp[2], dequant[2];
-    uint16_t pad2_;
+    uint8_t  quarter_pel; /* tpl_ctrls.subpel_depth == QUARTER_PEL (tpl level 3 = presets M5 / M6; 16x16 blocks only): every candidate
+                           * vector is refined by tpl_subpel_search (src_ops_process.c:418-517: svt_av1_find_best_sub_pixel_tree_pruned
+                           * with two rounds — half, quarter — of the four cardinal neighbours, bilinear sub-pixel variance, no vector
+                           * cost, no diagonal), and a fractional vector is compensated with the regular 8-tap kernels for the SAD,
+                           * the source-based residual and the reconstruction.  mi_rows / mi_cols of Av1Common are taken as the
+                           * picture size rounded up to 8, in 4x4 units */
+    uint8_t  pad2_;
     SvtHipTplStats    *stats;     /* [rows][stride]: stride = (aligned_width + 15) / 16 for synth_blk_size 16, twice that for 8, (aligned_width + 31) / 32 for 32 */
     SvtHipTplSrcStats *src_stats; /* [..][(aligned_width + 15) >> 4] */
     void              *workspace; /* device scratch of svt_hip_tpl_workspace_bytes(): the done-flags of the blocks, one status word

@@ -13,6 +13,9 @@
 void ref_init(void);
 void svt_aom_init_intra_dc_predictors_c_internal(void);
 void svt_aom_init_intra_predictors_internal(void);
+void svt_aom_asm_set_convolve_asm_table(void);
+void svt_aom_asm_set_convolve_hbd_asm_table(void);
+void init_fn_ptr(void);
 
 static void plane_desc(EbPictureBufferDesc *d, const uint8_t *sample0, uint32_t stride, uint16_t org_x, uint16_t org_y, uint16_t w, uint16_t h) {
     memset(d, 0, sizeof(*d));
@@ -37,6 +40,9 @@ __attribute__((visibility("default"))) int ref_tpl_dispenser_frame(const SvtHipT
     if (!tables_done) { /* one-time table set-up of svt_av1_enc_init (enc_handle.c:1478-1491) */
         svt_aom_init_intra_dc_predictors_c_internal();
         svt_aom_init_intra_predictors_internal();
+        svt_aom_asm_set_convolve_asm_table(); /* tpl level 3: svt_aom_enc_make_inter_predictor, svt_aom_mefn_ptr */
+        svt_aom_asm_set_convolve_hbd_asm_table();
+        init_fn_ptr();
         tables_done = 1;
     }
     const uint32_t W = job->src.width, H = job->src.height;
@@ -78,7 +84,9 @@ __attribute__((visibility("default"))) int ref_tpl_dispenser_frame(const SvtHipT
     TplControls *c = &pcs->tpl_ctrls;
     c->enable = 1, c->compute_rate = 0, c->disable_intra_pred_nref = job->disable_intra_pred, c->intra_mode_end = DC_PRED;
     c->pf_shape = (EB_TRANS_COEFF_SHAPE)job->pf_shape, c->use_sad_in_src_search = 1, c->dispenser_search_level = job->blk_size == 32 ? 1 : 0, c->subsample_tx = job->subsample_tx;
-    c->synth_blk_size = job->synth_blk_size, c->subpel_depth = FULL_PEL;
+    c->synth_blk_size = job->synth_blk_size, c->subpel_depth = job->quarter_pel ? QUARTER_PEL : FULL_PEL, c->subpel_diag_refinement = 4; /* set_tpl_params levels 3 - 5 */
+    scs->static_config.qp = 35, pcs->update_type = SVT_AV1_ARF_UPDATE; /* feed the (unused: MV_COST_NONE) rdmult of tpl_subpel_search */
+    svt_av1_setup_scale_factors_for_frame(&scs->sf_identity, (int)W, (int)H, (int)W, (int)H);
     pcs->tpl_data.base_pcs = base, pcs->tpl_data.is_ref = job->is_ref;
     pcs->tpl_data.tpl_slice_type = job->tpl_i_slice ? I_SLICE : B_SLICE;
     enc->mc_flow_rec_picture_buffer[0] = &recon;

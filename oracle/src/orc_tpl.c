@@ -114,9 +114,89 @@ static int64_t quantize_error(const SvtHipTplFrameJob *job, const uint8_t *src, 
 
 static inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 
+/* ---- tpl level 3: tpl_subpel_search (src_ops_process.c:418-517) = svt_av1_find_best_sub_pixel_tree_pruned (mcomp.c:609-695) with
+ * allow_hp 0, forced_stop QUARTER_PEL (two rounds: hstep 4, 2), iters_per_step 2, skip_diag_refinement 4 (org_error 0: neither the
+ * diagonal nor the second level is ever tried), MV_COST_NONE, abs_th_mult / pred_variance_th 0, round_dev_th MAX: per round the four
+ * cardinal neighbours of the round's start vector through svt_check_better_fast -> vfp->svf = svt_aom_sub_pixel_varianceWxH_c
+ * (variance.c:28-68, 303-318: 2-tap bilinear, first pass to 16 bit, second pass to 8 bit). */
+static const uint8_t BIL_2T[8][2] = {{128, 0}, {112, 16}, {96, 32}, {80, 48}, {64, 64}, {48, 80}, {32, 96}, {16, 112}};
+static uint32_t subpel_variance(const uint8_t *a, ptrdiff_t a_stride, int xo, int yo, const uint8_t *b, ptrdiff_t b_stride, int n) {
+    uint16_t f[33 * 32];
+    for (int i = 0; i <= n; i++)
+        for (int j = 0; j < n; j++)
+            f[i * n + j] = (uint16_t)(((int)a[i * a_stride + j] * BIL_2T[xo][0] + (int)a[i * a_stride + j + 1] * BIL_2T[xo][1] + 64) >> 7);
+    int      sum = 0;
+    uint32_t sse = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            const int p = (uint8_t)(((int)f[i * n + j] * BIL_2T[yo][0] + (int)f[(i + 1) * n + j] * BIL_2T[yo][1] + 64) >> 7);
+            const int d = p - b[i * b_stride + j];
+            sum += d, sse += (uint32_t)(d * d);
+        }
+    return sse - (uint32_t)(((int64_t)sum * sum) / (n * n));
+}
+static inline int imax_(int a, int b) { return a > b ? a : b; }
+static inline int imin_(int a, int b) { return a < b ? a : b; }
+/* mx / my: in the clipped full-pel candidate (1/8 units, multiple of 8), out the refined vector */
+static void tpl_subpel_search(const uint8_t *src, ptrdiff_t ss, const uint8_t *ref0 /* sample (x, y) of the reference */, ptrdiff_t rs, int x, int y,
+                              int bs, int mi_rows, int mi_cols, int16_t *mx, int16_t *my) {
+    /* MvLimits of the block (:438-449), svt_av1_set_mv_search_range and svt_av1_set_subpel_mv_search_range around a zero ref_mv */
+    const int mi_row = y >> 2, mi_col = x >> 2, mi = bs >> 2;
+    int row_min = -(((mi_row + mi) * 4) + 4), col_min = -(((mi_col + mi) * 4) + 4);
+    int row_max = (mi_rows - mi_row) * 4 + 4, col_max = (mi_cols - mi_col) * 4 + 4;
+    col_min = imax_(col_min, imax_(-1023, (-16384 >> 3) + 1)), row_min = imax_(row_min, imax_(-1023, (-16384 >> 3) + 1));
+    col_max = imin_(col_max, imin_(1023, (16384 >> 3) - 1)), row_max = imin_(row_max, imin_(1023, (16384 >> 3) - 1));
+    const int sc_min = imax_(-16384 + 1, imax_(col_min * 8, -1023 * 8)), sc_max = imin_(16384 - 1, imin_(col_max * 8, 1023 * 8));
+    const int sr_min = imax_(-16384 + 1, imax_(row_min * 8, -1023 * 8)), sr_max = imin_(16384 - 1, imin_(row_max * 8, 1023 * 8));
+    int best_r = (*my >> 3) * 8, best_c = (*mx >> 3) * 8; /* best_mv >> 3, back to 1/8 units */
+    unsigned besterr;
+    {
+        const uint8_t *a = ref0 + (ptrdiff_t)(best_r >> 3) * rs + (best_c >> 3);
+        int      sum = 0;
+        uint32_t sse = 0;
+        for (int i = 0; i < bs; i++)
+            for (int j = 0; j < bs; j++) {
+                const int d = a[i * rs + j] - src[i * ss + j];
+                sum += d, sse += (uint32_t)(d * d);
+            }
+        besterr = sse - (uint32_t)(((int64_t)sum * sum) / (bs * bs));
+    }
+    int start_r = best_r, start_c = best_c;
+    for (int iter = 0, hstep = 4; iter < 2; iter++, hstep >>= 1) {
+        const int cr[4] = {start_r, start_r, start_r - hstep, start_r + hstep}, cc[4] = {start_c - hstep, start_c + hstep, start_c, start_c};
+        for (int k = 0; k < 4; k++) { /* left, right, up, down */
+            if (cc[k] < sc_min || cc[k] > sc_max || cr[k] < sr_min || cr[k] > sr_max)
+                continue;
+            const uint8_t *a = ref0 + (ptrdiff_t)(cr[k] >> 3) * rs + (cc[k] >> 3);
+            const unsigned cost = subpel_variance(a, rs, cc[k] & 7, cr[k] & 7, src, ss, bs);
+            if (cost < besterr)
+                besterr = cost, best_r = cr[k], best_c = cc[k];
+        }
+        start_r = best_r, start_c = best_c;
+    }
+    *mx = (int16_t)best_c, *my = (int16_t)best_r;
+}
+/* svt_aom_enc_make_inter_predictor of the luma block (:814-850): regular 8-tap kernels, vector clamped as
+ * clamp_mv_to_umv_border_sb does with the xd of init_xd_tpl; plane0 = sample (0, 0) of the reference plane */
+extern const int16_t orc_interp_kernels[3][16][8];
+static void tpl_predict(const uint8_t *plane0, ptrdiff_t stride, int x, int y, int bs, int mvx, int mvy, int mi_rows, int mi_cols, uint8_t *dst,
+                        ptrdiff_t dst_stride) {
+    const int     mirow = y >> 2, micol = x >> 2, bmi = bs >> 2;
+    const int32_t to_top = -((mirow * 4) * 8), to_bottom = ((mi_rows - bmi - mirow) * 4) * 8;
+    const int32_t to_left = -((micol * 4) * 8), to_right = ((mi_cols - bmi - micol) * 4) * 8;
+    const int32_t spel_left = (4 + bs) << 4, spel_right = spel_left - 16, spel_top = (4 + bs) << 4, spel_bottom = spel_top - 16;
+    int col = (int16_t)(mvx * 2), row = (int16_t)(mvy * 2);
+    col = imax_(to_left * 2 - spel_left, imin_(col, to_right * 2 + spel_right)), row = imax_(to_top * 2 - spel_top, imin_(row, to_bottom * 2 + spel_bottom));
+    const int sx = col & 15, sy = row & 15;
+    const uint8_t *src = plane0 + (ptrdiff_t)(y + (row >> 4)) * stride + x + (col >> 4);
+    orc_convolve_sr(src, (int32_t)stride, dst, (int32_t)dst_stride, bs, bs, orc_interp_kernels[0][sx], sx ? 8 : 0, orc_interp_kernels[0][sy], sy ? 8 : 0, 3, 11, 8,
+                    0);
+}
+
 ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
     const uint32_t W = job->src.width, H = job->src.height, aw = (W + 7) & ~7u, ah = (H + 7) & ~7u;
     const uint32_t bw64 = (aw + 63) / 64, bh64 = (ah + 63) / 64, a16 = (aw + 15) >> 4, rows16 = (ah + 15) >> 4;
+    const int      mi_rows = (int)(ah >> 2), mi_cols = (int)(aw >> 2); /* Av1Common of the picture */
     const uint8_t *src0 = job->src.buf + (size_t)job->src.org_y * job->src.stride + job->src.org_x;
     uint8_t       *rec0 = job->recon.buf + (size_t)job->recon.org_y * job->recon.stride + job->recon.org_x;
     const uint32_t ss = job->src.stride, rs = job->recon.stride;
@@ -125,6 +205,8 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
         return -1;
     if ((job->blk_size != 0 && job->blk_size != 16 && job->blk_size != 32) || (sub != 0 && sub != 2) || (job->blk_size != 32 && sub != 0))
         return -1;
+    if (job->quarter_pel && job->blk_size == 32)
+        return -1; /* set_tpl_params: QUARTER_PEL only with dispenser_search_level 0 */
     for (uint32_t sb = 0; sb < bw64 * bh64; sb++) {
         /* the caller dispenses an incomplete 64x64 block (right / bottom picture edge) with 16x16 blocks whatever the level
          * (svt_aom_tpl_disp_kernel, :2043-2051); the transform sub-sampling stays: TX_16X4 there */
@@ -147,7 +229,7 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
             int32_t  best_rf_idx = -1;
             int16_t  mv_row = 0, mv_col = 0;
             uint8_t  best_mode = 0;
-            uint8_t  pred[1024];
+            uint8_t  pred[1024], comp[1024];
             int32_t  dq[1024];
             uint16_t eob;
             if (!job->src_data_ready) {
@@ -181,7 +263,16 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
                     if ((int)y + (int)bs + (my >> 3) > TPL_PAD + (int)rf->max_height - 1)
                         my = (int16_t)(((TPL_PAD + (int)rf->max_height - 1) - ((int)y + (int)bs)) << 3);
                     const uint8_t *rp = rf->src + ((ptrdiff_t)y + my / 8) * (ptrdiff_t)rf->src_stride + (ptrdiff_t)x + mx / 8;
-                    const int64_t  cost = orc_nxm_sad(src, ss, rp, rf->src_stride, bs, bs);
+                    ptrdiff_t      rps = rf->src_stride;
+                    if (job->quarter_pel) {
+                        tpl_subpel_search(src, ss, rf->src + (ptrdiff_t)y * rf->src_stride + x, rf->src_stride, (int)x, (int)y, (int)bs, mi_rows, mi_cols, &mx, &my);
+                        rp = rf->src + ((ptrdiff_t)y + my / 8) * (ptrdiff_t)rf->src_stride + (ptrdiff_t)x + mx / 8;
+                        if ((mx & 7) || (my & 7)) {
+                            tpl_predict(rf->src, rf->src_stride, (int)x, (int)y, (int)bs, mx, my, mi_rows, mi_cols, comp, bs);
+                            rp = comp, rps = bs;
+                        }
+                    }
+                    const int64_t  cost = orc_nxm_sad(src, ss, rp, (uint32_t)rps, bs, bs);
                     if (cost < best_inter)
                         best_inter = cost, best_ref_poc = rf->picture_number, best_rf_idx = (int32_t)(dir * 4 + ri), mv_row = my, mv_col = mx;
                 }
@@ -190,7 +281,12 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
                 if (best_mode == NEWMV_MODE) {
                     const SvtHipTplRef *rf = &job->ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
                     const uint8_t      *rp = rf->src + ((ptrdiff_t)y + (mv_row >> 3)) * (ptrdiff_t)rf->src_stride + (ptrdiff_t)x + (mv_col >> 3);
-                    recon_error = quantize_error(job, src, ss, rp, rf->src_stride, dq, &eob, (int)bs, sub);
+                    uint32_t            rps = rf->src_stride;
+                    if ((mv_col & 7) || (mv_row & 7)) {
+                        tpl_predict(rf->src, rf->src_stride, (int)x, (int)y, (int)bs, mv_col, mv_row, mi_rows, mi_cols, comp, bs);
+                        rp = comp, rps = bs;
+                    }
+                    recon_error = quantize_error(job, src, ss, rp, rps, dq, &eob, (int)bs, sub);
                     st.srcrf_rate = 0, st.srcrf_dist = (recon_error << 4) << sub;
                 }
                 if (job->store_src_stats) {
@@ -206,7 +302,10 @@ ORC_API int32_t orc_tpl_dispenser_frame(const SvtHipTplFrameJob *job) {
             if (best_mode == NEWMV_MODE) {
                 const SvtHipTplRef *rf = &job->ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
                 const uint8_t      *rp = rf->recon + ((ptrdiff_t)y + (mv_row >> 3)) * (ptrdiff_t)rf->recon_stride + (ptrdiff_t)x + (mv_col >> 3);
-                for (uint32_t r = 0; r < bs; r++) memcpy(dst + (size_t)r * rs, rp + (ptrdiff_t)r * rf->recon_stride, bs);
+                if ((mv_col & 7) || (mv_row & 7))
+                    tpl_predict(rf->recon, rf->recon_stride, (int)x, (int)y, (int)bs, mv_col, mv_row, mi_rows, mi_cols, dst, rs);
+                else
+                    for (uint32_t r = 0; r < bs; r++) memcpy(dst + (size_t)r * rs, rp + (ptrdiff_t)r * rf->recon_stride, bs);
             } else {
                 dc_predict(rec0, rs, x, y, W, H, dst, rs, bs);
             }

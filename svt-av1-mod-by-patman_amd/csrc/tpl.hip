@@ -167,14 +167,121 @@ __device__ int64_t quantize_error(const TplArgs &a, const uint8_t *src, uint32_t
     return err > 1 ? err : 1;
 }
 
+// ---- tpl level 3 (tpl_ctrls.subpel_depth == QUARTER_PEL): tpl_subpel_search and the compensation of a fractional vector.
+// One wave = one 16x16 block: lane (lr, lc) owns the four samples of row lr from column lc on.
+__device__ const int16_t TPL_REGULAR[16][8] = {  // sub_pel_filters_8 (EIGHTTAP_REGULAR, inter_prediction.c:223-240)
+    {0, 0, 0, 128, 0, 0, 0, 0},      {0, 2, -6, 126, 8, -2, 0, 0},    {0, 2, -10, 122, 18, -4, 0, 0},  {0, 2, -12, 116, 28, -8, 2, 0},
+    {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -14, 102, 48, -12, 2, 0}, {0, 2, -16, 94, 58, -12, 2, 0},  {0, 2, -14, 84, 66, -12, 2, 0},
+    {0, 2, -14, 76, 76, -14, 2, 0},  {0, 2, -12, 66, 84, -14, 2, 0},  {0, 2, -12, 58, 94, -16, 2, 0},  {0, 2, -12, 48, 102, -14, 2, 0},
+    {0, 2, -10, 38, 110, -14, 2, 0}, {0, 2, -8, 28, 116, -12, 2, 0},  {0, 0, -4, 18, 122, -10, 2, 0},  {0, 0, -2, 8, 126, -6, 2, 0}};
+__device__ __forceinline__ int32_t wave_sum_i32(int32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t byte_of(uint32_t w, int i) { return (w >> (8 * i)) & 0xffu; }
+// svt_aom_sub_pixel_variance16x16_c (variance.c:28-68, 303-318) of the 16x16 block at `a` (this lane's first sample at the integer
+// position) with the bilinear phase (xo, yo) in eighths, against the lane's source samples; phase (0, 0) is svt_aom_variance16x16_c
+__device__ __forceinline__ uint32_t subpel_var16(const uint8_t *a, ptrdiff_t stride, int xo, int yo, uint32_t spx) {
+    const int32_t  f0 = 128 - 16 * xo, f1 = 16 * xo, g0 = 128 - 16 * yo, g1 = 16 * yo;
+    const uint32_t r0 = ld4(a), e0 = ld8(a + 4), r1 = ld4(a + stride), e1 = ld8(a + stride + 4);
+    int32_t        sum = 0;
+    uint32_t       sse = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int32_t a0 = (int32_t)byte_of(r0, k), a1 = k < 3 ? (int32_t)byte_of(r0, k + 1) : (int32_t)e0;
+        const int32_t b0 = (int32_t)byte_of(r1, k), b1 = k < 3 ? (int32_t)byte_of(r1, k + 1) : (int32_t)e1;
+        const int32_t h0 = (a0 * f0 + a1 * f1 + 64) >> 7, h1 = (b0 * f0 + b1 * f1 + 64) >> 7;
+        const int32_t p  = ((h0 * g0 + h1 * g1 + 64) >> 7) & 0xff;
+        const int32_t d  = p - (int32_t)byte_of(spx, k);
+        sum += d, sse += (uint32_t)(d * d);
+    }
+    sum = wave_sum_i32(sum), sse = wave_sum(sse);
+    return sse - (uint32_t)(((int64_t)sum * sum) >> 8);
+}
+// tpl_subpel_search (src_ops_process.c:418-517) = svt_av1_find_best_sub_pixel_tree_pruned (mcomp.c:609-695) as the dispenser configures
+// it: two rounds (half, quarter) of the four cardinal neighbours of the round's start vector, no vector cost, no diagonal / second
+// level (skip_diag_refinement 4), candidates outside the sub-pel limits skipped.  mx / my: in the clipped full-pel vector (1/8 units),
+// out the refined one; uniform over the wave.  ref_blk = this lane's first sample of the co-located block in the reference.
+__device__ void tpl_subpel(const uint8_t *ref_blk, ptrdiff_t stride, int x, int y, int mi_rows, int mi_cols, uint32_t spx, int &mx, int &my) {
+    const int mi_row = y >> 2, mi_col = x >> 2, mi = 4;
+    int row_min = -(((mi_row + mi) * 4) + 4), col_min = -(((mi_col + mi) * 4) + 4), row_max = (mi_rows - mi_row) * 4 + 4, col_max = (mi_cols - mi_col) * 4 + 4;
+    col_min = max(col_min, -1023), row_min = max(row_min, -1023), col_max = min(col_max, 1023), row_max = min(row_max, 1023);  // MAX_FULL_PEL_VAL; MV_LOW / MV_UPP lie outside
+    const int sc_min = col_min * 8, sc_max = col_max * 8, sr_min = row_min * 8, sr_max = row_max * 8;
+    int       best_r = (my >> 3) * 8, best_c = (mx >> 3) * 8;
+    uint32_t  besterr = subpel_var16(ref_blk + (ptrdiff_t)(best_r >> 3) * stride + (best_c >> 3), stride, 0, 0, spx);
+    int       start_r = best_r, start_c = best_c;
+    for (int iter = 0, hstep = 4; iter < 2; iter++, hstep >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // left, right, up, down
+            const int cr = start_r + (k == 2 ? -hstep : (k == 3 ? hstep : 0)), cc = start_c + (k == 0 ? -hstep : (k == 1 ? hstep : 0));
+            if (cc < sc_min || cc > sc_max || cr < sr_min || cr > sr_max)
+                continue;
+            const uint32_t cost = subpel_var16(ref_blk + (ptrdiff_t)(cr >> 3) * stride + (cc >> 3), stride, cc & 7, cr & 7, spx);
+            if (cost < besterr)
+                besterr = cost, best_r = cr, best_c = cc;
+        }
+        start_r = best_r, start_c = best_c;
+    }
+    mx = best_c, my = best_r;
+}
+// svt_aom_enc_make_inter_predictor of the 16x16 luma block (:814-850): regular 8-tap kernels, the vector clamped as
+// clamp_mv_to_umv_border_sb does with the xd of init_xd_tpl.  The 2-D form (round_0 = 3, round_1 = 11) is used for every fractional
+// vector: with the unit kernel of phase 0 on one axis it returns what svt_av1_convolve_x_sr / _y_sr return (the offsets cancel).
+// Returns this lane's four samples.  Every lane filters the eight rows its samples need in registers: a version that shared the
+// horizontal pass through LDS (23 x 16 intermediates) cost fewer instructions but is not needed at this level's speed.
+__device__ uint32_t tpl_compensate(const uint8_t *plane0, ptrdiff_t stride, int x, int y, int mvx, int mvy, int mi_rows, int mi_cols) {
+    const int     lane = threadIdx.x, lr = lane >> 2, lc = (lane & 3) * 4;
+    const int     mirow = y >> 2, micol = x >> 2, bmi = 4;
+    const int32_t to_top = -((mirow * 4) * 8), to_bottom = ((mi_rows - bmi - mirow) * 4) * 8, to_left = -((micol * 4) * 8), to_right = ((mi_cols - bmi - micol) * 4) * 8;
+    const int32_t spel_left = (4 + 16) << 4, spel_right = spel_left - 16, spel_top = (4 + 16) << 4, spel_bottom = spel_top - 16;
+    int           col = (int16_t)(mvx * 2), row = (int16_t)(mvy * 2);
+    col = max(to_left * 2 - spel_left, min(col, to_right * 2 + spel_right)), row = max(to_top * 2 - spel_top, min(row, to_bottom * 2 + spel_bottom));
+    const int      sx = col & 15, sy = row & 15;
+    const uint8_t *p = plane0 + (ptrdiff_t)(y + (row >> 4)) * stride + x + (col >> 4);
+    if (!sx && !sy)
+        return ld4(p + (ptrdiff_t)lr * stride + lc);
+    int32_t fx[8], fy[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) fx[t] = __builtin_amdgcn_readfirstlane((int)TPL_REGULAR[sx][t]), fy[t] = __builtin_amdgcn_readfirstlane((int)TPL_REGULAR[sy][t]);
+    // per lane: the eight rows its four samples need, each filtered horizontally in registers (three dwords of a row), then the vertical taps
+    int32_t v4[4] = {(1 << 19) + 1024 - ((((1 << 8) + (1 << 7))) << 11), 0, 0, 0};
+    v4[1] = v4[2] = v4[3] = v4[0];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint8_t *q = p + (ptrdiff_t)(lr - 3 + t) * stride + lc - 3;
+        const uint32_t w0 = ld4(q), w1 = ld4(q + 4), w2 = ld4(q + 8);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int32_t acc = (1 << 14) + 4;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = k + u;
+                acc += fx[u] * (int32_t)byte_of(i < 4 ? w0 : (i < 8 ? w1 : w2), i & 3);
+            }
+            v4[k] += fy[t] * (int32_t)(int16_t)(acc >> 3);
+        }
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int32_t v = v4[k] >> 11;
+        v         = v < 0 ? 0 : (v > 255 ? 255 : v);
+        out |= (uint32_t)v << (8 * k);
+    }
+    return out;
+}
+
 __device__ __forceinline__ int64_t max64(int64_t x, int64_t y) { return x > y ? x : y; }
 
 // One block: (x, y) its origin.  Dependency flags live on the 16x16-cell grid (a block of 32x32 covers four cells).
-template <int BS, int SUB>
+template <int BS, int SUB, bool QPEL = false>
 __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, const uint32_t y, int32_t *tile, uint8_t *nb) {
     constexpr int NDW = BS * BS / 256;     // dwords of the block a lane holds: 1 (16x16) or 4 (32x32)
     constexpr int LPR = BS / (4 * NDW);    // lanes per block row: 4 or 2
     static_assert((64 / BS) * (BS >> SUB) * (BS + 1) <= 4 * 16 * 17, "transform tile");
+    static_assert(!QPEL || (BS == 16 && SUB == 0), "quarter-pel refinement comes with 16x16 blocks only (set_tpl_params)");
+    const int mi_rows = (int)(((a.H + 7) & ~7u) >> 2), mi_cols = (int)(((a.W + 7) & ~7u) >> 2);  // Av1Common of the picture
     const SvtHipTplFrameJob &j = a.j;
     const int      lane = threadIdx.x;
     const uint32_t cx = x >> 4, cy = y >> 4, cell0 = cy * a.a16 + cx;
@@ -241,13 +348,21 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
             }
             for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
                 const int           src_lane = __builtin_ctzll(todo);
-                const int           cmx = __shfl(mx, src_lane, 64), cmy = __shfl(my, src_lane, 64);
+                int                 cmx = __shfl(mx, src_lane, 64), cmy = __shfl(my, src_lane, 64);
                 const uint32_t      crf = (uint32_t)__shfl((int)rfi, src_lane, 64);
                 const SvtHipTplRef &rf  = j.ref[crf >> 2][crf & 3];
+                uint32_t            sad = 0;
+                if constexpr (QPEL) {  // tpl_subpel_search, then the SAD against the compensated block when the vector is fractional
+                    tpl_subpel(rf.src + ((ptrdiff_t)y + lr) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + lc, (ptrdiff_t)rf.src_stride, (int)x, (int)y, mi_rows, mi_cols,
+                               spx[0], cmx, cmy);
+                    const uint32_t pv = ((cmx | cmy) & 7) ? tpl_compensate(rf.src, (ptrdiff_t)rf.src_stride, (int)x, (int)y, cmx, cmy, mi_rows, mi_cols)
+                                                          : ld4(rf.src + ((ptrdiff_t)y + cmy / 8 + lr) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + cmx / 8 + lc);
+                    sad = __builtin_amdgcn_sad_u8(spx[0], pv, 0u);
+                } else {
                 const uint8_t *rp = rf.src + ((ptrdiff_t)y + cmy / 8 + lr) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + cmx / 8 + lc;
-                uint32_t       sad = 0;
 #pragma unroll
                 for (int k = 0; k < NDW; k++) sad = __builtin_amdgcn_sad_u8(spx[k], ld4(rp + 4 * k), sad);
+                }
                 const int64_t cost = wave_sum(sad);
                 if (cost < best_inter)
                     best_inter = cost, best_ref_poc = rf.picture_number, best_rf_idx = (int32_t)crf, mv_row = cmy, mv_col = cmx;
@@ -258,7 +373,18 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
         if (best_mode == NEWMV_MODE) {
             const SvtHipTplRef &rf = j.ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
             const uint8_t      *rp = rf.src + ((ptrdiff_t)y + (mv_row >> 3)) * (ptrdiff_t)rf.src_stride + (ptrdiff_t)x + (mv_col >> 3);
-            srcrf_dist = (quantize_error<BS, SUB>(a, src, ss, rp, rf.src_stride, nullptr, 0, false, tile, &nonzero) << 4) << SUB;
+            uint32_t            rps = rf.src_stride;
+            if (QPEL && ((mv_col | mv_row) & 7)) {
+                // the source-based residual of a fractional vector is taken against the compensated block: it is parked in the block's
+                // own (not yet written) reconstruction area, which the transform block reads like any other prediction
+                const uint32_t pv = tpl_compensate(rf.src, (ptrdiff_t)rf.src_stride, (int)x, (int)y, mv_col, mv_row, mi_rows, mi_cols);
+                uint8_t       *o2 = dst + (size_t)lr * rs + lc;
+                o2[0] = (uint8_t)pv, o2[1] = (uint8_t)(pv >> 8), o2[2] = (uint8_t)(pv >> 16), o2[3] = (uint8_t)(pv >> 24);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __syncthreads();
+                rp = dst, rps = rs;
+            }
+            srcrf_dist = (quantize_error<BS, SUB>(a, src, ss, rp, rps, nullptr, 0, false, tile, &nonzero) << 4) << SUB;
         }
         if (j.store_src_stats && lane == 0) {
             SvtHipTplSrcStats s;
@@ -276,9 +402,14 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
     if (best_mode == NEWMV_MODE) {
         const SvtHipTplRef &rf = j.ref[best_rf_idx < 4 ? 0 : 1][best_rf_idx & 3];
         const uint8_t      *rp = rf.recon + ((ptrdiff_t)y + (mv_row >> 3) + lr) * (ptrdiff_t)rf.recon_stride + (ptrdiff_t)x + (mv_col >> 3) + lc;
+        uint32_t            qv = 0;
+        const bool          frac = QPEL && ((mv_col | mv_row) & 7);
+        if (frac) {
+            qv = tpl_compensate(rf.recon, (ptrdiff_t)rf.recon_stride, (int)x, (int)y, mv_col, mv_row, mi_rows, mi_cols);
+        }
 #pragma unroll
         for (int k = 0; k < NDW; k++) {
-            const uint32_t v = ld4(rp + 4 * k);
+            const uint32_t v = frac ? qv : ld4(rp + 4 * k);
             o[4 * k] = (uint8_t)v, o[4 * k + 1] = (uint8_t)(v >> 8), o[4 * k + 2] = (uint8_t)(v >> 16), o[4 * k + 3] = (uint8_t)(v >> 24);
         }
     } else {
@@ -392,7 +523,7 @@ __device__ __forceinline__ void tpl_block(const TplArgs &a, const uint32_t x, co
     }
 }
 
-// MODE 0: every block 16x16, transform 16x16 (tpl levels 3 / 4).  MODE 1 (level 5): complete 64x64 blocks are dispensed as 32x32
+// MODE 0: every block 16x16, transform 16x16 (tpl level 4); MODE 2: the same with the quarter-pel refinement of level 3.  MODE 1 (level 5): complete 64x64 blocks are dispensed as 32x32
 // blocks, incomplete ones (right / bottom picture edge) as 16x16 blocks (svt_aom_tpl_disp_kernel, :2043-2051), transform on every 4th
 // row in both.  A workgroup takes the next block in raster order of the block origins from the ticket counter: every block a block
 // waits for (left, top, top-left) has a lower ticket, so it is running or done whatever the dispatch order.
@@ -407,6 +538,10 @@ __global__ __launch_bounds__(64) void tpl_kernel(TplArgs a) {
     const uint32_t t = s_ticket;
     if (MODE == 0) {
         tpl_block<16, 0>(a, (t % a.a16) * 16, (t / a.a16) * 16, tile, nb);
+        return;
+    }
+    if (MODE == 2) {  // level 3: level 4 + quarter-pel refinement
+        tpl_block<16, 0, true>(a, (t % a.a16) * 16, (t / a.a16) * 16, tile, nb);
         return;
     }
     const uint32_t aw = (a.W + 7) & ~7u, ah = (a.H + 7) & ~7u;
@@ -457,6 +592,8 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     const bool b32 = job->blk_size == 32;
     if (job->blk_size != 0 && job->blk_size != 16 && !b32)
         return bad("blk_size must be 16 (or 0) or 32");
+    if (job->quarter_pel > 1 || (job->quarter_pel && b32))
+        return bad("quarter_pel is 0 or 1, and comes with 16x16 blocks only (set_tpl_params)");
     if (b32 ? job->subsample_tx != 2 : job->subsample_tx != 0)
         return bad("subsample_tx must be 0 with 16x16 blocks and 2 with 32x32 blocks");
     if (job->synth_blk_size != 16 && job->synth_blk_size != 8 && !(b32 && job->synth_blk_size == 32))
@@ -501,6 +638,8 @@ extern "C" int32_t svt_hip_tpl_dispenser_frame(const SvtHipTplFrameJob *job, voi
     a.W = s.width, a.H = s.height, a.a16 = a16, a.rows16 = rows16, a.coherent_rows = (r.stride % 4 == 0 && ((uintptr_t)(r.buf + (size_t)r.org_y * r.stride + r.org_x) % 4) == 0 && !job->publish_fence) ? 1u : 0u, a.flags = (uint32_t *)ws, a.error = (uint32_t *)(ws + fb);
     if (b32)
         hipLaunchKernelGGL((tpl_kernel<1>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
+    else if (job->quarter_pel)
+        hipLaunchKernelGGL((tpl_kernel<2>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
     else
         hipLaunchKernelGGL((tpl_kernel<0>), dim3((uint32_t)blocks), dim3(64), 0, st, a);
     SVT_HIP_CHECK(hipGetLastError());

@@ -334,7 +334,7 @@ class TplFrameJob(C.Structure):          # SvtHipTplFrameJob
                 ("is_ref", C.c_uint8), ("i_slice", C.c_uint8), ("tpl_i_slice", C.c_uint8), ("src_data_ready", C.c_uint8),
                 ("store_src_stats", C.c_uint8), ("synth_blk_size", C.c_uint8), ("blk_size", C.c_uint8), ("subsample_tx", C.c_uint8), ("publish_fence", C.c_uint8),
                 ("round_fp", C.c_int16 * 2),
-                ("quant_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2), ("pad2_", C.c_uint16), ("stats", C.c_void_p), ("src_stats", C.c_void_p),
+                ("quant_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2), ("quarter_pel", C.c_uint8), ("pad2_", C.c_uint8), ("stats", C.c_void_p), ("src_stats", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
 
 

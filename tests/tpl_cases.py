@@ -10,6 +10,7 @@ from svtav1_hip import abi, frames
 # (name, clip kind, width, height, qindex, options)
 BASE = dict(pf_shape=2, disable_intra_pred=0, is_ref=1, i_slice=0, tpl_i_slice=0, src_data_ready=0, store_src_stats=1, synth_blk_size=16)
 L5 = dict(blk_size=32, subsample_tx=2)
+L3 = dict(quarter_pel=1)
 CASES = [
     ("pan_n4", "pan", 192, 128, 120, dict(BASE)),
     ("blocks_full", "blocks", 256, 192, 60, dict(BASE, pf_shape=0)),
@@ -28,6 +29,13 @@ CASES = [
     ("l5_pan_islice", "pan", 160, 96, 90, dict(BASE, i_slice=1, tpl_i_slice=1, **L5)),
     ("l5_pan_second_pass", "pan", 192, 128, 120, dict(BASE, src_data_ready=1, **L5)),
     ("l5_pan_half_column", "pan", 376, 216, 120, dict(BASE, **L5)),   # the last 32x32 column / row is 24 samples inside the picture
+    # tpl level 3 (presets M5 / M6): quarter-pel refinement of every candidate (tpl_subpel_search), 8-tap compensation
+    ("l3_pan_n4", "pan", 192, 128, 120, dict(BASE, **L3)),
+    ("l3_blocks_full", "blocks", 256, 192, 60, dict(BASE, pf_shape=0, **L3)),
+    ("l3_fastpan_n2_ragged", "fastpan", 200, 136, 180, dict(BASE, pf_shape=1, synth_blk_size=8, **L3)),
+    ("l3_noise_intra", "noise", 136, 72, 40, dict(BASE, **L3)),
+    ("l3_static_nointra_nonref", "static", 128, 128, 100, dict(BASE, disable_intra_pred=1, is_ref=0, **L3)),
+    ("l3_fastpan_second_pass", "fastpan", 200, 136, 180, dict(BASE, pf_shape=1, src_data_ready=1, **L3)),
 ]
 # round_fp[2], quant_fp[2], dequant[2] of the reference's 8-bit tables (svt_av1_build_quantizer) at the qindex values above,
 # read from the reference by tests/golden/make_golden_tpl.py and checked against it in test_tpl_oracle.py
