@@ -93,6 +93,23 @@ def test_batched_tf_bitstream_md5(hip, case, lp):
 
 @needs_app
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,lp", [("p5_8bit_lf", 3), ("p6_10bit_lf", 4)])
+def test_batched_tpl_level3_bitstream_md5(hip, case, lp):
+    """GPU: presets M5 / M6 (BASELINE configs[3]'s preset) run tpl level 3 — every candidate vector refined to a quarter sample by
+    tpl_subpel_search, fractional vectors compensated with the 8-tap kernels — through svt_hip_tpl_dispenser_frame (quarter_pel = 1),
+    with the batched picture analysis, ME and temporal filter.  Same bitstream."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_TPL": "1", "SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_ME": "1",
+                                                               "SVTAV1_HIP_TIERB_PA": "1", "SVTAV1_HIP_ONLY": "__none__"})
+    E.assert_hip_ran_clean(log)
+    m = re.search(r"svt_hip_bind_tpl: (\d+) pictures", log)
+    assert m and int(m.group(1)) >= 1, "the batched TPL dispenser did not run:\n" + log[-2000:]
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched TPL dispenser (level 3)\n{log[-1500:]}"
+
+
+@needs_app
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,lp", [("p8_8bit_ld", 4), ("p8_10bit_ld", 4)])
 def test_batched_tf_low_delay_bitstream_md5(hip, case, lp):
     """GPU: the low-delay prediction structure (`--pred-struct 1`) runs produce_temporally_filtered_pic_ld — co-located predictions, no

@@ -53,13 +53,31 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
     EncodeContext      *enc = scs->enc_ctx;
     const TplControls  *tc  = &pcs->tpl_ctrls;
     EbPictureBufferDesc *src = pcs->enhanced_pic, *recon = enc->mc_flow_rec_picture_buffer[frame_idx];
-    /* tpl level 4 (16x16 blocks) or level 5 (32x32 blocks, TX_32X8 on every 4th row) */
+    /* tpl level 4 (16x16 blocks), level 3 (the same with the quarter-pel refinement of tpl_subpel_search) or level 5 (32x32 blocks, TX_32X8
+     * on every 4th row) */
     const int lvl5 = tc->dispenser_search_level == 1 && tc->subsample_tx == 2;
-    if (!(lvl5 || (tc->dispenser_search_level == 0 && tc->subsample_tx == 0)) || tc->intra_mode_end != DC_PRED || !tc->use_sad_in_src_search ||
-        tc->subpel_depth != FULL_PEL || tc->compute_rate || !scs->in_loop_ois || src->org_x < 32 || src->org_y < 32 || recon->org_x < 32 ||
-        recon->org_y < 32 || (tc->synth_blk_size != 8 && tc->synth_blk_size != 16 && tc->synth_blk_size != 32) ||
-        scs->static_config.tile_rows || scs->static_config.tile_columns)
+    const int qpel = tc->subpel_depth == QUARTER_PEL;
+    /* (the clamp of svt_aom_enc_make_inter_predictor keeps a compensated block within 16 + 4 samples of the picture and the taps add three:
+     * the 32 samples of padding the full-pel path needs cover it) */
+    if (qpel && (lvl5 || tc->subpel_diag_refinement < 4 ||
+                 pcs->av1_cm->mi_rows != (int32_t)(pcs->aligned_height >> 2) || pcs->av1_cm->mi_cols != (int32_t)(pcs->aligned_width >> 2))) {
+        static int said;
+        if (!__atomic_exchange_n(&said, 1, __ATOMIC_RELAXED))
+            fprintf(stderr, "svt_hip_bind_tpl: level 3 declined: lvl5 %d diag %d mi %d x %d vs %d x %d\n", lvl5, tc->subpel_diag_refinement, pcs->av1_cm->mi_rows,
+                    pcs->av1_cm->mi_cols, pcs->aligned_height >> 2, pcs->aligned_width >> 2);
         return 1;
+    }
+    if (!(lvl5 || (tc->dispenser_search_level == 0 && tc->subsample_tx == 0)) || tc->intra_mode_end != DC_PRED || !tc->use_sad_in_src_search ||
+        (tc->subpel_depth != FULL_PEL && !qpel) || tc->compute_rate || !scs->in_loop_ois || src->org_x < 32 || src->org_y < 32 || recon->org_x < 32 ||
+        recon->org_y < 32 || (tc->synth_blk_size != 8 && tc->synth_blk_size != 16 && tc->synth_blk_size != 32) ||
+        scs->static_config.tile_rows || scs->static_config.tile_columns) {
+        static int said2;
+        if (!__atomic_exchange_n(&said2, 1, __ATOMIC_RELAXED) && getenv("SVTAV1_E2E_TRACE_TPL"))
+            fprintf(stderr, "svt_hip_bind_tpl: declined: search level %d subsample_tx %d intra_mode_end %d sad %d subpel %d rate %d ois %d synth %d\n",
+                    tc->dispenser_search_level, tc->subsample_tx, tc->intra_mode_end, tc->use_sad_in_src_search, tc->subpel_depth, tc->compute_rate, scs->in_loop_ois,
+                    tc->synth_blk_size);
+        return 1;
+    }
     SvtHipTplFrameJob *job = (SvtHipTplFrameJob *)calloc(1, sizeof(*job));
     if (!job)
         return 1;
@@ -164,6 +182,7 @@ static int run_picture(PictureParentControlSet *pcs, int32_t frame_idx, int32_t 
         job->src_data_ready = pcs->tpl_src_data_ready, job->store_src_stats = scs->tpl_lad_mg > 0;
         /* level 4: one cell per 16x16 block, the synthesizer's grid is filled below; level 5: the library writes that grid itself */
         job->synth_blk_size = lvl5 ? tc->synth_blk_size : 16, job->blk_size = lvl5 ? 32 : 16, job->subsample_tx = lvl5 ? 2 : 0;
+        job->quarter_pel = (uint8_t)qpel;
         for (int i = 0; i < 2; i++) {
             job->round_fp[i] = enc->quants_8bit.y_round_fp[qindex][i], job->quant_fp[i] = enc->quants_8bit.y_quant_fp[qindex][i];
             job->dequant[i] = enc->deq_8bit.y_dequant_qtx[qindex][i];
