@@ -4,11 +4,12 @@
  * Reference interface replaced (paths relative to /root/reference):
  *   Source/Lib/Codec/src_ops_process.c:519-1207   tpl_mc_flow_dispenser_sb_generic, called per 64x64 block from
  *                                                 tpl_mc_flow_dispenser (:1348-1410) / svt_aom_tpl_disp_kernel (:1964)
- * for the configurations the reference runs at presets M7 and faster (tpl levels 4 and 5 of set_tpl_params,
- * initial_rc_process.c:284-296, 359-382; and level 3 without its sub-pel refinement): 16x16 blocks (dispenser_search_level 0)
+ * for the configurations the reference runs at presets M5 and faster (tpl levels 3, 4 and 5 of set_tpl_params,
+ * initial_rc_process.c:284-296, 345-382): 16x16 blocks (dispenser_search_level 0)
  * or 32x32 blocks whose transform runs on every 4th row (level 5: dispenser_search_level 1, subsample_tx 2, TX_32X8), DC intra
  * prediction only (intra_mode_end == DC_PRED), SAD in the source-based search, full-pel vectors straight from the open-loop
- * ME results, no rate estimate (compute_rate 0), any coefficient shape (pf_shape).  Per block:
+ * ME results — or, level 3 (quarter_pel), refined to a quarter sample and compensated with the 8-tap kernels —, no rate estimate
+ * (compute_rate 0), any coefficient shape (pf_shape).  Per block:
  *   source-based path  DC prediction from the SOURCE neighbours and its sub-sampled SAD; every single-reference ME candidate,
  *                      vector clipped to the TPL padding, sub-sampled SAD against the reference's source picture; for an
  *                      inter winner residual -> DCT 16x16 (32x8) -> svt_av1_quantize_fp -> svt_av1_block_error  (srcrf_dist)
@@ -24,8 +25,8 @@
  * XCD's L2), waiting for those stores and then setting its flags; this needs 4-byte aligned reconstruction rows (stride and sample
  * (0,0) address multiples of 4), otherwise — or with SVTAV1_HIP_TPL_FENCE set in the environment — a device-scope release fence per
  * block (an L2 write-back, about three times slower) does it.
- * Not provided: the other intra modes and the SATD source search (tpl levels 1, 2), sub-pel refinement (levels 1-3),
- * 64x64 dispenser blocks, subsample_tx 1, the rate estimate.
+ * Not provided: the other intra modes and the SATD source search (tpl levels 1, 2), 64x64 dispenser blocks, subsample_tx 1, the
+ * rate estimate.
  */
 #ifndef SVT_HIP_TPL_H
 #define SVT_HIP_TPL_H

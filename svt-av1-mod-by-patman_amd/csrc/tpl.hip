@@ -1,6 +1,6 @@
 // tpl.hip — the TPL dispenser of one picture on gfx950: tpl_mc_flow_dispenser_sb_generic
-// (src_ops_process.c:519-1207) for the DC / SAD / full-pel configurations described in include/svt_hip_tpl.h: 16x16 blocks, or 32x32
-// blocks whose transform is TX_32X8 on every 4th row (tpl level 5).
+// (src_ops_process.c:519-1207) for the DC / SAD configurations described in include/svt_hip_tpl.h: 16x16 blocks with full-pel (tpl level 4)
+// or quarter-pel refined vectors (level 3), or 32x32 blocks whose transform is TX_32X8 on every 4th row (level 5).
 //
 // One wavefront per block, all blocks of the picture in ONE launch:
 //   source-based path (no dependencies): the block's source samples stay in registers (one or four dwords per lane); DC prediction
