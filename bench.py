@@ -734,7 +734,7 @@ def pmc_groups():
               "sgr_filter": (["sgr_filter_kernel<0>"], 1), "sgr_apply": (["sgr_filter_kernel<1>"], 1),
               "wiener_stats": (["wiener_stats_kernel", "wiener_finalize_kernel"], 1), "wiener_convolve": (["wiener_convolve_kernel"], 1),
               "tf": (["me_b64_kernel<true>", "tf_refine_kernel", "tf_blocks_kernel", "tf_predict", "tf_filter_blocks_kernel", "tf_accumulate_kernel", "tf_central_kernel", "tf_normalise_kernel"], 1),
-              "tpl4": (["tpl_kernel<0>"], 1), "tpl5": (["tpl_kernel<1>"], 1)})
+              "tpl4": (["tpl_kernel<0>"], 1), "tpl5": (["tpl_kernel<1>"], 1), "tpl3": (["tpl_kernel<2>"], 1)})
     return g
 
 
@@ -839,6 +839,15 @@ def tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
     ms5 = timed_launches(stream, *((1, 0) if args.pmc_child else (5, 2)), run_tpl)
     out.append(roof("tpl_kernel level 5 (32x32 / 16x16 blocks, TX_32X8 / TX_16X4 on every 4th row)", nblk * (256 * (1 + 5) + 2 * 256) + (nblk // 4) * (64 + 40), ms5,
                     unit_of_work="one 4K picture", result_checksum=int(stats.to(torch.int64).sum().item()), pmc_key="tpl5"))
+    # tpl level 3 (presets M5 / M6, BASELINE configs[3]): level 4 + quarter-pel refinement of every candidate (9 bilinear sub-pixel
+    # variances over two rows of 17 samples each) and 8-tap compensation of fractional vectors (23 x 23 samples, three times for a winner)
+    tj.blk_size, tj.subsample_tx, tj.synth_blk_size, tj.quarter_pel = 16, 0, 16, 1
+    stats.zero_()
+    ms3 = timed_launches(stream, *((1, 0) if args.pmc_child else (5, 2)), run_tpl)
+    out.append(roof("tpl_kernel level 3 (16x16 blocks, quarter-pel refinement + 8-tap compensation)", nblk * (256 * (1 + 5) + 2 * 256 + 64 + 40), ms3,
+                    unit_of_work=f"one 4K picture, {nblk} blocks (same algorithmic bytes as level 4: the refinement re-reads cached samples)",
+                    result_checksum=int(stats.to(torch.int64).sum().item()), pmc_key="tpl3"))
+    tj.quarter_pel = 0
     return out
 
 
