@@ -147,6 +147,11 @@ typedef struct SvtHipTfB64State {
     uint8_t  split32[4];       /* tf_32x32_block_split_flag */
     uint8_t  use_64x64;        /* the block is predicted as one 64x64 (convert_64x64_info_to_32x32_info applies) */
     uint8_t  pad_[3];
+    /* enable_8x8_pred (tf level 1): tf_8x8_block_error / tf_8x8_mv_x / _y in the reference's order (idx_32x32 * 16 + idx_16x16 * 4 +
+     * idx_8x8) and tf_16x16_block_split_flag[idx_32x32][idx_16x16]; err16 of a split 16x16 block is the sum of its four 8x8 errors */
+    uint64_t err8[64];
+    int16_t  mv8_x[64], mv8_y[64];
+    uint8_t  split16[16];
 } SvtHipTfB64State;
 
 /* ---- noise estimate (svt_estimate_noise_fp16 / svt_estimate_noise_highbd_fp16, aom_dsp_rtcd.h:874-877;

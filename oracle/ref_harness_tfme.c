@@ -85,7 +85,7 @@ __attribute__((visibility("default"))) int ref_tf_picture(const SvtHipTfPictureJ
         tables_done = 1;
     }
     const int n = (int)job->n_refs + 1;
-    if (n > ALTREF_MAX_NFRAMES || job->ctrls.enable_8x8_pred)
+    if (n > ALTREF_MAX_NFRAMES)
         return -1;
     SequenceControlSet *scs = calloc(1, sizeof(*scs));
     TfPicBuild         *pb  = calloc((size_t)n, sizeof(*pb));

@@ -26,7 +26,7 @@ ORC_API void orc_tf_central(const SvtHipTfBlock *b);
 ORC_API void orc_tf_normalise(const SvtHipTfBlock *b, const SvtHipTfOut *o);
 
 /* the AV1 interpolation kernels (inter_prediction.c:223-300): regular, sharp, bilinear — 16 phases x 8 taps */
-ORC_API const int16_t orc_interp_kernels[3][16][8] = {
+ORC_API const int16_t orc_interp_kernels[4][16][8] = {
     {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 2, -6, 126, 8, -2, 0, 0}, {0, 2, -10, 122, 18, -4, 0, 0}, {0, 2, -12, 116, 28, -8, 2, 0},
      {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -14, 102, 48, -12, 2, 0}, {0, 2, -16, 94, 58, -12, 2, 0}, {0, 2, -14, 84, 66, -12, 2, 0},
      {0, 2, -14, 76, 76, -14, 2, 0}, {0, 2, -12, 66, 84, -14, 2, 0}, {0, 2, -12, 58, 94, -16, 2, 0}, {0, 2, -12, 48, 102, -14, 2, 0},
@@ -39,8 +39,14 @@ ORC_API const int16_t orc_interp_kernels[3][16][8] = {
     {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, 0, 120, 8, 0, 0, 0}, {0, 0, 0, 112, 16, 0, 0, 0}, {0, 0, 0, 104, 24, 0, 0, 0},
      {0, 0, 0, 96, 32, 0, 0, 0}, {0, 0, 0, 88, 40, 0, 0, 0}, {0, 0, 0, 80, 48, 0, 0, 0}, {0, 0, 0, 72, 56, 0, 0, 0},
      {0, 0, 0, 64, 64, 0, 0, 0}, {0, 0, 0, 56, 72, 0, 0, 0}, {0, 0, 0, 48, 80, 0, 0, 0}, {0, 0, 0, 40, 88, 0, 0, 0},
-     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 24, 104, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}, {0, 0, 0, 8, 120, 0, 0, 0}}};
-enum { K_REGULAR = 0, K_SHARP = 1, K_BILINEAR = 2 };
+     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 24, 104, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}, {0, 0, 0, 8, 120, 0, 0, 0}},
+    /* sub_pel_filters_4 (inter_prediction.c:239-254): what av1_get_interp_filter_params_with_block_size gives blocks of width <= 4 for the
+     * regular AND the sharp filter (inter_prediction.h:137-145) */
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, -4, 126, 8, -2, 0, 0}, {0, 0, -8, 122, 18, -4, 0, 0}, {0, 0, -10, 116, 28, -6, 0, 0},
+     {0, 0, -12, 110, 38, -8, 0, 0}, {0, 0, -12, 102, 48, -10, 0, 0}, {0, 0, -14, 94, 58, -10, 0, 0}, {0, 0, -12, 84, 66, -10, 0, 0},
+     {0, 0, -12, 76, 76, -12, 0, 0}, {0, 0, -10, 66, 84, -12, 0, 0}, {0, 0, -10, 58, 94, -14, 0, 0}, {0, 0, -10, 48, 102, -12, 0, 0},
+     {0, 0, -8, 38, 110, -12, 0, 0}, {0, 0, -6, 28, 116, -10, 0, 0}, {0, 0, -4, 18, 122, -8, 0, 0}, {0, 0, -2, 8, 126, -4, 0, 0}}};
+enum { K_REGULAR = 0, K_SHARP = 1, K_BILINEAR = 2, K_REGULAR4 = 3 };
 
 typedef struct Geo { /* what the reference keeps in MacroBlockD / Av1Common for the motion-vector clamp */
     int32_t mi_rows, mi_cols;
@@ -164,7 +170,7 @@ static void final_prediction(const SvtHipTfPictureJob *job, const Geo *g, const 
         const int    px = (((ox + lx) >> 3) << 3) / 2, py = (((oy + ly) >> 3) << 3) / 2; /* pu_origin_*_chroma */
         const int    dx = ((lx >> 3) << 3) / 2, dy = ((ly >> 3) << 3) / 2;
         predict(g, c0, (int32_t)ref->chroma8_stride, is16, job->bit_depth, (uint8_t *)pred[p] + (((size_t)dy * 32 + dx) << is16), 32, px, py, bsize / 2,
-                bsize / 2, mvx, mvy, 1, ox + lx, oy + ly, bsize, K_SHARP, 0);
+                bsize / 2, mvx, mvy, 1, ox + lx, oy + ly, bsize, bsize / 2 <= 4 ? K_REGULAR4 : K_SHARP, 0);
     }
 }
 
@@ -236,21 +242,51 @@ low_delay:
         if (st->err32[i] < c->pred_error_32x32_th) {
             st->split32[i] = 0;
         } else {
-            /* tf_16x16_sub_pel_search (always the regular 8-tap kernel), then derive_tf_32x32_block_split_flag without 8x8 */
-            int64_t sum16 = 0;
+            /* tf_16x16_sub_pel_search (always the regular 8-tap kernel), tf_8x8_sub_pel_search (:2106-2224) with enable_8x8_pred, then
+             * derive_tf_32x32_block_split_flag (:236-285) */
             for (int k = 0; k < 4; k++) {
                 const int q = i * 4 + k;
                 st->err16[q]  = 0x7fffffff;
                 st->mv16_x[q] = (int16_t)(mv_x_of(best_mv[5 + q]) << 3), st->mv16_y[q] = (int16_t)(mv_y_of(best_mv[5 + q]) << 3);
                 subpel_search(&s, 16, lx + (k & 1) * 16, ly + (k >> 1) * 16, K_REGULAR, &st->err16[q], &st->mv16_x[q], &st->mv16_y[q]);
-                sum16 += (int)st->err16[q];
             }
-            st->split32[i] = !((int)st->err32[i] * 14 < (int)sum16 * 16);
+            if (c->enable_8x8_pred)
+                for (int k = 0; k < 4; k++)
+                    for (int e = 0; e < 4; e++) {
+                        /* idx_32x32_to_idx_8x8 / subblock_xy_8x8 / tab8x8: the 8x8 blocks in z-order, their vectors in the same order */
+                        const int idx = i * 16 + k * 4 + e, lx8 = lx + (k & 1) * 16 + (e & 1) * 8, ly8 = ly + (k >> 1) * 16 + (e >> 1) * 8;
+                        st->err8[idx]  = 0x7fffffff;
+                        st->mv8_x[idx] = (int16_t)(mv_x_of(best_mv[21 + idx]) << 3), st->mv8_y[idx] = (int16_t)(mv_y_of(best_mv[21 + idx]) << 3);
+                        subpel_search(&s, 8, lx8, ly8, K_REGULAR, &st->err8[idx], &st->mv8_x[idx], &st->mv8_y[idx]);
+                    }
+            int sum16 = 0;
+            for (int k = 0; k < 4; k++) {
+                const int q = i * 4 + k;
+                int       sub = (int)st->err16[q];
+                if (c->enable_8x8_pred) {
+                    int e8 = 0;
+                    for (int e = 0; e < 4; e++) e8 += (int)st->err8[q * 4 + e];
+                    if (sub * 8 < e8 * 16) {
+                        st->split16[q] = 0;
+                    } else {
+                        st->split16[q] = 1, st->err16[q] = (uint64_t)e8, sub = e8;
+                    }
+                }
+                sum16 += sub;
+            }
+            st->split32[i] = !((int)st->err32[i] * 14 < sum16 * 16);
         }
         /* tf_32x32_inter_prediction */
         if (st->split32[i])
-            for (int k = 0; k < 4; k++)
-                final_prediction(job, &s.g, ref, pred, ox, oy, lx + (k & 1) * 16, ly + (k >> 1) * 16, 16, st->mv16_x[i * 4 + k], st->mv16_y[i * 4 + k]);
+            for (int k = 0; k < 4; k++) {
+                if (st->split16[i * 4 + k]) {
+                    for (int e = 0; e < 4; e++)
+                        final_prediction(job, &s.g, ref, pred, ox, oy, lx + (k & 1) * 16 + (e & 1) * 8, ly + (k >> 1) * 16 + (e >> 1) * 8, 8,
+                                         st->mv8_x[i * 16 + k * 4 + e], st->mv8_y[i * 16 + k * 4 + e]);
+                } else {
+                    final_prediction(job, &s.g, ref, pred, ox, oy, lx + (k & 1) * 16, ly + (k >> 1) * 16, 16, st->mv16_x[i * 4 + k], st->mv16_y[i * 4 + k]);
+                }
+            }
         else
             final_prediction(job, &s.g, ref, pred, ox, oy, lx, ly, 32, st->mv32_x[i], st->mv32_y[i]);
     }
@@ -280,7 +316,7 @@ static void tf_block_of(const SvtHipTfPictureJob *job, int ox, int oy, int q, vo
 
 /* states: [n_refs][n_b64] or NULL; tot[2] += horizontal / vertical block counts (motion_estimation.c:2539-2544) */
 ORC_API int32_t orc_tf_filter_picture(const SvtHipTfPictureJob *job, SvtHipTfB64State *states, uint32_t *tot) {
-    if (job->ctrls.enable_8x8_pred || job->n_refs > SVT_HIP_TF_MAX_REFS || (job->bit_depth != 8 && job->bit_depth != 10))
+    if (job->n_refs > SVT_HIP_TF_MAX_REFS || (job->bit_depth != 8 && job->bit_depth != 10))
         return -1;
     const SvtHipPlane8 *cf = &job->centre.pyr.full;
     const uint32_t W = cf->width, H = cf->height, bw = (W + 63) / 64, bh = (H + 63) / 64, nb = bw * bh;

@@ -178,7 +178,7 @@ static void tpl_subpel_search(const uint8_t *src, ptrdiff_t ss, const uint8_t *r
 }
 /* svt_aom_enc_make_inter_predictor of the luma block (:814-850): regular 8-tap kernels, vector clamped as
  * clamp_mv_to_umv_border_sb does with the xd of init_xd_tpl; plane0 = sample (0, 0) of the reference plane */
-extern const int16_t orc_interp_kernels[3][16][8];
+extern const int16_t orc_interp_kernels[4][16][8];
 static void tpl_predict(const uint8_t *plane0, ptrdiff_t stride, int x, int y, int bs, int mvx, int mvy, int mi_rows, int mi_cols, uint8_t *dst,
                         ptrdiff_t dst_stride) {
     const int     mirow = y >> 2, micol = x >> 2, bmi = bs >> 2;

@@ -308,7 +308,8 @@ class TfPictureJob(C.Structure):         # SvtHipTfPictureJob
 class TfB64State(C.Structure):           # SvtHipTfB64State
     _fields_ = [("err64", C.c_uint64), ("err32", C.c_uint64 * 4), ("err16", C.c_uint64 * 16), ("mv64_x", C.c_int16), ("mv64_y", C.c_int16),
                 ("mv32_x", C.c_int16 * 4), ("mv32_y", C.c_int16 * 4), ("mv16_x", C.c_int16 * 16), ("mv16_y", C.c_int16 * 16),
-                ("split32", C.c_uint8 * 4), ("use_64x64", C.c_uint8), ("pad_", C.c_uint8 * 3)]
+                ("split32", C.c_uint8 * 4), ("use_64x64", C.c_uint8), ("pad_", C.c_uint8 * 3), ("err8", C.c_uint64 * 64),
+                ("mv8_x", C.c_int16 * 64), ("mv8_y", C.c_int16 * 64), ("split16", C.c_uint8 * 16)]
 
 
 class TplStats(C.Structure):             # SvtHipTplStats (include/svt_hip_tpl.h)

@@ -34,6 +34,11 @@ CASES = [
     ("pan_ld_8bit", "pan", 192, 128, 2, 8, "m8_360p_tl0", dict(LVL6, low_delay=1)),
     ("static_ld_sub_10bit", "static", 144, 80, 3, 10, "m8_360p_tl0", dict(LVL8, low_delay=1, chroma=1)),
     ("blocks_ld_10bit", "blocks", 128, 128, 1, 10, "m6_360p_tl0", dict(LVL1, low_delay=1)),
+    # tf level 1 (presets <= M2): enable_8x8_pred — tf_8x8_sub_pel_search, 16x16 -> 8x8 split flags, 8x8 luma / 4x4 chroma predictions
+    ("blocks_lvl1_8x8_8bit", "blocks", 256, 128, 2, 8, "m6_360p_tl0", dict(LVL1, enable_8x8_pred=1)),
+    ("subpel16_8x8_10bit", "subpel16", 128, 128, 1, 10, "m6_360p_tl0", dict(LVL1, enable_8x8_pred=1)),
+    ("fastpan_8x8_sub_8bit", "fastpan", 144, 80, 2, 8, "m6_360p_tl0", dict(LVL1, enable_8x8_pred=1, sub_sampling_shift=1, subpel_early_exit_th=1, use_2tap=1)),
+    ("blocks_8x8_10bit_sub8", "blocks", 256, 128, 2, 10, "m6_360p_tl0", dict(LVL1, enable_8x8_pred=1, use_8bit_subpel=1, eight_pel_mode=0)),
 ]
 NOISE_LOG1P_FP16 = (3 << 16) // 4, (1 << 16) // 2, (1 << 16) // 2
 QP = 35
@@ -142,6 +147,7 @@ def make_job(pics, w, h, bd, key, ctl, decay=(0, 0, 0), ptrs=None):
               "subpel_early_exit_th", "use_8bit_subpel", "pred_error_32x32_th"):
         setattr(job.ctrls, k, ctl[k])
     job.ctrls.use_zz_based_filter, job.ctrls.low_delay = ctl.get("use_zz_based_filter", 0), ctl.get("low_delay", 0)
+    job.ctrls.enable_8x8_pred = ctl.get("enable_8x8_pred", 0)
     for i in range(3):
         job.decay_factor_fp16[i] = decay[i]
     job.mv_dist_th = min(450, max(64, min(h, w) - 150))
