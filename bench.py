@@ -935,7 +935,7 @@ def headline(lib, dev, args, world, rank, local_rank, rehearsal, traffic, traffi
         # the dominant kernel of a multi-kernel entry prices its instructions
         dom = {"dlf": "dlf_pass_kernel<1>", "cdef_search": "cdef_search_kernel", "cdef_apply": "cdef_apply_frame_kernel", "sgr_filter": "sgr_filter_kernel<0>",
                "sgr_apply": "sgr_filter_kernel<1>", "wiener_stats": "wiener_stats_kernel<7>", "wiener_convolve": "wiener_convolve_kernel",
-               "tf": "tf_refine_kernel<false>", "tpl4": "tpl_kernel<0>", "tpl5": "tpl_kernel<1>"}
+               "tf": "tf_refine_kernel<false, false>", "tpl4": "tpl_kernel<0>", "tpl5": "tpl_kernel<1>", "tpl3": "tpl_kernel<2>"}
         for r in lf_stage_rooflines(lib, dev, args, sp, stream, rank) + tf_tpl_stage_rooflines(lib, dev, args, sp, stream, mw):
             key = r.pop("pmc_key")
             rl_all.append(attach(r, key, dom[key]))

@@ -85,7 +85,9 @@ SVT_HIP_API int32_t svt_hip_tf_filter_blocks(const SvtHipTfBlock *const *d_ref_b
  * What stays with the caller (scalar control logic): which pictures enter the window (the ahd-error / brightness outlier
  * tests, ref_frame_factor), tf_decay_factor_fp16 (noise levels, qp), tf_chroma, tf_mv_dist_th; packing 10-bit pictures into
  * 16-bit planes before and unpacking / re-decimating the filtered centre picture after (svt_hip_pyramid_frame).
- * 8x8 prediction (TfControls::enable_8x8_pred, tf level 1 only) is not provided: the call refuses it. */
+ * 8x8 prediction (TfControls::enable_8x8_pred, tf level 1 = presets <= M2): tf_8x8_sub_pel_search (:2106-2224) behind the 16x16
+ * searches, the 16x16 -> 8x8 decisions of derive_tf_32x32_block_split_flag (:236-285), 8x8 luma / 4x4 chroma predictions (:2384-2445;
+ * the chroma blocks with the 4-tap kernels of narrow blocks); the ME parameters must have enable_me_8x8 set. */
 #define SVT_HIP_TF_MAX_REFS 32 /* ALTREF_MAX_NFRAMES - 1 */
 
 typedef struct SvtHipTfCtrls {      /* the TfControls fields (definitions.h:120-215) the block loop reads */

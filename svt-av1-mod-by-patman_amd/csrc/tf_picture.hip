@@ -23,7 +23,7 @@ using namespace svthip;
 namespace {
 
 // the AV1 interpolation kernels (inter_prediction.c:223-300): regular, sharp, bilinear — 16 phases x 8 taps
-__device__ const int16_t TF_KERNELS[3][16][8] = {
+__device__ const int16_t TF_KERNELS[4][16][8] = {
     {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 2, -6, 126, 8, -2, 0, 0}, {0, 2, -10, 122, 18, -4, 0, 0}, {0, 2, -12, 116, 28, -8, 2, 0},
      {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -14, 102, 48, -12, 2, 0}, {0, 2, -16, 94, 58, -12, 2, 0}, {0, 2, -14, 84, 66, -12, 2, 0},
      {0, 2, -14, 76, 76, -14, 2, 0}, {0, 2, -12, 66, 84, -14, 2, 0}, {0, 2, -12, 58, 94, -16, 2, 0}, {0, 2, -12, 48, 102, -14, 2, 0},
@@ -36,8 +36,13 @@ __device__ const int16_t TF_KERNELS[3][16][8] = {
     {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, 0, 120, 8, 0, 0, 0}, {0, 0, 0, 112, 16, 0, 0, 0}, {0, 0, 0, 104, 24, 0, 0, 0},
      {0, 0, 0, 96, 32, 0, 0, 0}, {0, 0, 0, 88, 40, 0, 0, 0}, {0, 0, 0, 80, 48, 0, 0, 0}, {0, 0, 0, 72, 56, 0, 0, 0},
      {0, 0, 0, 64, 64, 0, 0, 0}, {0, 0, 0, 56, 72, 0, 0, 0}, {0, 0, 0, 48, 80, 0, 0, 0}, {0, 0, 0, 40, 88, 0, 0, 0},
-     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 24, 104, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}, {0, 0, 0, 8, 120, 0, 0, 0}}};
-enum { K_REGULAR = 0, K_SHARP = 1, K_BILINEAR = 2 };
+     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 24, 104, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}, {0, 0, 0, 8, 120, 0, 0, 0}},
+    // sub_pel_filters_4: what blocks of width <= 4 get for the regular and the sharp filter (inter_prediction.h:137-145)
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, -4, 126, 8, -2, 0, 0}, {0, 0, -8, 122, 18, -4, 0, 0}, {0, 0, -10, 116, 28, -6, 0, 0},
+     {0, 0, -12, 110, 38, -8, 0, 0}, {0, 0, -12, 102, 48, -10, 0, 0}, {0, 0, -14, 94, 58, -10, 0, 0}, {0, 0, -12, 84, 66, -10, 0, 0},
+     {0, 0, -12, 76, 76, -12, 0, 0}, {0, 0, -10, 66, 84, -12, 0, 0}, {0, 0, -10, 58, 94, -14, 0, 0}, {0, 0, -10, 48, 102, -12, 0, 0},
+     {0, 0, -8, 38, 110, -12, 0, 0}, {0, 0, -6, 28, 116, -10, 0, 0}, {0, 0, -4, 18, 122, -8, 0, 0}, {0, 0, -2, 8, 126, -4, 0, 0}}};
+enum { K_REGULAR = 0, K_SHARP = 1, K_BILINEAR = 2, K_REGULAR4 = 3 };
 constexpr int WIN_MARGIN = 10;
 constexpr int DESC_PER_B64 = 48;
 
@@ -172,7 +177,7 @@ struct Geo {
     static constexpr int WD = W + 2 * WIN_MARGIN;      // window width = height = pitch
     static constexpr int WDP = WD > 64 ? 128 : 64;      // the staging loop's row length (a power of two)
     static constexpr int G = 64 / W;                    // items per wave
-    static constexpr int LB = W == 64 ? 6 : (W == 32 ? 5 : 4);
+    static constexpr int LB = W == 64 ? 6 : (W == 32 ? 5 : (W == 16 ? 4 : 3));
 };
 
 // evaluate the item of this lane's group (valid == false: an idle group); returns the distortion on every lane of the group
@@ -383,10 +388,15 @@ __device__ void fill_block(const RefineArgs &a, uint32_t b, int q, const uint8_t
     t.is_16bit = (uint8_t)is16, t.bit_depth = a.bit_depth, t.zz_based = a.ctrls.use_zz_based_filter;
 }
 
-template <bool S16>
+// E8: with the 8x8 stage of tf level 1 (its own instance: the extra search keeps 26 more registers live across the whole kernel)
+template <bool S16, bool E8>
 __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const RefineRef *__restrict__ refs, uint32_t *__restrict__ tot) {
     __shared__ Lds              L;
-    __shared__ SvtHipTfB64State st;
+    // the block's state record; without the 8x8 stage only the part in front of err8 lives in LDS (the whole record cost 0.12 ms per picture)
+    constexpr int ST_BYTES = E8 ? (int)sizeof(SvtHipTfB64State) : (int)offsetof(SvtHipTfB64State, err8);
+    static_assert(ST_BYTES % 8 == 0, "state record prefix");
+    __shared__ uint64_t st_mem[ST_BYTES / 8];
+    SvtHipTfB64State   &st = *reinterpret_cast<SvtHipTfB64State *>(st_mem);
     const RefineRef    &R = refs[blockIdx.y];  // a by-value copy went to scratch memory: its plane arrays are indexed at run time
     const uint32_t      b = blockIdx.x;
     const int           tid = threadIdx.x, ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64;
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
     s.ref0 = S16 ? (const void *)R.pic.y16 : (const void *)R.pic.y8, s.ref_stride = R.pic.stride;
     const void *src0 = S16 ? (const void *)a.centre.y16 : (const void *)a.centre.y8;
     for (int i = tid; i < 64 * 64; i += 256) L.src[i] = (uint16_t)ldg<S16>(src0, (ptrdiff_t)(oy + (i >> 6)) * a.centre.stride + ox + (i & 63));
-    for (int i = tid; i < (int)(sizeof(st) / 4); i += 256) ((uint32_t *)&st)[i] = 0;
+    for (int i = tid; i < ST_BYTES / 4; i += 256) ((uint32_t *)&st)[i] = 0;
     L.taps[tid >> 7][(tid >> 3) & 15][tid & 7] = TF_KERNELS[(tid >> 7) ? K_BILINEAR : K_REGULAR][(tid >> 3) & 15][tid & 7];
     const SvtHipMeSearchResult sr = R.sr[(size_t)b * 8];
     const uint32_t *best_mv = R.best_mv + (size_t)b * 8 * 85, *best_sad = R.best_sad + (size_t)b * 8 * 85;
@@ -463,8 +473,45 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
             for (int k = 0; k < 4; k++) sum16 += (int)L.blk[k].best;
             if (tid < 4)
                 st.err16[i * 4 + tid] = L.blk[tid].best, st.mv16_x[i * 4 + tid] = (int16_t)L.blk[tid].mvx, st.mv16_y[i * 4 + tid] = (int16_t)L.blk[tid].mvy;
-            if (tid == 0)
-                st.split32[i] = !((int)e32 * 14 < (int)sum16 * 16);
+            if (!E8 || !c.enable_8x8_pred) {
+                if (tid == 0)
+                    st.split32[i] = !((int)e32 * 14 < (int)sum16 * 16);
+                __syncthreads();  // L.blk[] is rewritten by the next 32x32 block
+                continue;
+            }
+            // tf_8x8_sub_pel_search (temporal_filtering.c:2106-2224): the four 8x8 blocks of each 16x16 block side by side, eight candidates
+            // per wave; then derive_tf_32x32_block_split_flag with the 16x16 -> 8x8 decisions (:236-285)
+            for (int k = 0; k < 4; k++) {
+                __syncthreads();  // L.blk[] has been read
+                if (tid < 4) {
+                    Blk      &B = L.blk[tid];
+                    const int idx = i * 16 + k * 4 + tid;  // idx_32x32_to_idx_8x8 / tab8x8: z-order, the ME's 8x8 vectors in the same order
+                    B.best = 0x7fffffff, B.lx = (int16_t)((i & 1) * 32 + (k & 1) * 16 + (tid & 1) * 8), B.ly = (int16_t)((i >> 1) * 32 + (k >> 1) * 16 + (tid >> 1) * 8);
+                    B.mvx = (int16_t)(mvx_of(best_mv[21 + idx]) << 3), B.mvy = (int16_t)(mvy_of(best_mv[21 + idx]) << 3);
+                }
+                if constexpr (E8)
+                    search_blocks<S16, 8, 8>(L, s, 4, K_REGULAR);
+                if (tid < 4) {
+                    const int idx = i * 16 + k * 4 + tid;
+                    st.err8[idx] = L.blk[tid].best, st.mv8_x[idx] = (int16_t)L.blk[tid].mvx, st.mv8_y[idx] = (int16_t)L.blk[tid].mvy;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) {
+                    const int q = i * 4 + k;
+                    int       sub = (int)st.err16[q], e8 = 0;
+                    for (int e = 0; e < 4; e++) e8 += (int)st.err8[q * 4 + e];
+                    if (sub * 8 < e8 * 16) {
+                        st.split16[q] = 0;
+                    } else {
+                        st.split16[q] = 1, st.err16[q] = (uint64_t)e8, sub = e8;
+                    }
+                    sum += sub;
+                }
+                st.split32[i] = !((int)e32 * 14 < sum * 16);
+            }
             __syncthreads();  // L.blk[] is rewritten by the next 32x32 block
         }
     }
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
     if (tid == 0)
         st.err64 = err64, st.mv64_x = (int16_t)mv64x, st.mv64_y = (int16_t)mv64y, st.use_64x64 = use64;
     __syncthreads();
-    for (int i = tid; i < (int)(sizeof(st) / 4); i += 256) ((uint32_t *)&R.state[b])[i] = ((const uint32_t *)&st)[i];
+    for (int i = tid; i < (int)(sizeof(SvtHipTfB64State) / 4); i += 256) ((uint32_t *)&R.state[b])[i] = i < ST_BYTES / 4 ? ((const uint32_t *)&st)[i] : 0u;
     // ---- descriptors of the final predictions (sharp kernel, the filter's bit depth): 16 luma + 16 + 16 chroma slots
     if (tid < DESC_PER_B64) {
         const int plane = tid / 16, idx = tid % 16, q = idx >> 2, k = idx & 3;
@@ -482,7 +529,7 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
         if (st.use_64x64) {
             on = idx == 0, lx = ly = 0, bsz = 64, mx = st.mv64_x, my = st.mv64_y;
         } else if (st.split32[q]) {
-            on = true, lx = (q & 1) * 32 + (k & 1) * 16, ly = (q >> 1) * 32 + (k >> 1) * 16, bsz = 16, mx = st.mv16_x[idx], my = st.mv16_y[idx];
+            on = !(E8 && st.split16[idx]) /* else four 8x8 blocks: tf_predict8_kernel */, lx = (q & 1) * 32 + (k & 1) * 16, ly = (q >> 1) * 32 + (k >> 1) * 16, bsz = 16, mx = st.mv16_x[idx], my = st.mv16_y[idx];
         } else {
             on = k == 0, lx = (q & 1) * 32, ly = (q >> 1) * 32, bsz = 32, mx = st.mv32_x[q], my = st.mv32_y[q];
         }
@@ -546,6 +593,66 @@ __global__ __launch_bounds__(64) void tf_predict_small_kernel(const RefineRef *_
         const SvtHipConvolveDesc d = descs[__builtin_ctzll(todo)];
         __syncthreads();
         conv::convolve_tile_t<64, SMALL_T, SMALL_P>(d, 0, in, im);
+    }
+}
+
+// tf_32x32_inter_prediction for the 16x16 blocks that were split into 8x8 (temporal_filtering.c:2384-2445, enable_8x8_pred): 8x8 luma
+// with the sharp 8-tap kernels, 4x4 chroma with the 4-tap kernels of narrow blocks.  One workgroup per (reference picture, 64x64 block);
+// a wave per 8x8 block: lane = luma sample, lanes 0 .. 15 / 16 .. 31 also one Cb / Cr sample.  Each lane filters its eight rows itself
+// (2-D form with the unit kernel where an axis has no fraction: equal to the 1-D functions, see eval_item) — tf level 1 only.
+__device__ __forceinline__ int32_t predict_sample(const void *plane, uint32_t stride, int is16, int bd, int px, int py, int sx, int sy, int kernel) {
+    int32_t v = (1 << (bd + 11)) + 1024 - (((1 << bd) + (1 << (bd - 1))) << 11);
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        int32_t h = (1 << (bd + 6)) + 4;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const ptrdiff_t i = (ptrdiff_t)(py - 3 + t) * stride + px - 3 + u;
+            h += (int32_t)TF_KERNELS[kernel][sx][u] * (int32_t)(is16 ? ldg<true>(plane, i) : ldg<false>(plane, i));
+        }
+        v += (int32_t)TF_KERNELS[kernel][sy][t] * (int32_t)(int16_t)(h >> 3);
+    }
+    v >>= 11;
+    const int32_t hi = (1 << bd) - 1;
+    return v < 0 ? 0 : (v > hi ? hi : v);
+}
+__global__ __launch_bounds__(256) void tf_predict8_kernel(RefineArgs a, const RefineRef *__restrict__ refs) {
+    const RefineRef        &R = refs[blockIdx.y];
+    const uint32_t          b = blockIdx.x;
+    const SvtHipTfB64State &st = R.state[b];
+    if (st.use_64x64)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, e = tid >> 6, ox = (int)(b % a.bw) * 64, oy = (int)(b / a.bw) * 64, is16 = a.bit_depth > 8;
+    for (int q16 = 0; q16 < 16; q16++) {
+        if (!st.split32[q16 >> 2] || !st.split16[q16])
+            continue;
+        const int i = q16 >> 2, k = q16 & 3, idx = q16 * 4 + e;
+        const int lx = (i & 1) * 32 + (k & 1) * 16 + (e & 1) * 8, ly = (i >> 1) * 32 + (k >> 1) * 16 + (e >> 1) * 8, mx = st.mv8_x[idx], my = st.mv8_y[idx];
+        {
+            int col, row;
+            clamp_mv(a.mi_rows, a.mi_cols, 8, 8, mx, my, 0, ox + lx, oy + ly, 8, col, row);
+            const int   r = lane >> 3, cc = lane & 7;
+            const void *pl = is16 ? (const void *)R.pic.y16 : (const void *)R.pic.y8;
+            const int32_t v = predict_sample(pl, R.pic.stride, is16, a.bit_depth, ox + lx + (col >> 4) + cc, oy + ly + (row >> 4) + r, col & 15, row & 15, K_SHARP);
+            const size_t  o = ((size_t)b * 3) * 4096 + (size_t)(ly + r) * 64 + lx + cc;
+            if (is16)
+                ((uint16_t *)R.pred)[o] = (uint16_t)v;
+            else
+                R.pred[o] = (uint8_t)v;
+        }
+        if (a.chroma && lane < 32) {
+            const int plane = 1 + (lane >> 4), r = (lane >> 2) & 3, cc = lane & 3;
+            int       col, row;
+            clamp_mv(a.mi_rows, a.mi_cols, 4, 4, mx, my, 1, ox + lx, oy + ly, 8, col, row);
+            const int   pre_x = (((ox + lx) >> 3) << 3) / 2, pre_y = (((oy + ly) >> 3) << 3) / 2, dx = ((lx >> 3) << 3) / 2, dy = ((ly >> 3) << 3) / 2;
+            const void *pl = is16 ? (const void *)R.pic.c16[plane - 1] : (const void *)R.pic.c8[plane - 1];
+            const int32_t v = predict_sample(pl, R.pic.stride_c, is16, a.bit_depth, pre_x + (col >> 4) + cc, pre_y + (row >> 4) + r, col & 15, row & 15, K_REGULAR4);
+            const size_t  o = ((size_t)b * 3 + plane) * 4096 + (size_t)(dy + r) * 32 + dx + cc;
+            if (is16)
+                ((uint16_t *)R.pred)[o] = (uint16_t)v;
+            else
+                R.pred[o] = (uint8_t)v;
+        }
     }
 }
 
@@ -716,8 +823,8 @@ extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void
         return bad("n_refs must be 1 .. SVT_HIP_TF_MAX_REFS");
     if (job->bit_depth != 8 && job->bit_depth != 10)
         return bad("bit_depth must be 8 or 10");
-    if (job->ctrls.enable_8x8_pred)
-        return bad("8x8 prediction (enable_8x8_pred) is not provided");
+    if (job->ctrls.enable_8x8_pred > 1 || job->ctrls.low_delay > 1)
+        return bad("enable_8x8_pred / low_delay are 0 or 1");
     if (job->ctrls.sub_sampling_shift > 1 || job->ctrls.use_2tap > 1)
         return bad("sub_sampling_shift / use_2tap out of range");
     if (!f.buf || f.width < 64 || f.height < 64 || f.org_x < 68 || f.org_y < 68 || (f.org_x & 1) || (f.org_y & 1))
@@ -800,13 +907,22 @@ extern "C" int32_t svt_hip_tf_filter_picture(const SvtHipTfPictureJob *job, void
     if (low_delay) {
         hipLaunchKernelGGL(tf_low_delay_kernel, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs);
     } else {
-        if (s16)
-            hipLaunchKernelGGL(tf_refine_kernel<true>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
-        else
-            hipLaunchKernelGGL(tf_refine_kernel<false>, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs, job->tot_blks);
+        const dim3 grid(nb, job->n_refs);
+        if (job->ctrls.enable_8x8_pred) {
+            if (s16)
+                hipLaunchKernelGGL((tf_refine_kernel<true, true>), grid, dim3(256), 0, st, a, d_refs, job->tot_blks);
+            else
+                hipLaunchKernelGGL((tf_refine_kernel<false, true>), grid, dim3(256), 0, st, a, d_refs, job->tot_blks);
+        } else if (s16) {
+            hipLaunchKernelGGL((tf_refine_kernel<true, false>), grid, dim3(256), 0, st, a, d_refs, job->tot_blks);
+        } else {
+            hipLaunchKernelGGL((tf_refine_kernel<false, false>), grid, dim3(256), 0, st, a, d_refs, job->tot_blks);
+        }
         SVT_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(tf_predict_kernel, dim3(nb, job->n_refs), dim3(256), 0, st, d_refs);
         hipLaunchKernelGGL(tf_predict_small_kernel, dim3(nb * SMALL_SPLIT, job->n_refs), dim3(64), 0, st, d_refs);
+        if (job->ctrls.enable_8x8_pred)
+            hipLaunchKernelGGL(tf_predict8_kernel, dim3(nb, job->n_refs), dim3(256), 0, st, a, d_refs);
     }
     SVT_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(tf_blocks_kernel, dim3(nb, job->n_refs + 1), dim3(256), 0, st, a, d_refs, job->n_refs, static_blocks, outs);

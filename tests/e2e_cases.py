@@ -44,7 +44,12 @@ LD_CASES = {
     "p8_10bit_ld": (1280, 720, 6, 10, 8),
 }
 EXTRA_ARGS = {"p8_8bit_ld": ["--pred-struct", "1"], "p8_10bit_ld": ["--pred-struct", "1"]}
-ALL_CASES = dict(CASES, **TIER_B_CASES, **LF_CASES, **LD_CASES)
+# presets <= M2 run tf level 1: the temporal filter with 8x8 prediction (enable_8x8_pred)
+TF8_CASES = {
+    "p2_8bit_tf8": (192, 128, 8, 8, 2),
+    "p2_10bit_tf8": (192, 128, 6, 10, 2),
+}
+ALL_CASES = dict(CASES, **TIER_B_CASES, **LF_CASES, **LD_CASES, **TF8_CASES)
 
 
 def have_app():

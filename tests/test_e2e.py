@@ -173,6 +173,32 @@ def test_batched_paths_ragged_clip(hip, case, lp):
 
 
 @needs_app
+@pytest.mark.parametrize("case", list(E.TF8_CASES))
+def test_c_path_reproduces_golden_tf_8x8(case):
+    """CPU: the goldens of the preset-2 clips (tf level 1: the temporal filter predicts with 8x8 blocks)."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, _ = E.encode(case, d, "c", lp=4)
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}
+
+
+@needs_app
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,lp", [("p2_8bit_tf8", 4), ("p2_10bit_tf8", 3)])
+def test_batched_tf_8x8_bitstream_md5(hip, case, lp):
+    """GPU: preset 2 = tf level 1 = enable_8x8_pred: tf_8x8_sub_pel_search, the 16x16 -> 8x8 split decisions and the 8x8 luma / 4x4 chroma
+    predictions inside svt_hip_tf_filter_picture, with the batched picture analysis and ME.  Same bitstream."""
+    with tempfile.TemporaryDirectory() as d:
+        md5, log = E.encode(case, d, "hip", lp=lp, env_extra={"SVTAV1_HIP_TIERB_TF": "1", "SVTAV1_HIP_TIERB_ME": "1", "SVTAV1_HIP_TIERB_PA": "1",
+                                                               "SVTAV1_HIP_ONLY": "__none__"})
+    E.assert_hip_ran_clean(log)
+    m = re.search(r"svt_hip_bind_tf: (\d+) pictures", log)
+    assert m and int(m.group(1)) >= 1, "the batched temporal filter did not run:\n" + log[-2000:]
+    g = E.golden()[case]
+    assert md5 == {"ivf": g["ivf"], "recon": g["recon"]}, f"{case}: bitstream differs with the batched temporal filter (8x8 prediction)\n{log[-1500:]}"
+
+
+@needs_app
 @pytest.mark.parametrize("case", list(E.LD_CASES))
 def test_c_path_reproduces_golden_low_delay(case):
     """CPU: the low-delay goldens (`--pred-struct 1`, 720p: the smallest size at which the reference filters in that mode), and the

@@ -91,7 +91,7 @@ def test_argument_checks(hip, orc):
     wsb = hip.svt_hip_tf_workspace_bytes(w, h, n_refs)
     ws = device.DeviceBuffer(hip, wsb)
     job.workspace, job.workspace_bytes = ws.ptr, wsb
-    job.ctrls.enable_8x8_pred = 1
+    job.ctrls.enable_8x8_pred = 2   # a flag: 0 or 1
     assert hip.svt_hip_tf_filter_picture(C.byref(job), None) == abi.SVT_HIP_ERR_BAD_PARAMETER
     assert b"8x8" in hip.svt_hip_last_error()
     job.ctrls.enable_8x8_pred, job.n_refs = 0, 0

@@ -128,7 +128,7 @@ static int run_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc *
     SequenceControlSet      *scs    = centre->scs;
     EbPictureBufferDesc     *cpic   = pics[index_center];
     const TfControls        *tc     = &ctx->tf_ctrls;
-    if (tc->enable_8x8_pred || scs->subsampling_x != 1 || scs->subsampling_y != 1 || cpic->width < 64 || cpic->height < 64 || cpic->org_x < 68 ||
+    if ((tc->enable_8x8_pred && !centre->enable_me_8x8) /* tf_8x8_sub_pel_search starts from the ME's 8x8 vectors */ || scs->subsampling_x != 1 || scs->subsampling_y != 1 || cpic->width < 64 || cpic->height < 64 || cpic->org_x < 68 ||
         cpic->org_y < 68 || cpic->stride_cb * 2 != cpic->stride_y || (is_highbd && scs->static_config.encoder_bit_depth != 10))
         return 1;
     SvtHipTfPictureJob *job = (SvtHipTfPictureJob *)calloc(1, sizeof(*job));
@@ -178,6 +178,7 @@ static int run_picture(PictureParentControlSet **pcs_list, EbPictureBufferDesc *
     job->ctrls.use_8bit_subpel = tc->use_8bit_subpel, job->ctrls.use_zz_based_filter = tc->use_zz_based_filter;
     job->ctrls.pred_error_32x32_th = tc->pred_error_32x32_th;
     job->ctrls.low_delay           = (uint8_t)t_low_delay;
+    job->ctrls.enable_8x8_pred     = tc->enable_8x8_pred ? 1 : 0;
     for (int p = 0; p < 3; p++) job->decay_factor_fp16[p] = ctx->tf_decay_factor_fp16[p];
     job->mv_dist_th = ctx->tf_mv_dist_th, job->chroma = ctx->tf_chroma, job->bit_depth = is_highbd ? 10 : 8;
     job->mi_rows = (uint32_t)centre->av1_cm->mi_rows, job->mi_cols = (uint32_t)centre->av1_cm->mi_cols, job->n_refs = (uint32_t)n;
