@@ -119,16 +119,17 @@ def test_fence_publish_path(hip, orc):
             assert np.array_equal(got[k], v), (case[0], k)
 
 
-@pytest.mark.parametrize("level,fence", [(4, 0), (5, 0), (4, 1)])
+@pytest.mark.parametrize("level,fence", [(4, 0), (5, 0), (4, 1), (3, 0)])
 def test_stale_line_pattern_4k(hip, orc, level, fence):
     """The hand-over the write-through publication has to get right: block columns ALTERNATE between inter blocks (static
     stripes: they start at once and read nothing of their neighbours) and intra blocks (fresh noise per picture: they wait for the
     left / top / top-left neighbours and read their reconstructed border samples).  An inter block to the right of an intra block
     shares 128-byte row lines with it and is reconstructed long before it, so the line is in some XCD's L2 in its old state when the
     intra block next to it -- on another XCD -- publishes; the intra block one further right must still see the published samples.
-    3840x2160, tpl level 4 (16x16 blocks, 16-sample stripes) and level 5 (32x32 blocks, 32-sample stripes), both publication modes."""
-    bs = 16 if level == 4 else 32
-    opt = dict(T.BASE, publish_fence=fence, **(T.L5 if level == 5 else {}))
+    3840x2160, tpl level 4 (16x16 blocks, 16-sample stripes), level 3 (the same with the quarter-pel refinement) and level 5 (32x32 blocks,
+    32-sample stripes), both publication modes."""
+    bs = 32 if level == 5 else 16
+    opt = dict(T.BASE, publish_fence=fence, **(T.L5 if level == 5 else (T.L3 if level == 3 else {})))
     if level == 5:
         opt["synth_blk_size"] = 32
     case = (f"stripes{bs}_4k", f"stripes{bs}", 3840, 2160, 120, opt)
@@ -138,7 +139,8 @@ def test_stale_line_pattern_4k(hip, orc, level, fence):
     modes = b.src_stats["best_mode"].reshape(-1, 3840 // 16)[::step, ::step]
     cols = np.arange(3840 // bs) & 1
     # the pattern is what the test is about: noisy columns intra (DC_PRED = 0), static columns inter (NEWMV = 16)
-    assert (modes[:, cols == 1] == 0).mean() > 0.95 and (modes[:, cols == 0] == 16).mean() > 0.95
+    # (with the quarter-pel refinement of level 3 a seventh of the noisy blocks find a smoothed inter prediction cheaper than DC)
+    assert (modes[:, cols == 1] == 0).mean() > (0.8 if level == 3 else 0.95) and (modes[:, cols == 0] == 16).mean() > 0.95
     got = run_gpu(hip, a)
     for k, v in b.results().items():
         assert np.array_equal(got[k], v), (case[0], k, int((got[k] != v).sum()))
@@ -151,3 +153,9 @@ def test_argument_checks(hip, orc):
     assert hip.svt_hip_tpl_dispenser_frame(C.byref(job), None) == abi.SVT_HIP_ERR_BAD_PARAMETER  # no workspace
     assert b"workspace" in hip.svt_hip_last_error()
     assert hip.svt_hip_tpl_dispenser_frame(None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER
+    hip.svt_hip_tpl_workspace_bytes.restype = C.c_uint64
+    wsb = hip.svt_hip_tpl_workspace_bytes(s.case[2], s.case[3])
+    ws = device.DeviceBuffer(hip, wsb)
+    job.workspace, job.workspace_bytes, job.quarter_pel, job.blk_size, job.subsample_tx = ws.ptr, wsb, 1, 32, 2
+    assert hip.svt_hip_tpl_dispenser_frame(C.byref(job), None) == abi.SVT_HIP_ERR_BAD_PARAMETER  # quarter-pel comes with 16x16 blocks only
+    assert b"quarter_pel" in hip.svt_hip_last_error()
