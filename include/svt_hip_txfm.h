@@ -116,6 +116,11 @@ SVT_HIP_API uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint
 SVT_HIP_API uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride,
                                                            uint8_t *pred, int32_t pred_offset, uint32_t pred_stride,
                                                            uint32_t area_width, uint32_t area_height);
+/* Tier B form of the two distortion leaves: the sum of squared differences of two DEVICE planes (strides in samples) into *d_out (device,
+ * zeroed by the call).  Caller: picture_sse_calculations (deblocking_filter.c:716-834) after every trial of the deblocking level search
+ * (try_filter_frame :842-882) — the filtered trial picture then never leaves the device, 8 bytes come back. */
+SVT_HIP_API int32_t svt_hip_plane_sse(const void *d_a, uint32_t a_stride, const void *d_b, uint32_t b_stride, uint32_t width, uint32_t height, int32_t is_16bit,
+                                      uint64_t *d_out, void *stream);
 SVT_HIP_API void svt_aom_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr,
                                             ptrdiff_t src_stride, const uint8_t *pred_ptr, ptrdiff_t pred_stride);
 SVT_HIP_API void svt_aom_highbd_subtract_block_hip(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride,

@@ -185,6 +185,30 @@ extern "C" void svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_str
 static void svt_residual_kernel16bit_hip_impl(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height) {
     subtract_tier_a<uint16_t>((int)area_height, (int)area_width, residual, residual_stride, input, input_stride, pred, pred_stride);
 }
+// Tier B: the same sum over two DEVICE planes (what picture_sse_calculations, deblocking_filter.c:716-834, asks of the two leaves after
+// every trial of the deblocking level search): *d_out (device, 8 bytes) is zeroed by the call and holds the sum when the stream has run
+extern "C" int32_t svt_hip_plane_sse(const void *d_a, uint32_t a_stride, const void *d_b, uint32_t b_stride, uint32_t width, uint32_t height, int32_t is_16bit,
+                                     uint64_t *d_out, void *stream) {
+    if (!d_a || !d_b || !d_out || !width || !height) {
+        set_error("svt_hip_plane_sse: bad argument");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    if (!ensure_init())
+        return SVT_HIP_ERR_NO_DEVICE;
+    hipStream_t st = resolve_stream(stream);
+    SVT_HIP_CHECK(hipMemsetAsync(d_out, 0, 8, st));
+    const size_t pix = (size_t)width * height;
+    const int    blocks = (int)((pix + 255) / 256 < 1024 ? (pix + 255) / 256 : 1024);
+    if (is_16bit)
+        hipLaunchKernelGGL((spatial_sse_kernel<uint16_t>), dim3(blocks), dim3(256), 0, st, (const uint16_t *)d_a, (int)a_stride, (const uint16_t *)d_b, (int)b_stride, (int)width,
+                           (int)height, (unsigned long long *)d_out);
+    else
+        hipLaunchKernelGGL((spatial_sse_kernel<uint8_t>), dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_a, (int)a_stride, (const uint8_t *)d_b, (int)b_stride, (int)width,
+                           (int)height, (unsigned long long *)d_out);
+    SVT_HIP_CHECK(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
 // svt_spatial_full_distortion_kernel (common_dsp_rtcd.h:171; picture_operators_c.c:62-78) and svt_full_distortion_kernel16_bits
 // (common_dsp_rtcd.h:173; pic_operators.c:174-196: byte pointers reinterpreted as 16-bit samples, offsets in samples)
 static uint64_t svt_spatial_full_distortion_kernel_hip_impl(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset, uint32_t recon_stride, uint32_t area_width, uint32_t area_height);

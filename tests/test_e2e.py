@@ -256,6 +256,11 @@ def test_batched_in_loop_filters_bitstream_md5(hip, case, lp, wiener):
     assert dlf >= 1 and cdef_s >= 1, (case, m.groups())
     if wiener:
         assert wn >= 1 and lr >= 1, (case, m.groups())
+    if case in ("p5_8bit_lf", "p3_8bit_lf", "p6_10bit_lf"):
+        # presets <= M5 (and base pictures at M6) search the deblocking level: every trial is filtered AND measured on the device
+        # (svt_hip_bind_dlf_try: svt_hip_loop_filter_frame on a scratch copy + svt_hip_plane_sse against the source mirror)
+        t = re.search(r"(\d+) trials of the deblocking level search filtered and measured on the device", log)
+        assert t and int(t.group(1)) >= 3, (case, log[-1500:])
     m = re.search(r"svt_hip_bind_pa: (\d+) pyramids, (\d+) variance maps", log)
     w, h, n, bd, preset = E.ALL_CASES[case]
     # every picture once from the picture-analysis kernel, temporally filtered pictures again when they are re-decimated

@@ -142,3 +142,21 @@ def test_tier_b_source_minus_prediction_to_recon(hip, orc, bd):
         assert int(res[i, 8:10].view(np.uint16)[0]) == eob and int(res[i, 12:16].view(np.uint32)[0]) == satd, ("eob/satd", i)
         got = g(d.recon_off, h * (w + 4), dt).reshape(h, w + 4)
         assert np.array_equal(got[:, :w], rec[:, :w].astype(dt)), ("recon", i)
+
+
+def test_plane_sse_device_planes(hip):
+    """svt_hip_plane_sse (Tier B form of svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits: two DEVICE planes, the sum
+    into device memory) against numpy; what picture_sse_calculations asks for after a trial of the deblocking level search."""
+    rng = np.random.default_rng(17)
+    for dt, is16, hi in ((np.uint8, 0, 256), (np.uint16, 1, 1024)):
+        for (w, h, sa, sb) in ((64, 48, 80, 72), (1, 1, 8, 8), (1923, 1081, 2048, 1984), (200, 3, 208, 256)):
+            a = rng.integers(0, hi, size=(h, sa), dtype=dt)
+            b = rng.integers(0, hi, size=(h, sb), dtype=dt)
+            da, db, dout = device.DeviceBuffer(hip, a.nbytes), device.DeviceBuffer(hip, b.nbytes), device.DeviceBuffer(hip, 8)
+            da.upload(a), db.upload(b), dout.fill(0xAB)
+            device.check(hip, hip.svt_hip_plane_sse(C.c_void_p(da.ptr), sa, C.c_void_p(db.ptr), sb, w, h, is16, C.c_void_p(dout.ptr), None), "svt_hip_plane_sse")
+            device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+            got = int(dout.download(np.uint64, (1,))[0])
+            want = int(((a[:, :w].astype(np.int64) - b[:, :w].astype(np.int64)) ** 2).sum())
+            assert got == want, (dt, w, h)
+    assert hip.svt_hip_plane_sse(None, 8, None, 8, 4, 4, 0, None, None) == abi.SVT_HIP_ERR_BAD_PARAMETER

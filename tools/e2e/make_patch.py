@@ -78,8 +78,8 @@ def patch_src_ops_process(t):
 
 
 def patch_deblocking_filter(t):
-    """Step 4a: the whole-picture deblocking in front of the SB loop of svt_av1_loop_filter_frame (also reached by every trial of
-    the level search through try_filter_frame)."""
+    """Step 4a: the whole-picture deblocking in front of the SB loop of svt_av1_loop_filter_frame, and the device-side trial of the
+    level search in try_filter_frame (a trial the glue declines still reaches the first hook through the reference's own sequence)."""
     t = edit(t, '#include "deblocking_filter.h"\n', '#include "deblocking_filter.h"\n#include "svt_hip_bind.h"\n')
     old = ("    uint32_t picture_height_in_sb = (pcs->ppcs->aligned_height + scs->sb_size - 1) / scs->sb_size;\n\n"
            "    svt_av1_loop_filter_frame_init(&pcs->ppcs->frm_hdr, &pcs->ppcs->lf_info, plane_start, plane_end);\n")
@@ -87,6 +87,12 @@ def patch_deblocking_filter(t):
            "    if (svt_hip_bind_dlf_frame(frame_buffer, pcs, plane_start, plane_end) == 0)\n"
            "        return;\n"
            "    svt_av1_loop_filter_frame_init(&pcs->ppcs->frm_hdr, &pcs->ppcs->lf_info, plane_start, plane_end);\n")
+    t = edit(t, old, new)
+    # a trial of the level search (try_filter_frame): filter + picture_sse_calculations on the device, nothing to restore
+    old = ("    svt_av1_loop_filter_frame(recon_buffer, pcs, plane, plane + 1);\n\n"
+           "    filt_err = picture_sse_calculations(pcs, recon_buffer, plane);\n")
+    new = ("    if (svt_hip_bind_dlf_try(recon_buffer, pcs, plane, &filt_err) == 0)\n"
+           "        return filt_err;\n" + old)
     return edit(t, old, new)
 
 

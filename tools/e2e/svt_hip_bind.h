@@ -62,6 +62,8 @@ struct Yv12BufferConfig;
 struct RestorationTileLimits;
 int  svt_hip_bind_dlf_deferred(void);
 int  svt_hip_bind_dlf_frame(struct EbPictureBufferDesc *frame_buffer, struct PictureControlSet *pcs, int32_t plane_start, int32_t plane_end);
+/* one trial of the level search (try_filter_frame): filter + picture_sse_calculations on the device; 0 = *filt_err is set */
+int  svt_hip_bind_dlf_try(struct EbPictureBufferDesc *frame_buffer, struct PictureControlSet *pcs, int32_t plane, int64_t *filt_err);
 int  svt_hip_bind_cdef_seg(struct PictureControlSet *pcs, struct SequenceControlSet *scs, uint32_t segment_index);
 int  svt_hip_bind_cdef_frame(struct SequenceControlSet *scs, struct PictureControlSet *pcs);
 int  svt_hip_bind_wiener_stats(struct PictureControlSet *pcs, int plane, int rest_unit_idx, int wiener_win, const uint8_t *dgd, const uint8_t *src,

@@ -55,15 +55,16 @@ static int32_t (*p_cdef_apply)(const SvtHipCdefPlane *, uint32_t, const uint8_t 
 static int32_t (*p_wiener_stats)(const SvtHipWienerUnit *, uint32_t, int32_t, int32_t, int32_t, int64_t *, int64_t *, void *);
 static int32_t (*p_lr_frame)(const SvtHipLrPlane *, uint32_t, void *);
 static int32_t (*p_copy)(void *, const void *, size_t, void *);
+static int32_t (*p_plane_sse)(const void *, uint32_t, const void *, uint32_t, uint32_t, uint32_t, int32_t, uint64_t *, void *);
 static int32_t (*p_download_2d)(void *, size_t, const void *, size_t, size_t, size_t, void *);
 static int g_dlf, g_cdef, g_lr;
-static unsigned long g_n_dlf, g_n_cdef_search, g_n_cdef_apply, g_n_wiener, g_n_lr;
+static unsigned long g_n_dlf, g_n_dlf_trials, g_n_cdef_search, g_n_cdef_apply, g_n_wiener, g_n_lr;
 
 static void report(void) {
     fprintf(stderr,
             "svt_hip_bind_lf: %lu frame deblocking calls, %lu CDEF searches, %lu CDEF applications, %lu Wiener statistics planes, %lu restoration "
-            "frames on the GPU\n",
-            g_n_dlf, g_n_cdef_search, g_n_cdef_apply, g_n_wiener, g_n_lr);
+            "frames on the GPU; %lu trials of the deblocking level search filtered and measured on the device\n",
+            g_n_dlf, g_n_cdef_search, g_n_cdef_apply, g_n_wiener, g_n_lr, g_n_dlf_trials);
 }
 
 void svt_hip_bind_lf_setup(void *(*sym)(const char *)) {
@@ -75,6 +76,7 @@ void svt_hip_bind_lf_setup(void *(*sym)(const char *)) {
     p_wiener_stats = (int32_t(*)(const SvtHipWienerUnit *, uint32_t, int32_t, int32_t, int32_t, int64_t *, int64_t *, void *))sym("svt_hip_wiener_stats");
     p_lr_frame     = (int32_t(*)(const SvtHipLrPlane *, uint32_t, void *))sym("svt_hip_restoration_filter_frame");
     p_copy         = (int32_t(*)(void *, const void *, size_t, void *))sym("svt_hip_copy");
+    p_plane_sse    = (int32_t(*)(const void *, uint32_t, const void *, uint32_t, uint32_t, uint32_t, int32_t, uint64_t *, void *))sym("svt_hip_plane_sse");
     p_download_2d  = (int32_t(*)(void *, size_t, const void *, size_t, size_t, size_t, void *))sym("svt_hip_download_2d");
     const int base = g_hd.ok && p_copy && p_download_2d;
     g_dlf          = base && hd_env_on("SVTAV1_HIP_TIERB_DLF") && p_lf_frame;
@@ -173,16 +175,28 @@ static const SvtHipLfMi *gather_mi(PictureControlSet *pcs, size_t *bytes) {
     return mi;
 }
 
-static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end);
+static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end, int64_t *trial_sse);
 int svt_hip_bind_dlf_frame(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
     if (!g_dlf)
         return 1;
     const uint64_t t0 = hd_now_ns();
-    const int      rc = dlf_frame_impl(frame_buffer, pcs, plane_start, plane_end);
+    const int      rc = dlf_frame_impl(frame_buffer, pcs, plane_start, plane_end, NULL);
     hd_timer_add("dlf_frame", hd_now_ns() - t0);
     return rc;
 }
-static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
+/* One trial of the deblocking level search (try_filter_frame, deblocking_filter.c:842-882) entirely on the device: the plane is filtered in a
+ * scratch copy of the mirror of the un-filtered reconstruction and compared with the source picture's mirror there (picture_sse_calculations,
+ * :716-834); 8 bytes come back instead of the filtered plane, and the encoder's buffer is never touched (the reference filters it, measures
+ * and restores it).  Returns 0 with *filt_err set, 1 when the caller must run the reference's sequence. */
+int svt_hip_bind_dlf_try(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane, int64_t *filt_err) {
+    if (!g_dlf || !p_plane_sse || plane < 0 || plane > 2)
+        return 1;
+    const uint64_t t0 = hd_now_ns();
+    const int      rc = dlf_frame_impl(frame_buffer, pcs, plane, plane + 1, filt_err);
+    hd_timer_add("dlf_trial", hd_now_ns() - t0);
+    return rc;
+}
+static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end, int64_t *trial_sse) {
     if (!g_dlf || !covered(pcs) || pcs->ppcs->frm_hdr.delta_lf_params.delta_lf_present || plane_start < 0 || plane_end > 3 || plane_start >= plane_end)
         return 1;
     SequenceControlSet      *scs  = pcs->scs;
@@ -235,6 +249,30 @@ static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *
         rc = p_lf_frame(&f, NULL);
     }
     uint8_t *h_out[3] = {NULL, NULL, NULL};
+    if (trial_sse) {
+        /* picture_sse_calculations: against the source picture over the aligned size (8 bit) / the picture size (16 bit) */
+        const int            p     = plane_start, ss = p ? 1 : 0;
+        EbPictureBufferDesc *input = is16 ? pcs->input_frame16bit : ppcs->enhanced_pic;
+        PlaneRef             sp[3];
+        picture_planes(input, is16, sp);
+        const uint32_t w = is16 ? (uint32_t)(input->width + ss) >> ss : (uint32_t)ppcs->aligned_width >> ss;
+        const uint32_t h = is16 ? (uint32_t)(input->height + ss) >> ss : (uint32_t)ppcs->aligned_height >> ss;
+        uint8_t       *d_src = rc == 0 ? hd_mirror_get(sp[p].host, sp[p].bytes, HD_TAG(pcs->picture_number, is16 ? HD_ST_SOURCE16 : HD_ST_FILTERED)) : NULL;
+        uint8_t       *d_sum = rc == 0 ? hd_alloc(256) : NULL;
+        uint64_t       sum   = 0;
+        if (rc == 0 && (!d_src || !d_sum))
+            rc = -1;
+        if (rc == 0)
+            rc = p_plane_sse(d_src + sp[p].origin, sp[p].stride, d_work[p] + pl[p].origin, pl[p].stride, w, h, is16, (uint64_t *)d_sum, NULL);
+        if (rc == 0)
+            rc = hd_download(&sum, d_sum, 8);
+        rc |= hd_sync();
+        if (d_src)
+            hd_mirror_unpin(sp[p].host);
+        hd_free(d_sum);
+        if (rc == 0)
+            *trial_sse = (int64_t)sum;
+    } else {
     for (int p = plane_start; rc == 0 && p < plane_end; p++) {
         h_out[p] = (uint8_t *)hd_host_alloc(pl[p].bytes);
         rc       = h_out[p] ? hd_download(h_out[p], d_work[p], pl[p].bytes) : -1;
@@ -242,6 +280,7 @@ static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *
     rc |= hd_sync();
     if (rc == 0)
         for (int p = plane_start; p < plane_end; p++) memcpy(pl[p].host, h_out[p], pl[p].bytes);
+    }
     if (mi_pinned)
         hd_mirror_unpin(h_mi);
     for (int p = 0; p < 3; p++) hd_free(d_work[p]), hd_host_free(h_out[p]);
@@ -249,7 +288,7 @@ static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *
         fprintf(stderr, "svt_hip_bind_lf: deblocking of picture %llu stays on the CPU (%s)\n", (unsigned long long)pcs->picture_number, hd_error());
         return 1;
     }
-    __atomic_add_fetch(&g_n_dlf, 1, __ATOMIC_RELAXED);
+    __atomic_add_fetch(trial_sse ? &g_n_dlf_trials : &g_n_dlf, 1, __ATOMIC_RELAXED);
     return 0;
 }
 
