@@ -280,6 +280,17 @@ static int dlf_frame_impl(EbPictureBufferDesc *frame_buffer, PictureControlSet *
     rc |= hd_sync();
     if (rc == 0)
         for (int p = plane_start; p < plane_end; p++) memcpy(pl[p].host, h_out[p], pl[p].bytes);
+    /* the picture's final deblocking (all planes; a trial filters one): the filtered planes become the mirrors of the host planes they were
+     * just downloaded into, so that the CDEF search finds its input resident instead of uploading it again */
+    if (rc == 0 && plane_start == 0 && plane_end == 3)
+        for (int p = 0; p < 3; p++) {
+            uint8_t *d_new = hd_mirror_new(pl[p].host, pl[p].bytes, HD_TAG(pcs->picture_number, HD_ST_DEBLOCKED));
+            if (!d_new)
+                continue;
+            if (p_copy(d_new, d_work[p], pl[p].bytes, NULL) != 0 || hd_sync() != 0)
+                hd_mirror_drop(pl[p].host);
+            hd_mirror_unpin(pl[p].host);
+        }
     }
     if (mi_pinned)
         hd_mirror_unpin(h_mi);
