@@ -124,3 +124,22 @@ def test_filter_picture_4k(hip, orc):
     got, _, _ = run_gpu(hip, same, case, decay)
     for k, v in before.items():
         assert np.array_equal(got[k], v), k
+
+
+@pytest.mark.parametrize("case", [
+    ("blocks_8x8_4k", "blocks", 3840, 2160, 1, 8, "m8_4k_tl2", dict(tpc.LVL1, enable_8x8_pred=1)),
+    ("fastpan_ld_4k_10bit", "fastpan", 3840, 2160, 2, 10, "m8_4k_tl2", dict(tpc.LVL8, low_delay=1, chroma=1)),
+], ids=lambda c: c[0])
+def test_filter_picture_variants_4k(hip, orc, case):
+    """BASELINE size for the variants added in round 3: tf level 1 with 8x8 prediction (tens of thousands of 16x16 blocks split into 8x8) and
+    the low-delay filter on a 10-bit picture with two neighbours — GPU == oracle on every plane and every refinement state."""
+    decay = (2247286, 6156426, 6156426)
+    got, states, tot = run_gpu(hip, tpc.case_window(orc, case), case, decay)
+    pics = tpc.case_window(orc, case)
+    ostates, otot = tpc.run_oracle(orc, pics, case, decay)
+    assert tot == otot
+    assert np.array_equal(tpc.states_to_array(ostates), states)
+    if case[7].get("enable_8x8_pred"):
+        assert sum(sum(s.split16) for s in ostates) > 1000     # the 8x8 path is what this case is about
+    for k, v in pics[0].arrays().items():
+        assert np.array_equal(got[k], v), (k, int((got[k] != v).sum()))
