@@ -12,6 +12,7 @@
 // see "the sub-pel searches" below.
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/svt_hip_inter.h"
 #include "../../include/svt_hip_tf.h"
@@ -104,10 +105,16 @@ struct Item {  // one candidate position of a round
     int16_t mvx, mvy;
     uint8_t sx, sy, blk, on;
 };
-struct Lds {
-    uint16_t src[64 * 64];
-    alignas(4) uint16_t win[WIN_ELEMS];
+// S16 = false (8-bit searches): the windows and the source block are BYTES, the window stored as sample - 128 so that the horizontal
+// filter is two v_dot4_i32_i8 over eight samples (the taps fit an int8 except the unit tap 128 of phase 0: its row is stored as zeros
+// and an integer-phase lane adds 128 * sample itself); half the LDS of the 16-bit layout: a sixth workgroup per CU.
+template <bool S16>
+struct LdsT {
+    typedef typename std::conditional<S16, uint16_t, uint8_t>::type Pix;
+    alignas(4) Pix src[64 * 64];
+    alignas(4) Pix win[WIN_ELEMS];
     alignas(16) int16_t taps[2][16][8];  // regular, bilinear
+    alignas(8) int8_t   taps8[2][16][8]; // the same as int8, phase 0 zeroed (S16 = false)
     Item     item[MAX_ITEMS];
     uint64_t dist[MAX_ITEMS];
     Blk      blk[4];
@@ -159,6 +166,16 @@ __device__ __forceinline__ void lds_pairs(const uint16_t *win, int e, uint32_t s
 #pragma unroll
     for (int k = 0; k < NT / 2; k++) v[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
 }
+// 8-bit layout: sum of f[k] * x[k] over the eight samples from byte index e on (x stored as x - 128), + init.  f8 = the phase's int8 taps
+// (zeros for phase 0), k_unit = 128 on lanes whose phase is 0 (the unit tap multiplies the centre sample, byte 3), else 0.
+__device__ __forceinline__ int32_t hsum8_bytes(const uint8_t *win, int e, uint32_t shb, uint2 f8, int32_t k_unit, int32_t init) {
+    const uint32_t *q  = (const uint32_t *)win + (e >> 2);
+    const uint32_t  d0 = q[0], d1 = q[1], d2 = q[2];
+    const uint32_t  lo = __builtin_amdgcn_alignbyte(d1, d0, shb), hi = __builtin_amdgcn_alignbyte(d2, d1, shb);
+    int32_t acc = __builtin_amdgcn_sdot4((int)lo, (int)f8.x, init + 16384, false);  // sum f = 128: + 128 * 128 undoes the - 128 of the samples
+    acc         = __builtin_amdgcn_sdot4((int)hi, (int)f8.y, acc, false);
+    return acc + k_unit * (int32_t)__builtin_amdgcn_sbfe((int)lo, 24, 8);
+}
 // the NT non-zero taps of a phase as packed pairs in tap order (bilinear: taps 3 and 4 straddle two dwords of the 8-tap row)
 template <int NT>
 __device__ __forceinline__ void tap_pairs(const int16_t *row8, uint32_t (&f)[NT / 2]) {
@@ -182,7 +199,7 @@ struct Geo {
 
 // evaluate the item of this lane's group (valid == false: an idle group); returns the distortion on every lane of the group
 template <bool S16, int W, int NT>
-__device__ uint64_t eval_item(const Lds &L, const Item &it, bool valid, int kidx, int bd, bool centre, int sss) {
+__device__ uint64_t eval_item(const LdsT<S16> &L, const Item &it, bool valid, int kidx, int bd, bool centre, int sss) {
     constexpr int WD = Geo<W>::WD, LB = Geo<W>::LB, K0 = (8 - NT) / 2;
     const int     lane = threadIdx.x & 63, c = lane & (W - 1);
     const int     vshift = sss, rstep = centre ? 1 << sss : 1, n_out = W >> vshift, hi = (1 << bd) - 1;
@@ -196,21 +213,35 @@ __device__ uint64_t eval_item(const Lds &L, const Item &it, bool valid, int kidx
     int32_t  sum = 0;
     uint32_t sse = 0;
     const uint32_t psh = ((win0 - 3 + K0) & 1) * 16;  // the pitch is even: the parity of a lane's first sample is the same in every row
+    // 8-bit layout: the eight bytes from sample x - 3 on; the pitch is a multiple of 4, so the byte phase is the same in every row
+    const uint32_t shb = (uint32_t)(win0 - 3) & 3u;
+    uint2          f8  = {0u, 0u};
+    int32_t        k_unit = 0;
+    if (!S16) {
+        __builtin_memcpy(&f8, L.taps8[kidx][it.sx], 8);
+        k_unit = it.sx ? 0 : 128;
+    }
+    auto raw = [&](int idx) -> int32_t { return S16 ? (int32_t)L.win[idx] : (int32_t)(L.win[idx] ^ 0x80); };
     if (!has_v) {
         // rows o = i << vshift straight from the window: copy or horizontal filter
         int wo = win0 - 3 + K0, so = src0;
         for (int i = 0; i < n_out; i++, wo += WD << vshift, so += 64 << vshift) {
             int32_t p;
             if (has_h) {
-                uint32_t x[NT / 2];
-                lds_pairs<NT>(L.win, wo, psh, x);
-                int32_t acc = 4;
+                int32_t acc;
+                if constexpr (S16) {
+                    uint32_t x[NT / 2];
+                    lds_pairs<NT>((const uint16_t *)L.win, wo, psh, x);
+                    acc = 4;
 #pragma unroll
-                for (int k = 0; k < NT / 2; k++) acc = dot2(x[k], fx[k], acc);
+                    for (int k = 0; k < NT / 2; k++) acc = dot2(x[k], fx[k], acc);
+                } else {
+                    acc = hsum8_bytes((const uint8_t *)L.win, wo - K0, shb, f8, k_unit, 4);
+                }
                 p = ((acc >> 3) + 8) >> 4;
                 p = p < 0 ? 0 : (p > hi ? hi : p);
             } else {
-                p = L.win[wo + 3 - K0];
+                p = raw(wo + 3 - K0);
             }
             const int32_t d = p - (int32_t)L.src[so];
             sum += d, sse += (uint32_t)(d * d);
@@ -231,14 +262,19 @@ __device__ uint64_t eval_item(const Lds &L, const Item &it, bool valid, int kidx
                 if (j < n) {
                     uint32_t h;
                     if (has_h) {
-                        uint32_t x[NT / 2];
-                        lds_pairs<NT>(L.win, wo, psh, x);
-                        int32_t acc = c0;
+                        int32_t acc;
+                        if constexpr (S16) {
+                            uint32_t x[NT / 2];
+                            lds_pairs<NT>((const uint16_t *)L.win, wo, psh, x);
+                            acc = c0;
 #pragma unroll
-                        for (int k = 0; k < NT / 2; k++) acc = dot2(x[k], fx[k], acc);
+                            for (int k = 0; k < NT / 2; k++) acc = dot2(x[k], fx[k], acc);
+                        } else {
+                            acc = hsum8_bytes((const uint8_t *)L.win, wo - K0, shb, f8, k_unit, c0);
+                        }
                         h = (uint32_t)(acc >> 3);
                     } else {
-                        h = L.win[wo + 3 - K0];
+                        h = (uint32_t)raw(wo + 3 - K0);
                     }
                     ring[u] = (h << 16) | prev, prev = h;
                     if (j >= NT - 1 && ((j - (NT - 1)) & emit_mask) == 0) {
@@ -284,7 +320,7 @@ __device__ uint64_t eval_item(const Lds &L, const Item &it, bool valid, int kidx
 // tf_subpel_search of the nblk (1 or 4) square blocks of width W described by L.blk[]: in  .best / .mvx / .mvy / .lx / .ly,
 // out .best / .mvx / .mvy.  Called by the whole workgroup; the results are visible to every lane on return.
 template <bool S16, int W, int NT>
-__device__ void search_blocks(Lds &L, const SearchCtx &s, int nblk, int kernel) {
+__device__ void search_blocks(LdsT<S16> &L, const SearchCtx &s, int nblk, int kernel) {
     constexpr int WD = Geo<W>::WD, WDP = Geo<W>::WDP, G = Geo<W>::G;
     const SvtHipTfCtrls &c = s.a->ctrls;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lbn = nblk == 4 ? 2 : 0;
@@ -306,7 +342,8 @@ __device__ void search_blocks(Lds &L, const SearchCtx &s, int nblk, int kernel) 
                 const Blk &B = L.blk[b];
                 int32_t idx = (s.oy + B.wy + r) * (int32_t)s.ref_stride + s.ox + B.wx + cc;
                 idx         = idx < lo ? lo : (idx > hi ? hi : idx);
-                L.win[b * (WD * WD) + r * WD + cc] = (uint16_t)ldg<S16>(s.ref0, (ptrdiff_t)idx);
+                const uint32_t v = ldg<S16>(s.ref0, (ptrdiff_t)idx);
+                L.win[b * (WD * WD) + r * WD + cc] = (typename LdsT<S16>::Pix)(S16 ? v : (v ^ 0x80u));
             }
         }
     }
@@ -391,7 +428,7 @@ __device__ void fill_block(const RefineArgs &a, uint32_t b, int q, const uint8_t
 // E8: with the 8x8 stage of tf level 1 (its own instance: the extra search keeps 26 more registers live across the whole kernel)
 template <bool S16, bool E8>
 __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const RefineRef *__restrict__ refs, uint32_t *__restrict__ tot) {
-    __shared__ Lds              L;
+    __shared__ LdsT<S16>        L;
     // the block's state record; without the 8x8 stage only the part in front of err8 lives in LDS (the whole record cost 0.12 ms per picture)
     constexpr int ST_BYTES = E8 ? (int)sizeof(SvtHipTfB64State) : (int)offsetof(SvtHipTfB64State, err8);
     static_assert(ST_BYTES % 8 == 0, "state record prefix");
@@ -405,9 +442,10 @@ __global__ __launch_bounds__(256) void tf_refine_kernel(RefineArgs a, const Refi
     s.a = &a, s.ox = ox, s.oy = oy, s.is16 = S16, s.bd = S16 ? a.bit_depth : 8;
     s.ref0 = S16 ? (const void *)R.pic.y16 : (const void *)R.pic.y8, s.ref_stride = R.pic.stride;
     const void *src0 = S16 ? (const void *)a.centre.y16 : (const void *)a.centre.y8;
-    for (int i = tid; i < 64 * 64; i += 256) L.src[i] = (uint16_t)ldg<S16>(src0, (ptrdiff_t)(oy + (i >> 6)) * a.centre.stride + ox + (i & 63));
+    for (int i = tid; i < 64 * 64; i += 256) L.src[i] = (typename LdsT<S16>::Pix)ldg<S16>(src0, (ptrdiff_t)(oy + (i >> 6)) * a.centre.stride + ox + (i & 63));
     for (int i = tid; i < ST_BYTES / 4; i += 256) ((uint32_t *)&st)[i] = 0;
     L.taps[tid >> 7][(tid >> 3) & 15][tid & 7] = TF_KERNELS[(tid >> 7) ? K_BILINEAR : K_REGULAR][(tid >> 3) & 15][tid & 7];
+    L.taps8[tid >> 7][(tid >> 3) & 15][tid & 7] = ((tid >> 3) & 15) ? (int8_t)TF_KERNELS[(tid >> 7) ? K_BILINEAR : K_REGULAR][(tid >> 3) & 15][tid & 7] : (int8_t)0;
     const SvtHipMeSearchResult sr = R.sr[(size_t)b * 8];
     const uint32_t *best_mv = R.best_mv + (size_t)b * 8 * 85, *best_sad = R.best_sad + (size_t)b * 8 * 85;
     if (tid == 0 && tot)
