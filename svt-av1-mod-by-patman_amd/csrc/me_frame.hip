@@ -69,8 +69,8 @@ struct B64State {
     int32_t  staged, restage;
     uint32_t zero_sad, hme_mv_sad;
     // integer search set-up of every reference, prepared in one pass (lane = reference) when it does not depend on the search results of
-    // another reference (fullpel_prepare_all): centre, window size, whether the centre is probed, the block of positions staged for it
-    int16_t  fp_xc[NL * NR], fp_yc[NL * NR], fp_sw[NL * NR], fp_sh[NL * NR], fp_stx[NL * NR], fp_sty[NL * NR], fp_stw[NL * NR], fp_sth[NL * NR];
+    // another reference (fullpel_prepare_all): centre, whether the centre is probed, the final window (size and origin)
+    int16_t  fp_xc[NL * NR], fp_yc[NL * NR], fp_sw[NL * NR], fp_sh[NL * NR], fp_ox[NL * NR], fp_oy[NL * NR];
     uint8_t  fp_centre[NL * NR];
     uint32_t first_ref_sad64;        // p_sb_best_sad[0][0][0] (read by later references, :1359)
     uint64_t me_sad_sum[NL][NR];     // sum of the 64 best 8x8 SADs per reference (me_prune_ref, :1605-1611)
@@ -1026,18 +1026,67 @@ __device__ void fullpel_prepare_all(LDS &L, const Ctx &c) {
             sw = sh_ = 1;
         const int g = li * NR + ri;
         S.fp_xc[g] = xc, S.fp_yc[g] = yc, S.fp_sw[g] = sw, S.fp_sh[g] = sh_;
-        const int centre = p.me_8x8_var_enabled && (sw * sh_ > 24);
-        S.fp_centre[g] = (uint8_t)centre;
-        if (centre) {  // the block of positions staged for the centre probe and, if it fits, the search (see part 2 below)
-            int16_t cw_ = sw, chh = sh_, cx0, cy0;
-            clamp_me_window(xc, yc, ox_b, oy_b, W, H, pad, &cw_, &chh, &cx0, &cy0);
-            int x0 = MINV((int)xc, (int)cx0), x1 = MAXV((int)xc + 1, (int)cx0 + (cw_ > 0 ? cw_ : 0));
-            int y0 = MINV((int)yc, (int)cy0), y1 = MAXV((int)yc + 1, (int)cy0 + (chh > 0 ? chh : 0));
-            x0 -= (x0 - (int)xc) & 3;
-            if (x1 - x0 > (int)FP_TILE_W || (uint32_t)(y1 - y0 + 63) * fp_pitch((uint32_t)(x1 - x0)) > LDS::WIN_DW)
-                x0 = xc, x1 = xc + 1, y0 = yc, y1 = yc + 1;
-            S.fp_stx[g] = (int16_t)x0, S.fp_sty[g] = (int16_t)y0, S.fp_stw[g] = (int16_t)(x1 - x0), S.fp_sth[g] = (int16_t)(y1 - y0);
+        S.fp_centre[g] = (uint8_t)(p.me_8x8_var_enabled && (sw * sh_ > 24));
+    }
+    __syncthreads();
+    // The centre probes (:1393-1441) of all references, one wave per reference, straight from the reference plane: lane = one 8x8 block
+    // of the b64 in the order of its p_best_sad_8x8 entry (4 * z-order index of its 16x16 + quadrant), 8 rows of two v_sad_u8 — instead of
+    // a staged window and a 4-position quad search of which one position is wanted.  The 64 SADs stay in LDS for the reference's turn
+    // (they are the position-0 entries of its 85 minima: fullpel_ref), the variance of them decides the window size below.
+    uint16_t *const probe8  = (uint16_t *)L.src_q;  // [reference][64]; the down-scaled source blocks are dead by now
+    uint32_t *const probe_v = L.src_s;              // [reference]
+    {
+        const uint32_t wv = tid >> 6, lane = tid & 63, sh1 = me_sub ? 1u : 0u;
+        const uint32_t zo = lane >> 2, cq = lane & 3;
+        const uint32_t zy = 2 * (zo >> 3) + ((zo >> 1) & 1), zx = 2 * ((zo >> 2) & 1) + (zo & 1);
+        const uint32_t by = 2 * zy + (cq >> 1), bx = 2 * zx + (cq & 1);
+        for (int f = (int)wv; f < nref; f += (int)(blockDim.x >> 6)) {
+            const int li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0, g = li * NR + ri;
+            if (!S.sr[li][ri].do_ref || !S.fp_centre[g])  // uniform over the wave
+                continue;
+            const SvtHipPlane8 &rp  = job.ref[li][ri].full;
+            const uint8_t      *ref = plane_at(rp, (int)ox_b + S.fp_xc[g] + (int)(8 * bx), (int)oy_b + S.fp_yc[g] + (int)(8 * by));
+            const uint32_t     *sb  = &L.src_full[(8 * by) * 16 + 2 * bx];
+            uint32_t            acc = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < 8; r++) {
+                if (me_sub && (r & 1))
+                    continue;
+                const uint8_t *rr = ref + (size_t)(r * rp.stride);
+                acc = __builtin_amdgcn_sad_u8(sb[r * 16], load_u32_any(rr), acc);
+                acc = __builtin_amdgcn_sad_u8(sb[r * 16 + 1], load_u32_any(rr + 4), acc);
+            }
+            probe8[g * 64 + (int)lane] = (uint16_t)acc;  // <= 64 * 255
+            const uint32_t mean = (wave_sum_all(acc) << sh1) / 64;
+            const int32_t  dv   = (int32_t)(acc << sh1) - (int32_t)mean;
+            const uint32_t ssq  = wave_sum((uint32_t)(dv * dv));
+            if (lane == 0)
+                probe_v[g] = ssq / 64;
         }
+    }
+    __syncthreads();
+    // window size from the variance, final window (:1393-1561): lane = reference
+    if ((int)tid < nref) {
+        const int f = (int)tid, li = f < R0 ? 0 : 1, ri = f < R0 ? f : f - R0, g = li * NR + ri;
+        int16_t   sw = S.fp_sw[g], sh_ = S.fp_sh[g], ox, oy;
+        if (S.sr[li][ri].do_ref && S.fp_centre[g]) {
+            const uint32_t var = probe_v[g];
+            if (var > p.me_sr_mult2_th) {
+                sw  = (int16_t)((MAXV(1, sw * 3 / 2) + 7) & ~0x7);
+                sh_ = (int16_t)MAXV(1, sh_ * 3 / 2);
+            }
+            if (var < p.me_sr_div4_th) {
+                sw  = (int16_t)((MAXV(1, sw >> 2) + 7) & ~0x7);
+                sh_ = (int16_t)MAXV(1, sh_ >> 2);
+                sh_ = (int16_t)MAXV(3, sh_);
+            } else if (var < p.me_sr_div2_th) {
+                sw  = (int16_t)((MINV(sw, sw >> 1) + 7) & ~0x7);
+                sh_ = (int16_t)MINV(sh_, sh_ >> 1);
+                sh_ = (int16_t)MAXV(3, sh_);
+            }
+        }
+        clamp_me_window(S.fp_xc[g], S.fp_yc[g], ox_b, oy_b, W, H, pad, &sw, &sh_, &ox, &oy);
+        S.fp_sw[g] = sw, S.fp_sh[g] = sh_, S.fp_ox[g] = ox, S.fp_oy[g] = oy;
     }
     __syncthreads();
 }
@@ -1052,14 +1101,33 @@ __device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store, bo
     const int16_t ox_b = (int16_t)org_x, oy_b = (int16_t)org_y;
     const SvtHipPlane8 &rp = job.ref[li][ri].full;
     if (prepared) {
+        // centre, final window and the centre probe's SADs come from fullpel_prepare_all: the 85 minima start from the probe's values
+        // (position 0 of the scan order, :1393-1441) or empty
+        const int g = li * NR + ri;
         if (tid == 0) {
-            const int g = li * NR + ri;
-            S.xc = S.fp_xc[g], S.yc = S.fp_yc[g], S.sw = S.fp_sw[g], S.sh = S.fp_sh[g];
-            S.need_zero_sad = 0, S.need_hme_sad = 0;
-            S.do_centre = S.fp_centre[g], S.staged = S.fp_centre[g];
-            S.stx = S.fp_stx[g], S.sty = S.fp_sty[g], S.stw = S.fp_stw[g], S.sth = S.fp_sth[g];
+            S.xc = S.fp_xc[g], S.yc = S.fp_yc[g], S.sw = S.fp_sw[g], S.sh = S.fp_sh[g], S.ox = S.fp_ox[g], S.oy = S.fp_oy[g];
+            S.restage = 1;
         }
-        for (uint32_t pu = tid; pu < 85; pu += blockDim.x) L.bestkey[pu] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
+        if (S.fp_centre[g]) {  // uniform
+            if (tid < 64) {
+                const uint32_t sh1 = me_sub ? 1u : 0u;
+                const uint32_t v   = ((const uint16_t *)L.src_q)[g * 64 + (int)tid];
+                uint32_t       s16 = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+                s16                = dpp_add<0x4E>(s16);  // quad_perm [2,3,0,1]: the 16x16 of this lane's quad
+                uint32_t s32       = dpp_add<0x124>(s16); // row_ror:4
+                s32                = dpp_add<0x128>(s32); // row_ror:8: the 32x32 of this lane's row of 16
+                const uint32_t s64 = wave_sum_all(v);
+                L.bestkey[21 + tid] = (uint64_t)(v << sh1) << 32;
+                if ((tid & 3) == 0)
+                    L.bestkey[5 + (tid >> 2)] = (uint64_t)(s16 << sh1) << 32;
+                if ((tid & 15) == 0)
+                    L.bestkey[1 + (tid >> 4)] = (uint64_t)(s32 << sh1) << 32;
+                if (tid == 0)
+                    L.bestkey[0] = (uint64_t)(s64 << sh1) << 32;
+            }
+        } else {
+            for (uint32_t pu = tid; pu < 85; pu += blockDim.x) L.bestkey[pu] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
+        }
         __syncthreads();
     } else {
     // part 1: search area from settings + HME results
@@ -1153,7 +1221,6 @@ __device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store, bo
     }
     for (uint32_t pu = tid; pu < 85; pu += blockDim.x) L.bestkey[pu] = ((uint64_t)MAX_SAD_VALUE_ << 32) | 0xffffffffu;
     __syncthreads();
-    }
     if (S.do_centre) {
         fp_stage(L, plane_at(rp, ox_b + S.stx, oy_b + S.sty), rp.stride, (uint32_t)S.stw, (uint32_t)S.sth);
         fp_search(L, fp_pitch((uint32_t)S.stw), (uint32_t)(S.xc - S.stx), (uint32_t)(S.yc - S.sty), 1, 1, 0, 1, me_sub);
@@ -1193,6 +1260,7 @@ __device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store, bo
                       oy + (sh_ > 0 ? sh_ : 0) <= S.sty + S.sth && ((ox - S.stx) & 3) == 0);
     }
     __syncthreads();
+    }
     {
         const int      ox = S.ox, oy = S.oy;
         const uint32_t sw = (uint32_t)(S.sw > 0 ? S.sw : 0), sh_ = (uint32_t)(S.sh > 0 ? S.sh : 0);

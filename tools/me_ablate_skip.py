@@ -10,8 +10,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "svt-av1-mod-by-patman_amd"))
-STOPS = [1, 2, 3, 4, 99]
-MASKS = [0, 1, 2, 3, 7]
+STOPS = [int(x) for x in os.environ.get("ME_ABLATE_STOPS", "1,2,3,4,99").split(",")]
+MASKS = [int(x) for x in os.environ.get("ME_ABLATE_MASKS", "0,1,2,3,7").split(",")]
 
 
 def main():
