@@ -560,32 +560,63 @@ __device__ void stage_sources(LDS &L, const Ctx &c, int which) {
         stage_rows16(L.src_s, 4, plane_at(job.src.sixteenth, (int)(org_x >> 2), (int)(org_y >> 2)), job.src.sixteenth.stride, 16, blockDim.x, tid);
 }
 
-// init_me_hme_data (motion_estimation.c:3080-3140); lane 0 only
+// The per-reference rules between the stages (initialisation, the three pruning rules, the centre selection) run with ONE LANE PER
+// REFERENCE SLOT (list, index) of the first wave instead of a loop in lane 0: a loop over the slots is a chain of dependent LDS round
+// trips (the centre selection alone was 8 % of a workgroup's life), eight lanes read their slots at once and meet in three shuffles.
+struct Slot {
+    bool slot, searched;
+    int  li, ri;
+};
+__device__ __forceinline__ Slot slot_of(uint32_t tid, const SvtHipMeParams &p, int nlists) {
+    Slot s;
+    s.slot = tid < (uint32_t)(NL * NR);
+    s.li = s.slot ? (int)tid / NR : 0, s.ri = s.slot ? (int)tid % NR : 0;
+    s.searched = s.slot && s.li < nlists && s.ri < (int)p.num_of_ref_pic_to_search[s.li];
+    return s;
+}
+static_assert(NL * NR == 8, "slots_min covers eight lanes");
+__device__ __forceinline__ uint64_t slots_min(uint64_t v) {  // minimum over lanes 0..7 (every lane of the wave takes part)
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const uint64_t o = __shfl_xor((unsigned long long)v, off, 64);
+        v                = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t slots_min(uint32_t v) {
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const uint32_t o = __shfl_xor(v, off, 64);
+        v                = o < v ? o : v;
+    }
+    return v;
+}
+
+// init_me_hme_data (motion_estimation.c:3080-3140); lane = reference slot
 template <class LDS>
 __device__ void init_state_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
     if (tid == 0) {
         S.first_ref_sad64 = 0;
-        for (int i = 0; i < NL; i++)
-            for (int j = 0; j < NR; j++) S.me_sad_sum[i][j] = 0;
         S.org_x = org_x, S.org_y = org_y, S.b64_w = b64_w, S.b64_h = b64_h;
         S.l0_min = p.hme_l0_sa_min, S.l0_max = p.hme_l0_sa_max;
-        for (int i = 0; i < NL; i++)
-            for (int j = 0; j < NR; j++) {
-                S.sr[i][j].hme_sad  = MAX_U32_;
-                S.sr[i][j].hme_sc_x = S.sr[i][j].hme_sc_y = 0;
-                S.sr[i][j].do_ref                         = 1;
-                S.sr[i][j].pad_[0] = S.sr[i][j].pad_[1] = S.sr[i][j].pad_[2] = 0;
-                S.reduce_div[i][j] = 1;
-                S.zz_sad[i][j]     = ~0u;
-                for (int k = 0; k < 2; k++) {
-                    S.ph[i][j][k].valid = 0, S.ph[i][j][k].sad = 0, S.ph[i][j][k].col = S.ph[i][j][k].row = 0;
-                    S.performed_phme[i][j][k] = 0;
-                }
-                set_quadrants(S.l0x[i][j], S.l0y[i][j], S.l0s[i][j], 0, 0, 0);
-                set_quadrants(S.l1x[i][j], S.l1y[i][j], S.l1s[i][j], 0, 0, 0);
-                set_quadrants(S.l2x[i][j], S.l2y[i][j], S.l2s[i][j], 0, 0, 0);
-            }
+    }
+    if (tid < (uint32_t)(NL * NR)) {
+        const int i = (int)tid / NR, j = (int)tid % NR;
+        S.me_sad_sum[i][j]  = 0;
+        S.sr[i][j].hme_sad  = MAX_U32_;
+        S.sr[i][j].hme_sc_x = S.sr[i][j].hme_sc_y = 0;
+        S.sr[i][j].do_ref                         = 1;
+        S.sr[i][j].pad_[0] = S.sr[i][j].pad_[1] = S.sr[i][j].pad_[2] = 0;
+        S.reduce_div[i][j] = 1;
+        S.zz_sad[i][j]     = ~0u;
+        for (int k = 0; k < 2; k++) {
+            S.ph[i][j][k].valid = 0, S.ph[i][j][k].sad = 0, S.ph[i][j][k].col = S.ph[i][j][k].row = 0;
+            S.performed_phme[i][j][k] = 0;
+        }
+        set_quadrants(S.l0x[i][j], S.l0y[i][j], S.l0s[i][j], 0, 0, 0);
+        set_quadrants(S.l1x[i][j], S.l1y[i][j], S.l1s[i][j], 0, 0, 0);
+        set_quadrants(S.l2x[i][j], S.l2y[i][j], S.l2s[i][j], 0, 0, 0);
     }
 }
 
@@ -613,31 +644,21 @@ __device__ void zz_sad_all(LDS &L, const Ctx &c) {
     __syncthreads();
 }
 
-// zz-SAD based reference pruning (init_zz_sad, motion_estimation.c:2471-2504); lane 0 only
+// zz-SAD based reference pruning (init_zz_sad, motion_estimation.c:2471-2504); first wave, lane = reference slot
 template <class LDS>
 __device__ void zz_prune_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
-    if (tid == 0) {
-        uint32_t best = MAX_U32_;
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
-                if (tl > 0 || li == 0)
-                    best = MINV(best, S.zz_sad[li][ri]);
-        if (tl > 0 && best < p.zz_sad_th) {
-            for (int li = 0; li < nlists; ++li)
-                for (int ri = 1; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                    const uint32_t pct = p.zz_sad_pct;
-                    if ((uint32_t)((S.zz_sad[li][ri] - best) * 100u) > (uint32_t)(pct * best))
-                        S.sr[li][ri].do_ref = 0;
-                }
-        }
-        if (p.me_safe_limit_zz_th) {
-            const int lim = p.hierarchical_levels > 0 && nlists == 2 && tl >= p.hierarchical_levels &&
-                p.similar_brightness_refs && S.zz_sad[0][0] < p.me_safe_limit_zz_th &&
-                S.zz_sad[1][0] < p.me_safe_limit_zz_th;
-            if (lim)
-                for (int li = 0; li < nlists; ++li)
-                    for (int ri = 1; ri < p.num_of_ref_pic_to_search[li]; ++ri) S.sr[li][ri].do_ref = 0;
+    if (tid < 64) {
+        const Slot     q    = slot_of(tid, p, nlists);
+        const uint32_t z    = S.zz_sad[q.li][q.ri];
+        const uint32_t best = slots_min((q.searched && (tl > 0 || q.li == 0)) ? z : MAX_U32_);
+        if (q.searched && q.ri >= 1) {
+            bool drop = tl > 0 && best < p.zz_sad_th && (uint32_t)((z - best) * 100u) > (uint32_t)(p.zz_sad_pct * best);
+            if (p.me_safe_limit_zz_th)
+                drop = drop || (p.hierarchical_levels > 0 && nlists == 2 && tl >= p.hierarchical_levels && p.similar_brightness_refs &&
+                                S.zz_sad[0][0] < p.me_safe_limit_zz_th && S.zz_sad[1][0] < p.me_safe_limit_zz_th);
+            if (drop)
+                S.sr[q.li][q.ri].do_ref = 0;
         }
     }
 }
@@ -728,29 +749,17 @@ __device__ void prehme_round(LDS &L, const Ctx &c, int f0, int f1, bool searchin
     __syncthreads();
 }
 
-// pre-HME based reference pruning (:1851-1865); lane 0 only
+// pre-HME based reference pruning (:1851-1865); first wave, lane = reference slot
 template <class LDS>
 __device__ void phme_prune_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
-    if (tid == 0) {
-        uint32_t best_sad = MAX_U32_;
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri)
-                if (tl > 0 || li == 0) {
-                    const uint32_t m = (uint32_t)MINV(S.ph[li][ri][0].sad, S.ph[li][ri][1].sad);
-                    best_sad         = MINV(best_sad, m);
-                }
-        if (tl > 0 && best_sad < p.phme_sad_th) {
-            for (int li = 0; li < nlists; ++li)
-                for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                    if (!S.sr[li][ri].do_ref || ri == 0)
-                        continue;
-                    const uint32_t th  = p.phme_sad_pct;
-                    const uint32_t sad = (uint32_t)MINV(S.ph[li][ri][0].sad, S.ph[li][ri][1].sad);
-                    if ((uint32_t)((sad - best_sad) * 100u) > (uint32_t)(th * best_sad))
-                        S.sr[li][ri].do_ref = 0;
-                }
-        }
+    if (tid < 64) {
+        const Slot     q    = slot_of(tid, p, nlists);
+        const uint32_t sad  = (uint32_t)MINV(S.ph[q.li][q.ri][0].sad, S.ph[q.li][q.ri][1].sad);
+        const uint32_t best = slots_min((q.searched && (tl > 0 || q.li == 0)) ? sad : MAX_U32_);
+        if (tl > 0 && best < p.phme_sad_th && q.searched && q.ri != 0 && S.sr[q.li][q.ri].do_ref &&
+            (uint32_t)((sad - best) * 100u) > (uint32_t)(p.phme_sad_pct * best))
+            S.sr[q.li][q.ri].do_ref = 0;
     }
 }
 
@@ -949,51 +958,52 @@ __device__ void hme_l2_round(LDS &L, const Ctx &c, int f0, int f1, int part, Sea
     __syncthreads();
 }
 
-// set_final_seach_centre_sb (:2252-2450) + hme_prune_ref_and_adjust_sr (:2547-2588); lane 0 only
+// set_final_seach_centre_sb (:2252-2450) + hme_prune_ref_and_adjust_sr (:2547-2588); first wave, lane = reference slot
 template <class LDS>
 __device__ void centre_prune_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
-    if (tid == 0) {
-        int16_t  hx = 0, hy = 0, xc = 0, yc = 0;
-        uint64_t hsad = 0;
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                if (tl > 0 || li == 0) {
-                    if (p.enable_hme_flag) {
-                        if (p.enable_hme_level0_flag && !p.enable_hme_level1_flag && !p.enable_hme_level2_flag)
-                            best_quadrant(S.l0x[li][ri], S.l0y[li][ri], S.l0s[li][ri], &hx, &hy, &hsad);
-                        if (p.enable_hme_level1_flag && !p.enable_hme_level2_flag)
-                            best_quadrant(S.l1x[li][ri], S.l1y[li][ri], S.l1s[li][ri], &hx, &hy, &hsad);
-                        if (p.enable_hme_level2_flag)
-                            best_quadrant(S.l2x[li][ri], S.l2y[li][ri], S.l2s[li][ri], &hx, &hy, &hsad);
-                        xc = hx, yc = hy;
-                    }
-                } else {
-                    xc = 0, yc = 0;
-                }
-                S.sr[li][ri].hme_sc_x = xc, S.sr[li][ri].hme_sc_y = yc, S.sr[li][ri].hme_sad = hsad;
-            }
+    if (tid < 64) {
+        const Slot q = slot_of(tid, p, nlists);
+        // the reference's loop carries (x, y, sad) from one reference to the next: a reference whose centre is not taken from the HME
+        // (list 1 at temporal layer 0) gets the zero vector and the SAD of the reference before it in loop order, which then is the last
+        // reference of list 0; without a level to take the centre from everything stays zero
+        const bool from_l2 = p.enable_hme_level2_flag, from_l1 = !from_l2 && p.enable_hme_level1_flag;
+        const bool from_l0 = !from_l2 && !from_l1 && p.enable_hme_level0_flag;
+        const bool taken   = p.enable_hme_flag && (from_l0 || from_l1 || from_l2);
+        int16_t    hx = 0, hy = 0;
+        uint64_t   hsad = 0;
+        if (taken && q.searched && (tl > 0 || q.li == 0)) {
+            if (from_l2)
+                best_quadrant(S.l2x[q.li][q.ri], S.l2y[q.li][q.ri], S.l2s[q.li][q.ri], &hx, &hy, &hsad);
+            else if (from_l1)
+                best_quadrant(S.l1x[q.li][q.ri], S.l1y[q.li][q.ri], S.l1s[q.li][q.ri], &hx, &hy, &hsad);
+            else
+                best_quadrant(S.l0x[q.li][q.ri], S.l0y[q.li][q.ri], S.l0s[q.li][q.ri], &hx, &hy, &hsad);
+        }
+        const uint64_t last_l0 = __shfl((unsigned long long)hsad, R0 > 0 ? R0 - 1 : 0, 64);  // slot (0, R0 - 1)
+        if (q.searched && !(tl > 0 || q.li == 0))
+            hx = hy = 0, hsad = (taken && R0 > 0) ? last_l0 : 0;
+        // what the pruning rules below read: the slot's record as the loop above leaves it (untouched slots keep their initial values)
+        SvtHipMeSearchResult &r = S.sr[q.li][q.ri];
+        int16_t               sx = r.hme_sc_x, sy = r.hme_sc_y;
+        uint64_t              sad = q.slot ? r.hme_sad : ~(uint64_t)0;
+        if (q.searched) {
+            sx = hx, sy = hy, sad = hsad;
+            r.hme_sc_x = hx, r.hme_sc_y = hy, r.hme_sad = hsad;
+        }
         if (p.enable_hme_flag && !p.me_mctf) {  // prune_ref = enable_hme_flag && me_type != ME_MCTF (:3173)
             const uint16_t th = p.prune_ref_if_hme_sad_dev_bigger_than_th;
             if (p.enable_me_hme_ref_pruning && th != (uint16_t)~0) {
-                uint64_t best = ~(uint64_t)0;
-                for (int i = 0; i < NL; i++)
-                    for (int j = 0; j < NR; j++)
-                        if (S.sr[i][j].hme_sad < best) best = S.sr[i][j].hme_sad;
-                for (int i = 0; i < NL; i++)
-                    for (int j = 1; j < NR; j++)
-                        if ((S.sr[i][j].hme_sad - best) * 100 > (th * best)) S.sr[i][j].do_ref = 0;
+                const uint64_t best = slots_min(sad);
+                if (q.slot && q.ri >= 1 && (sad - best) * 100 > (th * best))
+                    r.do_ref = 0;
             }
-            if (p.enable_me_sr_adjustment) {
-                for (int i = 0; i < NL; i++)
-                    for (int j = 0; j < NR; j++) {
-                        if (ABSV(S.sr[i][j].hme_sc_x) <= p.reduce_me_sr_based_on_mv_length_th &&
-                            ABSV(S.sr[i][j].hme_sc_y) <= p.reduce_me_sr_based_on_mv_length_th &&
-                            S.sr[i][j].hme_sad < p.stationary_hme_sad_abs_th)
-                            S.reduce_div[i][j] = p.stationary_me_sr_divisor;
-                        else if (S.sr[i][j].hme_sad < p.reduce_me_sr_based_on_hme_sad_abs_th)
-                            S.reduce_div[i][j] = p.me_sr_divisor_for_low_hme_sad;
-                    }
+            if (p.enable_me_sr_adjustment && q.slot) {
+                if (ABSV(sx) <= p.reduce_me_sr_based_on_mv_length_th && ABSV(sy) <= p.reduce_me_sr_based_on_mv_length_th &&
+                    sad < p.stationary_hme_sad_abs_th)
+                    S.reduce_div[q.li][q.ri] = p.stationary_me_sr_divisor;
+                else if (sad < p.reduce_me_sr_based_on_hme_sad_abs_th)
+                    S.reduce_div[q.li][q.ri] = p.me_sr_divisor_for_low_hme_sad;
             }
         }
     }
@@ -1309,29 +1319,23 @@ __device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store, bo
     __syncthreads();
 }
 
-// me_prune_ref (motion_estimation.c:1592-1635); lane 0 only
+// me_prune_ref (motion_estimation.c:1592-1635); first wave, lane = reference slot
 template <class LDS>
 __device__ void me_prune_lane0(LDS &L, const Ctx &c) {
     ME_CTX_LOCALS(c);
-    if (tid == 0) {
-        for (int li = 0; li < nlists; ++li)
-            for (int ri = 0; ri < p.num_of_ref_pic_to_search[li]; ++ri) {
-                S.sr[li][ri].hme_sad = 0;
-                if (S.sr[li][ri].do_ref == 0) {
-                    S.sr[li][ri].hme_sad = (uint64_t)(MAX_SAD_VALUE_ * 64);
-                    continue;
-                }
-                S.sr[li][ri].hme_sad = S.me_sad_sum[li][ri];
-            }
+    if (tid < 64) {
+        const Slot            q   = slot_of(tid, p, nlists);
+        SvtHipMeSearchResult &r   = S.sr[q.li][q.ri];
+        uint64_t              sad = q.slot ? r.hme_sad : ~(uint64_t)0;
+        if (q.searched) {
+            sad       = r.do_ref ? S.me_sad_sum[q.li][q.ri] : (uint64_t)(MAX_SAD_VALUE_ * 64);
+            r.hme_sad = sad;
+        }
         const uint16_t th = p.prune_ref_if_me_sad_dev_bigger_than_th;
         if (th != (uint16_t)~0) {
-            uint64_t best = ~(uint64_t)0;
-            for (int i = 0; i < NL; i++)
-                for (int j = 0; j < NR; j++)
-                    if (S.sr[i][j].hme_sad < best) best = S.sr[i][j].hme_sad;
-            for (int i = 0; i < NL; i++)
-                for (int j = 1; j < NR; j++)
-                    if ((S.sr[i][j].hme_sad - best) * 100 > (th * best)) S.sr[i][j].do_ref = 0;
+            const uint64_t best = slots_min(sad);
+            if (q.slot && q.ri >= 1 && (sad - best) * 100 > (th * best))
+                r.do_ref = 0;
         }
     }
 }
