@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off randomised parity sweep (GPU box) over the round-3 additions: TPL level 3, temporal filter with 8x8 prediction / low delay.
+"""One-off randomised parity sweep (GPU box) over the round-3 additions: TPL level 3, temporal filter with 8x8 prediction / low delay,
+the open-loop ME with random presets / reference counts / thresholds (the all-reference centre probes and the lane-parallel rules).
     python tools/stress_r3.py [n]"""
 import ctypes as C
 import os
@@ -15,6 +16,8 @@ import tf_picture_cases as TP  # noqa: E402
 import tpl_cases as T  # noqa: E402
 import test_gpu_tf_picture as GTF  # noqa: E402
 import test_gpu_tpl as GTPL  # noqa: E402
+import me_cases as MC  # noqa: E402
+import test_gpu_me as GME  # noqa: E402
 from svtav1_hip import abi  # noqa: E402
 
 
@@ -67,6 +70,39 @@ def main():
         ok = tot == otot and np.array_equal(TP.states_to_array(ostates), states) and all(np.array_equal(got[k], v) for k, v in pics[0].arrays().items())
         s16 = sum(sum(s.split16) for s in ostates)
         print(f"tf   {i:2d} {case[1]:8s} {w}x{h} {bd}-bit refs {case[4]} ld {ctl.get('low_delay', 0)} sss {ctl['sub_sampling_shift']} split16 {s16:4d} {'ok' if ok else 'MISMATCH'}", flush=True)
+        bad += not ok
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "me_params.json")) as f:
+        keys = sorted(json.load(f))
+    for i in range(n):
+        w, h = int(rng.integers(17, 100)) * 8, int(rng.integers(9, 60)) * 8
+        key = str(rng.choice(keys))
+        tl = int(rng.choice([0, 2]))
+        n0, n1 = int(rng.integers(1, 5)), int(rng.integers(0, 4))
+        cur = 3
+        l0 = [int(x) for x in rng.choice([2, 1, 0], size=n0)]
+        l1 = [int(x) for x in rng.choice([4, 5, 6], size=n1)]
+        kind = str(rng.choice(("pan", "blocks", "fastpan", "noise", "static", "flat")))
+        clip = MC.make_clip(kind, w, h, 7, seed=int(rng.integers(0, 1000)))
+        pyrs = MC.build_pyramids(orc, clip)
+        prm = MC.scenario_params(key, cur, l0, l1, tl, int(rng.integers(0, 2)))
+        tweak = {}
+        if rng.integers(0, 2):
+            tweak.update(me_sr_div4_th=int(rng.choice([0, 2000, 80000, 10 ** 6])), me_sr_div2_th=int(rng.choice([0, 20000, 150000, 10 ** 7])),
+                         me_sr_mult2_th=int(rng.choice([0, 500, 2 ** 32 - 1])), me_8x8_var_enabled=1)
+        if rng.integers(0, 3) == 0:
+            tweak.update(me_early_exit_th=int(rng.choice([0, 6000, 32768, 400000])))
+        if rng.integers(0, 3) == 0:
+            tweak.update(me_search_method=int(rng.integers(0, 2)), hme_search_method=int(rng.integers(0, 2)))
+        if rng.integers(0, 4) == 0:
+            tweak.update(prune_ref_if_hme_sad_dev_bigger_than_th=int(rng.choice([5, 30, 65535])), prune_ref_if_me_sad_dev_bigger_than_th=int(rng.choice([5, 60, 65535])),
+                         zz_sad_th=int(rng.choice([0, 10 ** 6])), zz_sad_pct=int(rng.choice([5, 50])), phme_sad_th=int(rng.choice([0, 10 ** 6])), phme_sad_pct=int(rng.choice([5, 50])))
+        for k, v in tweak.items():
+            setattr(prm, k, v)
+        want = MC.run_cpu(orc.orc_me_frame_range, prm, pyrs, cur, l0, l1, w, h)
+        got = GME.run_hip_me(hip, prm, pyrs, cur, l0, l1, w, h)[0]
+        ok = all(np.array_equal(want[k], got[k]) for k in want)
+        print(f"me   {i:2d} {kind:8s} {w}x{h} {key} tl{tl} refs {n0}+{n1} {tweak} {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += not ok
     print("mismatches:", bad)
     return 1 if bad else 0
