@@ -3,15 +3,18 @@
 // svt_av1_highbd_wiener_convolve_add_src_c (convolve.c:57-200).
 //
 // Statistics.  The reference accumulates, per sample of the unit, y[k]*x and y[k]*y[l] for the win^2 taps
-// y[k] = dgd(sample + tap k) - avg.  Here the RAW second moments are accumulated instead and the mean is folded in at the
-// end (exact integer algebra: sum (a - m)(b - m) = sum ab - m sum a - m sum b + N m^2), so no pre-pass over the unit is
-// needed for `avg`.  One workgroup owns a 64 x 32 tile of the unit, staged in LDS with its border; a thread owns one
-// pair of tap COLUMNS (c1 <= c2) — or a tap column and the source, which is the same sliding block — and walks DOWN a
-// column of horizontally adjacent sample PAIRS: per step it reads one new row of each of its two columns (one aligned
-// 32-bit LDS read each: the tile is kept twice, the second copy shifted by one sample; the other six vertical taps are
-// the previous step's) and does the 49 multiply-accumulates of that 7 x 7 block of H as 49 v_dot2_u32_u16 in registers
-// (uint32 partials, flushed per tile to int64).  28 column pairs + 7 column-by-source blocks x 7 column slices fill the
-// 256 lanes; the first moments come from column sums of the tile.
+// y[k] = dgd(sample + tap k) - avg.  That is a Gram matrix: with Z = one row per sample and one column per tap (plus the source
+// sample and a constant 1), everything the function returns is in Z^T Z.  Here Z^T Z is computed on the matrix cores with EXACT
+// integer arithmetic: a sample minus half the range is split into two int8 digits c = 32 h + l (h = c >> 5 signed, l = c & 31), the
+// matrix gets a column for every digit (2 x (win^2 + 1) + the ones column = 101 rows for win 7, 53 for win 5, padded to 128 / 64),
+// and v_mfma_i32_32x32x32_i8 accumulates the products of 32 samples per instruction in int32.  Because both operands of a tile
+// product are fragments of the same matrix, the fragment of a tile row serves as A and as B; only the upper triangle of tiles is
+// computed.  The digits recombine as 1024 hh' + 32 (hl' + lh') + ll', the RAW moments follow from the ones column, and the mean is
+// folded in at the end (exact integer algebra: sum (a - m)(b - m) = sum ab - m sum a - m sum b + N m^2), so no pre-pass over the
+// unit is needed for `avg`.  One workgroup owns 64 x 128 samples of the unit (4 chunks of 32 rows staged in LDS as digit planes
+// with their borders); a wave takes every fourth sample row and walks it in steps of 32 samples: per step a lane builds the 16
+// bytes of each of its tile rows from aligned dword reads and v_alignbyte (the tap offset decides the byte phase, which is constant
+// per lane), then 10 (win 7) or 3 (win 5) MFMAs.  The accumulators are combined in LDS (int64) once per workgroup.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,7 +27,7 @@ using namespace svthip;
 
 namespace {
 
-constexpr int TW = 64, TH = 32;  // samples per tile (TH shrinks to 8 for 12-bit so that int32 partials cannot overflow)
+constexpr int TW = 64, TH = 32;  // samples per tile
 constexpr int W2MAX = 49;  // WIENER_WIN2
 
 using svthip::lr::ldpx;
@@ -38,159 +41,145 @@ struct StatsAux {  // raw first moments of one unit
 
 constexpr int CHUNKS = 4;  // row chunks of one tile column that a workgroup accumulates before it touches global memory
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
 template <int WIN>
-__global__ __launch_bounds__(256, 4) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int is16, int th,
+__global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int is16, int bd,
                                                            long long *__restrict__ M, long long *__restrict__ H, StatsAux *__restrict__ aux) {
     constexpr int HALF = WIN / 2, W2 = WIN * WIN;
-    constexpr int NPAIR = WIN * (WIN + 1) / 2, NJOB = NPAIR + WIN;  // column pairs (blocks of H), column x source (rows of M)
-    constexpr int NSL = 256 / NJOB;                                  // column slices per job
-    constexpr int DP = TW + 2 * 3 + 2;
-    // d1 is d shifted left by one sample: a thread whose column offset is odd reads its sample PAIRS from d1, so that every
-    // pair is one aligned 32-bit LDS read.  s holds the source rows HALF rows down (rows above / below: zero), which makes a
-    // column-by-source job the same sliding 7 x 7 block as a column pair: its middle column is the row of M.
-    __shared__ __attribute__((aligned(4))) uint16_t d[(TH + 2 * 3) * DP];
-    __shared__ __attribute__((aligned(4))) uint16_t d1[(TH + 2 * 3) * DP];
-    __shared__ __attribute__((aligned(4))) uint16_t s[(TH + 2 * 3) * TW];
-    __shared__ uint32_t  cs[WIN][TW + 2 * 3];                     // column sums of d over the tile rows, per vertical tap
-    __shared__ long long Hl[W2 * W2], Ml[W2], Sl[W2], misc[2];    // this workgroup's totals (int64), flushed once at the end
+    constexpr int NCOL = W2 + 1;                    // columns with two digits: the taps and the source sample
+    constexpr int ONES = 2 * NCOL, NROW = ONES + 1;  // rows of Z^T: high digits, low digits, the constant 1
+    constexpr int NT = (NROW + 31) / 32, NTP = NT * (NT + 1) / 2;
+    constexpr int P = 80;                           // bytes per row of a digit plane (64 samples + 2 * 3 border + the over-read of an aligned fragment)
+    constexpr int DROWS = TH + 2 * HALF;
+    constexpr int OFF_DH = 0, OFF_DL = OFF_DH + DROWS * P, OFF_SH = OFF_DL + DROWS * P, OFF_SL = OFF_SH + TH * P, OFF_ONE = OFF_SL + TH * P,
+                  OFF_ZERO = OFF_ONE + 128, PL_BYTES = OFF_ZERO + 128;
+    constexpr int HD = NCOL + 1;                    // Hx[a][b], a <= b: taps, source, ones
+    __shared__ alignas(16) uint8_t pl[PL_BYTES];
+    __shared__ long long Hx[HD * HD];
     const SvtHipWienerUnit u = units[blockIdx.z];
     const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
     const int x0 = blockIdx.x * TW;
-    if (x0 >= uw || (int)(blockIdx.y * CHUNKS * th) >= uh)
+    if (x0 >= uw || (int)(blockIdx.y * CHUNKS * TH) >= uh)
         return;
     const int tw = min(TW, uw - x0);
-    for (int i = threadIdx.x; i < W2 * W2; i += 256) Hl[i] = 0;
-    if (threadIdx.x < W2)
-        Ml[threadIdx.x] = 0, Sl[threadIdx.x] = 0;
-    if (threadIdx.x < 2)
-        misc[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < (TH + 2 * 3) * TW; i += 256) s[i] = 0;
-    const int job = threadIdx.x / NSL, sl = threadIdx.x - job * NSL;
-    int       c1 = 0, c2 = 0;
-    if (job < NPAIR) {  // column pair (c1 <= c2) from the triangular index
-        int rem = job;
-        while (rem >= WIN - c1) rem -= WIN - c1, c1++;
-        c2 = c1 + rem;
-    } else {
-        c1 = job - NPAIR;
+    for (int i = threadIdx.x; i < HD * HD; i += 256) Hx[i] = 0;
+    if (threadIdx.x < 128)
+        pl[OFF_ONE + threadIdx.x] = 1, pl[OFF_ZERO + threadIdx.x] = 0;
+    const int mid = 1 << (bd - 1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
+    // where this lane's row of each tile lives: byte offset of (sample row 0, sample 16 * kh) and the row pitch (0: a constant row)
+    uint32_t addr[NT], pit[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int g = 32 * t + r;
+        if (g < 2 * NCOL) {
+            const int  col = g < NCOL ? g : g - NCOL;
+            const bool low = g >= NCOL;
+            if (col < W2)  // tap index = column * WIN + row (restoration_pick.c:686-691)
+                addr[t] = (low ? OFF_DL : OFF_DH) + (col % WIN) * P + col / WIN;
+            else
+                addr[t] = low ? OFF_SL : OFF_SH;
+            pit[t] = P;
+        } else {
+            addr[t] = g == ONES ? OFF_ONE : OFF_ZERO, pit[t] = 0;
+        }
+        addr[t] += 16 * kh;
     }
-    const bool is_m = job >= NPAIR;
+    v16i acc[NTP];
+#pragma unroll
+    for (int p = 0; p < NTP; p++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[p][i] = 0;
     for (int chunk = 0; chunk < CHUNKS; chunk++) {
-        const int y0 = (blockIdx.y * CHUNKS + chunk) * th;
+        const int y0 = (blockIdx.y * CHUNKS + chunk) * TH;
         if (y0 >= uh)
             break;
-        const int tv = min(th, uh - y0), npx = tv * tw;
-        __syncthreads();  // previous chunk fully consumed (and the zeroing above done)
+        const int tv = min(TH, uh - y0);
+        __syncthreads();  // previous chunk fully consumed (and the initialisation above done)
         for (int idx = threadIdx.x; idx < (tv + 2 * HALF) * (tw + 2 * HALF); idx += 256) {
-            const int r = idx / (tw + 2 * HALF), c = idx - r * (tw + 2 * HALF);
-            const uint16_t v = (uint16_t)ldpx(u.dgd, (size_t)((ptrdiff_t)(u.v_start + y0 + r - HALF) * u.dgd_stride + (u.h_start + x0 + c - HALF)), is16);
-            d[r * DP + c] = v;
-            if (c)
-                d1[r * DP + c - 1] = v;
+            const int rr = idx / (tw + 2 * HALF), c = idx - rr * (tw + 2 * HALF);
+            const int v = (int)ldpx(u.dgd, (size_t)((ptrdiff_t)(u.v_start + y0 + rr - HALF) * u.dgd_stride + (u.h_start + x0 + c - HALF)), is16) - mid;
+            pl[OFF_DH + rr * P + c] = (uint8_t)(v >> 5), pl[OFF_DL + rr * P + c] = (uint8_t)(v & 31);
         }
-        for (int idx = threadIdx.x; idx < (tv + HALF) * TW; idx += 256) {   // rows below a short last chunk read as zero again
-            const int r = idx / TW, c = idx - r * TW;
-            s[(r + HALF) * TW + c] = r < tv && c < tw
-                ? (uint16_t)ldpx(u.src, (size_t)((ptrdiff_t)(u.v_start + y0 + r) * u.src_stride + (u.h_start + x0 + c)), is16) : (uint16_t)0;
+        for (int idx = threadIdx.x; idx < tv * tw; idx += 256) {
+            const int rr = idx / tw, c = idx - rr * tw;
+            const int v = (int)ldpx(u.src, (size_t)((ptrdiff_t)(u.v_start + y0 + rr) * u.src_stride + (u.h_start + x0 + c)), is16) - mid;
+            pl[OFF_SH + rr * P + c] = (uint8_t)(v >> 5), pl[OFF_SL + rr * P + c] = (uint8_t)(v & 31);
         }
         __syncthreads();
-        // Two horizontally adjacent samples per step: each multiply-accumulate of the block is one v_dot2_u32_u16 over the
-        // pair (the partner of the last sample of an odd-width tile is masked to zero).  A thread walks DOWN its sample
-        // columns: the WIN vertical taps of one row are WIN - 1 of the previous row's, so a step costs two LDS reads for the
-        // WIN x WIN multiply-accumulates; the row loop is unrolled WIN times, which makes the rotation of the tap registers
-        // a renaming.
-        const int hw = (tw + 1) >> 1;
-        if (job < NJOB) {
-            uint32_t acc[WIN][WIN];
+        for (int y = wv; y < tv; y += 4) {
+            for (int xs = 0; xs < tw; xs += 32) {
+                // samples of the unit among this lane's 16 (the bytes behind them belong to the border or to an earlier chunk)
+                const int  nv   = min(max(tw - xs - 16 * kh, 0), 16);
+                const bool edge = xs + 32 > tw;  // uniform
+                v4i        f[NT];
 #pragma unroll
-            for (int a = 0; a < WIN; a++)
+                for (int t = 0; t < NT; t++) {
+                    const uint32_t  a  = addr[t] + (uint32_t)y * pit[t] + (uint32_t)xs;
+                    const uint32_t *q  = (const uint32_t *)(pl + (a & ~3u));
+                    const uint32_t  sh = a & 3u;
+                    const uint32_t  d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                    f[t][0] = (int)__builtin_amdgcn_alignbyte(d1, d0, sh), f[t][1] = (int)__builtin_amdgcn_alignbyte(d2, d1, sh);
+                    f[t][2] = (int)__builtin_amdgcn_alignbyte(d3, d2, sh), f[t][3] = (int)__builtin_amdgcn_alignbyte(d4, d3, sh);
+                    if (edge) {
 #pragma unroll
-                for (int b = 0; b < WIN; b++) acc[a][b] = 0;
-            const uint16_t *ta = ((c1 & 1) ? d1 - 1 : d) + c1;
-            const uint16_t *tb = is_m ? s : ((c2 & 1) ? d1 - 1 : d) + c2;
-            const int       pb = is_m ? TW : DP;
-            for (int cp = sl; cp < hw; cp += NSL) {
-                const int      c    = 2 * cp;
-                const uint32_t mask = c + 1 < tw ? 0xffffffffu : 0x0000ffffu;
-                const uint16_t *qa = ta + c, *qb = tb + c;
-                u16x2           va[WIN], vb[WIN];
-#pragma unroll
-                for (int k = 0; k < WIN - 1; k++) {
-                    va[k] = __builtin_bit_cast(u16x2, *(const uint32_t *)&qa[k * DP] & mask);
-                    vb[k] = __builtin_bit_cast(u16x2, *(const uint32_t *)&qb[k * pb]);
-                }
-                for (int r = 0; r < tv; r += WIN) {
-#pragma unroll
-                    for (int j = 0; j < WIN; j++) {
-                        if (r + j < tv) {
-                            constexpr int NEWEST = WIN - 1;
-                            va[(j + NEWEST) % WIN] = __builtin_bit_cast(u16x2, *(const uint32_t *)&qa[(r + j + NEWEST) * DP] & mask);
-                            vb[(j + NEWEST) % WIN] = __builtin_bit_cast(u16x2, *(const uint32_t *)&qb[(r + j + NEWEST) * pb]);
-#pragma unroll
-                            for (int a = 0; a < WIN; a++)
-#pragma unroll
-                                for (int b = 0; b < WIN; b++)
-                                    acc[a][b] = __builtin_amdgcn_udot2(va[(j + a) % WIN], vb[(j + b) % WIN], acc[a][b], false);
+                        for (int i = 0; i < 4; i++) {
+                            const int vb = min(max(nv - 4 * i, 0), 4);
+                            f[t][i] &= vb == 4 ? -1 : (int)((1u << (8 * vb)) - 1u);
                         }
                     }
                 }
+                int p = 0;
+#pragma unroll
+                for (int ta = 0; ta < NT; ta++)
+#pragma unroll
+                    for (int tb = ta; tb < NT; tb++, p++) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[ta], f[tb], acc[p], 0, 0, 0);
             }
-            if (!is_m) {
-                // tap index = column * WIN + row (restoration_pick.c:686-691); only the upper triangle k <= l is kept
+        }
+    }
+    // digits -> columns: entry (a, b), a <= b, of Z^T Z goes to the column pair of its rows with the weight of its digits; a pair of
+    // different digits of ONE column appears once in the upper triangle but twice in the product
+    {
+        int p = 0;
 #pragma unroll
-                for (int a = 0; a < WIN; a++)
+        for (int ta = 0; ta < NT; ta++)
 #pragma unroll
-                    for (int b = 0; b < WIN; b++) {
-                        const int k = c1 * WIN + a, l = c2 * WIN + b;
-                        if (k <= l && acc[a][b])
-                            atomicAdd((unsigned long long *)&Hl[k * W2 + l], (unsigned long long)acc[a][b]);
+            for (int tb = ta; tb < NT; tb++, p++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int a = 32 * ta + (i & 3) + 8 * (i >> 2) + 4 * kh, b = 32 * tb + r;
+                    if (a <= b && b < NROW && acc[p][i]) {
+                        const int ca = a < NCOL ? a : (a < ONES ? a - NCOL : NCOL), wa = a < NCOL ? 32 : 1;
+                        const int cb = b < NCOL ? b : (b < ONES ? b - NCOL : NCOL), wb = b < NCOL ? 32 : 1;
+                        const int w  = wa * wb * ((a < b && ca == cb) ? 2 : 1);
+                        atomicAdd((unsigned long long *)&Hx[min(ca, cb) * HD + max(ca, cb)], (unsigned long long)((long long)acc[p][i] * w));
                     }
-            } else {
-#pragma unroll
-                for (int a = 0; a < WIN; a++) atomicAdd((unsigned long long *)&Ml[c1 * WIN + a], (unsigned long long)acc[a][HALF]);
-            }
-        }
-        // first moments: sum of dgd under every tap = column sums of the tile slid down the WIN vertical taps, then summed
-        // over the tw columns behind each horizontal tap; the source sum likewise
-        if ((int)threadIdx.x < tw + 2 * HALF) {
-            const int x = threadIdx.x;
-            uint32_t  w = 0;
-            for (int r = 0; r < tv; r++) w += d[r * DP + x];
-            cs[0][x] = w;
-#pragma unroll
-            for (int a = 1; a < WIN; a++) {
-                w += (uint32_t)d[(tv + a - 1) * DP + x] - (uint32_t)d[(a - 1) * DP + x];
-                cs[a][x] = w;
-            }
-        } else if (threadIdx.x >= 128 && (int)threadIdx.x < 128 + tw) {
-            const int x = threadIdx.x - 128;
-            long long ss = 0;
-            for (int r = 0; r < tv; r++) ss += s[(r + HALF) * TW + x];
-            atomicAdd((unsigned long long *)&misc[0], (unsigned long long)ss);
-        }
-        __syncthreads();
-        if (threadIdx.x < W2) {  // k = column * WIN + row
-            const int cc = threadIdx.x / WIN, a = threadIdx.x - cc * WIN;
-            long long t = 0;
-            for (int c = 0; c < tw; c++) t += cs[a][c + cc];
-            Sl[threadIdx.x] += t;
-        }
-        if (threadIdx.x == 0)
-            misc[1] += npx;
+                }
     }
     __syncthreads();
+    // centred -> raw moments (sum (c + m)(c' + m) = sum cc' + m sum c + m sum c' + N m^2), then this workgroup's share goes to the unit
     long long *Hu = H + (size_t)blockIdx.z * W2MAX * W2MAX, *Mu = M + (size_t)blockIdx.z * W2MAX;
     StatsAux  &A  = aux[blockIdx.z];
-    for (int e = threadIdx.x; e < W2 * W2; e += 256)
-        if (e / W2 <= e % W2 && Hl[e])
-            atomicAdd((unsigned long long *)&Hu[e], (unsigned long long)Hl[e]);
+    const long long n = Hx[NCOL * HD + NCOL], m = mid;
+    for (int e = threadIdx.x; e < W2 * W2; e += 256) {
+        const int k = e / W2, l = e - k * W2;
+        if (k <= l) {
+            const long long v = Hx[k * HD + l] + m * (Hx[k * HD + NCOL] + Hx[l * HD + NCOL]) + n * m * m;
+            if (v)
+                atomicAdd((unsigned long long *)&Hu[e], (unsigned long long)v);
+        }
+    }
     if (threadIdx.x < W2) {
-        atomicAdd((unsigned long long *)&Mu[threadIdx.x], (unsigned long long)Ml[threadIdx.x]);
-        atomicAdd((unsigned long long *)&A.S[threadIdx.x], (unsigned long long)Sl[threadIdx.x]);
+        const int       k  = threadIdx.x;
+        const long long sk = Hx[k * HD + NCOL], ss = Hx[W2 * HD + NCOL];
+        atomicAdd((unsigned long long *)&Mu[k], (unsigned long long)(Hx[k * HD + W2] + m * (sk + ss) + n * m * m));
+        atomicAdd((unsigned long long *)&A.S[k], (unsigned long long)(sk + n * m));
     }
     if (threadIdx.x == 0) {
-        atomicAdd((unsigned long long *)&A.sum_src, (unsigned long long)misc[0]);
-        atomicAdd((unsigned long long *)&A.n, (unsigned long long)misc[1]);
+        atomicAdd((unsigned long long *)&A.sum_src, (unsigned long long)(Hx[W2 * HD + NCOL] + n * m));
+        atomicAdd((unsigned long long *)&A.n, (unsigned long long)n);
     }
 }
 
@@ -288,13 +277,12 @@ extern "C" int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units, uint32_t 
     SVT_HIP_CHECK(hipMemsetAsync(d_M, 0, sizeof(int64_t) * W2MAX * n_units, st));
     SVT_HIP_CHECK(hipMemsetAsync(d_H, 0, sizeof(int64_t) * W2MAX * W2MAX * n_units, st));
     SVT_HIP_CHECK(hipMemsetAsync(ab.dev, 0, sizeof(StatsAux) * n_units, st));
-    // int32 partials: a thread sees at most th*64/NSL samples of one tile; 12-bit products need the smaller tile
-    const int  th = bit_depth == 12 ? 8 : TH;
-    const dim3 grid((max_w + TW - 1) / TW, (max_h + CHUNKS * th - 1) / (CHUNKS * th), n_units);
+    // int32 accumulators: a wave sees CHUNKS * TH / 4 rows of 64 samples, products of two digits are below 2^12
+    const dim3 grid((max_w + TW - 1) / TW, (max_h + CHUNKS * TH - 1) / (CHUNKS * TH), n_units);
     if (wiener_win == 7)
-        hipLaunchKernelGGL(wiener_stats_kernel<7>, grid, dim3(256), 0, st, d_units, is_16bit, th, (long long *)d_M, (long long *)d_H, ab.dev);
+        hipLaunchKernelGGL(wiener_stats_kernel<7>, grid, dim3(256), 0, st, d_units, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
     else
-        hipLaunchKernelGGL(wiener_stats_kernel<5>, grid, dim3(256), 0, st, d_units, is_16bit, th, (long long *)d_M, (long long *)d_H, ab.dev);
+        hipLaunchKernelGGL(wiener_stats_kernel<5>, grid, dim3(256), 0, st, d_units, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
     const int divider = is_16bit ? (bit_depth == 12 ? 16 : (bit_depth == 10 ? 4 : 1)) : 1;  // restoration_pick.c:719-723
     hipLaunchKernelGGL(wiener_finalize_kernel, dim3(n_units), dim3(256), 0, st, wiener_win, divider, (long long *)d_M, (long long *)d_H,
                        (const StatsAux *)ab.dev);

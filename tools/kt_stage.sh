@@ -8,6 +8,6 @@ f=$(find /tmp/kt_stage -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if any(k in r["Name"] for k in ("tf_", "tpl_", "me_b64", "convolve")):
+    if any(k in r["Name"] for k in ("tf_", "tpl_", "me_b64", "convolve", "wiener", "cdef", "sgr")):
         print(r["Name"][:70].ljust(70), r["Calls"], round(float(r["AverageNs"]) / 1e6, 4), "ms")
 PY
