@@ -11,7 +11,7 @@
 // product are fragments of the same matrix, the fragment of a tile row serves as A and as B; only the upper triangle of tiles is
 // computed.  The digits recombine as 1024 hh' + 32 (hl' + lh') + ll', the RAW moments follow from the ones column, and the mean is
 // folded in at the end (exact integer algebra: sum (a - m)(b - m) = sum ab - m sum a - m sum b + N m^2), so no pre-pass over the
-// unit is needed for `avg`.  One workgroup owns 64 x 128 samples of the unit (4 chunks of 32 rows staged in LDS as digit planes
+// unit is needed for `avg`.  One workgroup owns 64 x 256 samples of the unit (8 chunks of 32 rows staged in LDS as digit planes
 // with their borders); a wave takes every fourth sample row and walks it in steps of 32 samples: per step a lane builds the 16
 // bytes of each of its tile rows from aligned dword reads and v_alignbyte (the tap offset decides the byte phase, which is constant
 // per lane), then 10 (win 7) or 3 (win 5) MFMAs.  The accumulators are combined in LDS (int64) once per workgroup.
@@ -39,13 +39,38 @@ struct StatsAux {  // raw first moments of one unit
     long long sum_src, n;
 };
 
-constexpr int CHUNKS = 4;  // row chunks of one tile column that a workgroup accumulates before it touches global memory
+
+// eight horizontally adjacent samples from element `e` of a plane of bytes or 16-bit words (any alignment); `left` = samples that
+// exist from there on (fewer than 8 at the end of a row: the others are never used and are not touched)
+struct Px8 {
+    uint16_t v[8];
+};
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u128_any;
+typedef uint32_t __attribute__((ext_vector_type(2), aligned(1))) u64_any;
+__device__ __forceinline__ Px8 load_px8(const void *base, size_t e, int is16, int left) {
+    Px8 r;
+    if (left >= 8) {
+        if (is16) {
+            const u128_any q = *(const u128_any *)((const uint16_t *)base + e);
+#pragma unroll
+            for (int k = 0; k < 8; k++) r.v[k] = (uint16_t)(q[k >> 1] >> (16 * (k & 1)));
+        } else {
+            const u64_any q = *(const u64_any *)((const uint8_t *)base + e);
+#pragma unroll
+            for (int k = 0; k < 8; k++) r.v[k] = (uint16_t)((q[k >> 2] >> (8 * (k & 3))) & 0xff);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) r.v[k] = k < left ? (uint16_t)ldpx(base, e + k, is16) : (uint16_t)0;
+    }
+    return r;
+}
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 template <int WIN>
-__global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int is16, int bd,
+__global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int n_units, int gx, int gy, int is16, int bd,
                                                            long long *__restrict__ M, long long *__restrict__ H, StatsAux *__restrict__ aux) {
     constexpr int HALF = WIN / 2, W2 = WIN * WIN;
     constexpr int NCOL = W2 + 1;                    // columns with two digits: the taps and the source sample
@@ -58,17 +83,19 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
     constexpr int HD = NCOL + 1;                    // Hx[a][b], a <= b: taps, source, ones
     __shared__ alignas(16) uint8_t pl[PL_BYTES];
     __shared__ long long Hx[HD * HD];
-    const SvtHipWienerUnit u = units[blockIdx.z];
-    const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
-    const int x0 = blockIdx.x * TW;
-    if (x0 >= uw || (int)(blockIdx.y * CHUNKS * TH) >= uh)
+    // Work items = (unit, chunk of 32 rows, 64-wide tile) over the padded grid gx x gy per unit, tile fastest; the launch has as many
+    // workgroups as the GPU holds at once and each takes a contiguous range of items, so that consecutive items share the unit (and
+    // with it the accumulators: they are combined and sent to the unit's sums only when the unit changes) and every workgroup has the
+    // same share whatever the number and the sizes of the units.
+    const int total = n_units * gx * gy, per = __builtin_amdgcn_readfirstlane((total + (int)gridDim.x - 1) / (int)gridDim.x);
+    const int i0 = (int)blockIdx.x * per, i1 = min(total, i0 + per);
+    if (i0 >= i1)
         return;
-    const int tw = min(TW, uw - x0);
     for (int i = threadIdx.x; i < HD * HD; i += 256) Hx[i] = 0;
     if (threadIdx.x < 128)
         pl[OFF_ONE + threadIdx.x] = 1, pl[OFF_ZERO + threadIdx.x] = 0;
     const int mid = 1 << (bd - 1);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5, r_lane = r, kh_lane = kh;
     // where this lane's row of each tile lives: byte offset of (sample row 0, sample 16 * kh) and the row pitch (0: a constant row)
     uint32_t addr[NT], pit[NT];
 #pragma unroll
@@ -87,50 +114,135 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
         }
         addr[t] += 16 * kh;
     }
-    v16i acc[NTP];
+    auto flush = [&](int unit, const v16i(&acc)[NTP]) {
+        __syncthreads();  // Hx is zero (start of the kernel, end of the previous flush) before the first sum arrives
+        // (opaque copies: otherwise the 160 target addresses and weights below, which depend on the lane alone, are computed once in front
+        // of the loop over the units and held in registers through the whole kernel — next to 160 accumulators that is 220 spills)
+        int r = r_lane, kh = kh_lane;
+        asm volatile("" : "+v"(r), "+v"(kh));
+        // digits -> columns: entry (a, b), a <= b, of Z^T Z goes to the column pair of its rows with the weight of its digits; a pair of
+        // different digits of ONE column appears once in the upper triangle but twice in the product
+        {
+            int p = 0;
 #pragma unroll
-    for (int p = 0; p < NTP; p++)
+            for (int ta = 0; ta < NT; ta++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[p][i] = 0;
-    for (int chunk = 0; chunk < CHUNKS; chunk++) {
-        const int y0 = (blockIdx.y * CHUNKS + chunk) * TH;
-        if (y0 >= uh)
-            break;
-        const int tv = min(TH, uh - y0);
-        __syncthreads();  // previous chunk fully consumed (and the initialisation above done)
-        for (int idx = threadIdx.x; idx < (tv + 2 * HALF) * (tw + 2 * HALF); idx += 256) {
-            const int rr = idx / (tw + 2 * HALF), c = idx - rr * (tw + 2 * HALF);
-            const int v = (int)ldpx(u.dgd, (size_t)((ptrdiff_t)(u.v_start + y0 + rr - HALF) * u.dgd_stride + (u.h_start + x0 + c - HALF)), is16) - mid;
-            pl[OFF_DH + rr * P + c] = (uint8_t)(v >> 5), pl[OFF_DL + rr * P + c] = (uint8_t)(v & 31);
-        }
-        for (int idx = threadIdx.x; idx < tv * tw; idx += 256) {
-            const int rr = idx / tw, c = idx - rr * tw;
-            const int v = (int)ldpx(u.src, (size_t)((ptrdiff_t)(u.v_start + y0 + rr) * u.src_stride + (u.h_start + x0 + c)), is16) - mid;
-            pl[OFF_SH + rr * P + c] = (uint8_t)(v >> 5), pl[OFF_SL + rr * P + c] = (uint8_t)(v & 31);
-        }
-        __syncthreads();
-        for (int y = wv; y < tv; y += 4) {
-            for (int xs = 0; xs < tw; xs += 32) {
-                // samples of the unit among this lane's 16 (the bytes behind them belong to the border or to an earlier chunk)
-                const int  nv   = min(max(tw - xs - 16 * kh, 0), 16);
-                const bool edge = xs + 32 > tw;  // uniform
-                v4i        f[NT];
+                for (int tb = ta; tb < NT; tb++, p++)
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const uint32_t  a  = addr[t] + (uint32_t)y * pit[t] + (uint32_t)xs;
-                    const uint32_t *q  = (const uint32_t *)(pl + (a & ~3u));
-                    const uint32_t  sh = a & 3u;
-                    const uint32_t  d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-                    f[t][0] = (int)__builtin_amdgcn_alignbyte(d1, d0, sh), f[t][1] = (int)__builtin_amdgcn_alignbyte(d2, d1, sh);
-                    f[t][2] = (int)__builtin_amdgcn_alignbyte(d3, d2, sh), f[t][3] = (int)__builtin_amdgcn_alignbyte(d4, d3, sh);
-                    if (edge) {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int vb = min(max(nv - 4 * i, 0), 4);
-                            f[t][i] &= vb == 4 ? -1 : (int)((1u << (8 * vb)) - 1u);
+                    for (int i = 0; i < 16; i++) {
+                        const int a = 32 * ta + (i & 3) + 8 * (i >> 2) + 4 * kh, b = 32 * tb + r;
+                        if (a <= b && b < NROW && acc[p][i]) {
+                            const int ca = a < NCOL ? a : (a < ONES ? a - NCOL : NCOL), wa = a < NCOL ? 32 : 1;
+                            const int cb = b < NCOL ? b : (b < ONES ? b - NCOL : NCOL), wb = b < NCOL ? 32 : 1;
+                            const int w  = wa * wb * ((a < b && ca == cb) ? 2 : 1);
+                            atomicAdd((unsigned long long *)&Hx[min(ca, cb) * HD + max(ca, cb)], (unsigned long long)((long long)acc[p][i] * w));
                         }
                     }
+        }
+        __syncthreads();
+        // centred -> raw moments (sum (c + m)(c' + m) = sum cc' + m sum c + m sum c' + N m^2), then this workgroup's share goes to the unit
+        long long *Hu = H + (size_t)unit * W2MAX * W2MAX, *Mu = M + (size_t)unit * W2MAX;
+        StatsAux  &A  = aux[unit];
+        const long long n = Hx[NCOL * HD + NCOL], m = mid;
+        for (int e = threadIdx.x; e < W2 * W2; e += 256) {
+            const int k = e / W2, l = e - k * W2;
+            if (k <= l) {
+                const long long v = Hx[k * HD + l] + m * (Hx[k * HD + NCOL] + Hx[l * HD + NCOL]) + n * m * m;
+                if (v)
+                    atomicAdd((unsigned long long *)&Hu[e], (unsigned long long)v);
+            }
+        }
+        if (threadIdx.x < W2) {
+            const int       k  = threadIdx.x;
+            const long long sk = Hx[k * HD + NCOL], ss = Hx[W2 * HD + NCOL];
+            atomicAdd((unsigned long long *)&Mu[k], (unsigned long long)(Hx[k * HD + W2] + m * (sk + ss) + n * m * m));
+            atomicAdd((unsigned long long *)&A.S[k], (unsigned long long)(sk + n * m));
+        }
+        if (threadIdx.x == 0) {
+            atomicAdd((unsigned long long *)&A.sum_src, (unsigned long long)(Hx[W2 * HD + NCOL] + n * m));
+            atomicAdd((unsigned long long *)&A.n, (unsigned long long)n);
+        }
+        __syncthreads();  // the sums have left: start the next unit from zero
+        for (int i = threadIdx.x; i < HD * HD; i += 256) Hx[i] = 0;
+    };
+    for (int item = i0; item < i1;) {  // one round per unit of the range: its accumulators live from here to the flush
+        // (a division leaves its result in a vector register: back to a scalar one, or everything derived from the unit is held per lane)
+        const int              unit = __builtin_amdgcn_readfirstlane(item / (gx * gy)), end = min(i1, (unit + 1) * gx * gy);
+        const SvtHipWienerUnit u    = units[unit];
+        v16i                   acc[NTP];
+#pragma unroll
+        for (int p = 0; p < NTP; p++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[p][i] = 0;
+        for (; item < end; item++) {
+        const int rem = item - unit * (gx * gy), cy = __builtin_amdgcn_readfirstlane(rem / gx), x0 = (rem - cy * gx) * TW, y0 = cy * TH;
+        const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
+        if (x0 >= uw || y0 >= uh)
+            continue;
+        const int tw = min(TW, uw - x0), tv = min(TH, uh - y0);
+        __syncthreads();  // previous chunk fully consumed (and the initialisation above done)
+        // eight samples per item, every load of the chunk issued before the first digit is stored: one memory round trip per chunk
+        {
+            constexpr int NI = 3;  // (32 + 6) rows x 9 groups of the degraded tile <= 2 x 256 items, 32 x 8 of the source <= 256
+            const int     gd = (tw + 2 * HALF + 7) >> 3, nd = (tv + 2 * HALF) * gd, gs = (tw + 7) >> 3, ns = tv * gs;
+            Px8           px[NI];
+            int           dst[NI];
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const bool deg  = i < NI - 1;
+                const int  item = deg ? (int)threadIdx.x + 256 * i : (int)threadIdx.x;
+                const int  gpr = deg ? gd : gs, n = deg ? nd : ns, cols = deg ? tw + 2 * HALF : tw;
+                dst[i] = -1;
+                if (item < n) {
+                    const int rr = item / gpr, c = 8 * (item - rr * gpr);
+                    dst[i]       = (deg ? OFF_DH : OFF_SH) + rr * P + c;
+                    const size_t e = deg ? (size_t)((ptrdiff_t)(u.v_start + y0 + rr - HALF) * u.dgd_stride + (u.h_start + x0 + c - HALF))
+                                         : (size_t)((ptrdiff_t)(u.v_start + y0 + rr) * u.src_stride + (u.h_start + x0 + c));
+                    px[i] = load_px8(deg ? u.dgd : u.src, e, is16, cols - c);
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+                if (dst[i] >= 0) {
+                    uint32_t hi[2] = {0, 0}, lo[2] = {0, 0};
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int v = (int)px[i].v[k] - mid;
+                        hi[k >> 2] |= (uint32_t)((v >> 5) & 0xff) << (8 * (k & 3)), lo[k >> 2] |= (uint32_t)(v & 31) << (8 * (k & 3));
+                    }
+                    *(uint2 *)&pl[dst[i]] = make_uint2(hi[0], hi[1]);
+                    *(uint2 *)&pl[dst[i] + (i < NI - 1 ? OFF_DL - OFF_DH : OFF_SL - OFF_SH)] = make_uint2(lo[0], lo[1]);
+                }
+        }
+        __syncthreads();
+        // steps of 32 samples: this wave's rows y = wv, wv + 4, ..., two steps per row when the tile is wider than 32.
+        const int nxs = tw > 32 ? 2 : 1, nsteps = ((tv - wv + 3) >> 2) * nxs;  // tv > wv or no step
+        auto build = [&](int st, v4i(&f)[NT]) {
+            const int y = wv + 4 * (nxs == 2 ? st >> 1 : st), xs = nxs == 2 ? 32 * (st & 1) : 0;
+            // samples of the unit among this lane's 16 (the bytes behind them belong to the border or to an earlier chunk)
+            const int  nv   = min(max(tw - xs - 16 * kh, 0), 16);
+            const bool edge = xs + 32 > tw;  // uniform
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint32_t  a  = addr[t] + (uint32_t)y * pit[t] + (uint32_t)xs;
+                const uint32_t *q  = (const uint32_t *)(pl + (a & ~3u));
+                const uint32_t  sh = a & 3u;
+                const uint32_t  d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                f[t][0] = (int)__builtin_amdgcn_alignbyte(d1, d0, sh), f[t][1] = (int)__builtin_amdgcn_alignbyte(d2, d1, sh);
+                f[t][2] = (int)__builtin_amdgcn_alignbyte(d3, d2, sh), f[t][3] = (int)__builtin_amdgcn_alignbyte(d4, d3, sh);
+                if (edge) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int vb = min(max(nv - 4 * i, 0), 4);
+                        f[t][i] &= vb == 4 ? -1 : (int)((1u << (8 * vb)) - 1u);
+                    }
+                }
+            }
+        };
+        if (wv < tv) {
+            for (int st = 0; st < nsteps; st++) {
+                v4i f[NT];
+                build(st, f);
                 int p = 0;
 #pragma unroll
                 for (int ta = 0; ta < NT; ta++)
@@ -138,48 +250,8 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
                     for (int tb = ta; tb < NT; tb++, p++) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[ta], f[tb], acc[p], 0, 0, 0);
             }
         }
-    }
-    // digits -> columns: entry (a, b), a <= b, of Z^T Z goes to the column pair of its rows with the weight of its digits; a pair of
-    // different digits of ONE column appears once in the upper triangle but twice in the product
-    {
-        int p = 0;
-#pragma unroll
-        for (int ta = 0; ta < NT; ta++)
-#pragma unroll
-            for (int tb = ta; tb < NT; tb++, p++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int a = 32 * ta + (i & 3) + 8 * (i >> 2) + 4 * kh, b = 32 * tb + r;
-                    if (a <= b && b < NROW && acc[p][i]) {
-                        const int ca = a < NCOL ? a : (a < ONES ? a - NCOL : NCOL), wa = a < NCOL ? 32 : 1;
-                        const int cb = b < NCOL ? b : (b < ONES ? b - NCOL : NCOL), wb = b < NCOL ? 32 : 1;
-                        const int w  = wa * wb * ((a < b && ca == cb) ? 2 : 1);
-                        atomicAdd((unsigned long long *)&Hx[min(ca, cb) * HD + max(ca, cb)], (unsigned long long)((long long)acc[p][i] * w));
-                    }
-                }
-    }
-    __syncthreads();
-    // centred -> raw moments (sum (c + m)(c' + m) = sum cc' + m sum c + m sum c' + N m^2), then this workgroup's share goes to the unit
-    long long *Hu = H + (size_t)blockIdx.z * W2MAX * W2MAX, *Mu = M + (size_t)blockIdx.z * W2MAX;
-    StatsAux  &A  = aux[blockIdx.z];
-    const long long n = Hx[NCOL * HD + NCOL], m = mid;
-    for (int e = threadIdx.x; e < W2 * W2; e += 256) {
-        const int k = e / W2, l = e - k * W2;
-        if (k <= l) {
-            const long long v = Hx[k * HD + l] + m * (Hx[k * HD + NCOL] + Hx[l * HD + NCOL]) + n * m * m;
-            if (v)
-                atomicAdd((unsigned long long *)&Hu[e], (unsigned long long)v);
         }
-    }
-    if (threadIdx.x < W2) {
-        const int       k  = threadIdx.x;
-        const long long sk = Hx[k * HD + NCOL], ss = Hx[W2 * HD + NCOL];
-        atomicAdd((unsigned long long *)&Mu[k], (unsigned long long)(Hx[k * HD + W2] + m * (sk + ss) + n * m * m));
-        atomicAdd((unsigned long long *)&A.S[k], (unsigned long long)(sk + n * m));
-    }
-    if (threadIdx.x == 0) {
-        atomicAdd((unsigned long long *)&A.sum_src, (unsigned long long)(Hx[W2 * HD + NCOL] + n * m));
-        atomicAdd((unsigned long long *)&A.n, (unsigned long long)n);
+        flush(unit, acc);
     }
 }
 
@@ -277,12 +349,28 @@ extern "C" int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units, uint32_t 
     SVT_HIP_CHECK(hipMemsetAsync(d_M, 0, sizeof(int64_t) * W2MAX * n_units, st));
     SVT_HIP_CHECK(hipMemsetAsync(d_H, 0, sizeof(int64_t) * W2MAX * W2MAX * n_units, st));
     SVT_HIP_CHECK(hipMemsetAsync(ab.dev, 0, sizeof(StatsAux) * n_units, st));
-    // int32 accumulators: a wave sees CHUNKS * TH / 4 rows of 64 samples, products of two digits are below 2^12
-    const dim3 grid((max_w + TW - 1) / TW, (max_h + CHUNKS * TH - 1) / (CHUNKS * TH), n_units);
+    // one workgroup per slot of the GPU (two per CU at this kernel's register count), each with an equal range of (unit, chunk, tile) items.
+    // int32 accumulators: products of two digits are below 2^12 and a wave sees at most a quarter of one unit's samples between two
+    // flushes — units are at most 4096 x 4096, 2^22 samples per wave: safe up to 2^9 per product... so cap a range at 2^19 samples per wave
+    static int slots = 0;
+    if (!slots) {
+        int cus = 0;
+        SVT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+        slots = 2 * (cus > 0 ? cus : 256);
+    }
+    const int gx = (max_w + TW - 1) / TW, gy = (max_h + TH - 1) / TH;
+    const long long total = (long long)n_units * gx * gy;
+    if (total > 0x7fffffff) {
+        set_error("svt_hip_wiener_stats: too many tiles");
+        return SVT_HIP_ERR_BAD_PARAMETER;
+    }
+    // at least `slots` workgroups' worth of ranges, and no range longer than 1024 items (2^21 samples, 2^19 per wave: 2^31 / 2^12)
+    const int  nwg = (int)(total < slots ? total : (total / 1024 + 1 > slots ? total / 1024 + 1 : slots));
+    const dim3 grid((unsigned)nwg);
     if (wiener_win == 7)
-        hipLaunchKernelGGL(wiener_stats_kernel<7>, grid, dim3(256), 0, st, d_units, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
+        hipLaunchKernelGGL(wiener_stats_kernel<7>, grid, dim3(256), 0, st, d_units, (int)n_units, gx, gy, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
     else
-        hipLaunchKernelGGL(wiener_stats_kernel<5>, grid, dim3(256), 0, st, d_units, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
+        hipLaunchKernelGGL(wiener_stats_kernel<5>, grid, dim3(256), 0, st, d_units, (int)n_units, gx, gy, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
     const int divider = is_16bit ? (bit_depth == 12 ? 16 : (bit_depth == 10 ? 4 : 1)) : 1;  // restoration_pick.c:719-723
     hipLaunchKernelGGL(wiener_finalize_kernel, dim3(n_units), dim3(256), 0, st, wiener_win, divider, (long long *)d_M, (long long *)d_H,
                        (const StatsAux *)ab.dev);
