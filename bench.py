@@ -716,7 +716,16 @@ def lf_stage_rooflines(lib, dev, args, sp, stream, rank):
     out = []
     for name, fn, alg, key in stages:
         ms = timed_launches(stream, *((1, 0) if args.pmc_child else (lf_steps(args), 2)), fn)
-        out.append(roof(name, alg, ms, unit_of_work="one 4K 10-bit 4:2:0 picture", pmc_key=key))
+        r = roof(name, alg, ms, unit_of_work="one 4K 10-bit 4:2:0 picture", pmc_key=key)
+        if key == "wiener_stats":
+            # the statistics are a Gram matrix on the matrix cores (loopfilter_wiener.hip): per step of 32 samples 10 v_mfma_i32_32x32x32_i8
+            # (upper triangle of 4 x 4 tiles over the 101 digit rows padded to 128); the useful products are 50 * 51 / 2 + 50 per sample
+            ops = 2.0 * (P / 32) * 10 * 32 * 32 * 32
+            r["mfma"] = {"bound": "mfma", "achieved": round(ops / (ms * 1e-3) / 1e12, 1), "peak": 5000.0, "unit": "TOP/s (int8, dense)",
+                         "frac": round(ops / (ms * 1e-3) / 1e12 / 5000.0, 4), "issued_ops_per_launch": int(ops),
+                         "useful_mac_per_launch": int(P * (50 * 51 // 2 + 50)),
+                         "note": "issued int8 operations incl. the two-digit split (4x) and the padding 101 -> 128 rows; peak = 2x the dense bf16 figure of MI355X_MICROARCH.md"}
+        out.append(r)
     return out
 
 

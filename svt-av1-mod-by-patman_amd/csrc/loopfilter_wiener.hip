@@ -70,7 +70,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 template <int WIN>
-__global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int n_units, int gx, int gy, int is16, int bd,
+__global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWienerUnit *__restrict__ units, int wgs_per_unit, int per, int gx, int gy, int is16, int bd,
                                                            long long *__restrict__ M, long long *__restrict__ H, StatsAux *__restrict__ aux) {
     constexpr int HALF = WIN / 2, W2 = WIN * WIN;
     constexpr int NCOL = W2 + 1;                    // columns with two digits: the taps and the source sample
@@ -83,14 +83,14 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
     constexpr int HD = NCOL + 1;                    // Hx[a][b], a <= b: taps, source, ones
     __shared__ alignas(16) uint8_t pl[PL_BYTES];
     __shared__ long long Hx[HD * HD];
-    // Work items = (unit, chunk of 32 rows, 64-wide tile) over the padded grid gx x gy per unit, tile fastest; the launch has as many
-    // workgroups as the GPU holds at once and each takes a contiguous range of items, so that consecutive items share the unit (and
-    // with it the accumulators: they are combined and sent to the unit's sums only when the unit changes) and every workgroup has the
-    // same share whatever the number and the sizes of the units.
-    const int total = n_units * gx * gy, per = __builtin_amdgcn_readfirstlane((total + (int)gridDim.x - 1) / (int)gridDim.x);
-    const int i0 = (int)blockIdx.x * per, i1 = min(total, i0 + per);
+    // Work items of a unit = (chunk of 32 rows, 64-wide tile) over the padded grid gx x gy, tile fastest.  The launch has about as many
+    // workgroups as the GPU holds at once: `wgs_per_unit` per unit, each with a contiguous range of `per` items, so that a workgroup
+    // combines its accumulators and sends them to the unit's sums exactly once.
+    const int unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x / wgs_per_unit), sub = (int)blockIdx.x - unit * wgs_per_unit;
+    const int i0 = sub * per, i1 = min(gx * gy, i0 + per);
     if (i0 >= i1)
         return;
+    const SvtHipWienerUnit u = units[unit];
     for (int i = threadIdx.x; i < HD * HD; i += 256) Hx[i] = 0;
     if (threadIdx.x < 128)
         pl[OFF_ONE + threadIdx.x] = 1, pl[OFF_ZERO + threadIdx.x] = 0;
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
         addr[t] += 16 * kh;
     }
     auto flush = [&](int unit, const v16i(&acc)[NTP]) {
-        __syncthreads();  // Hx is zero (start of the kernel, end of the previous flush) before the first sum arrives
-        // (opaque copies: otherwise the 160 target addresses and weights below, which depend on the lane alone, are computed once in front
-        // of the loop over the units and held in registers through the whole kernel — next to 160 accumulators that is 220 spills)
+        __syncthreads();  // Hx is zero (start of the kernel) before the first sum arrives
+        // (opaque copies: otherwise the 160 target addresses and weights below, which depend on the lane alone, are computed in front of
+        // the item loop and held in registers through the whole kernel — next to 160 accumulators that is 220 spills)
         int r = r_lane, kh = kh_lane;
         asm volatile("" : "+v"(r), "+v"(kh));
         // digits -> columns: entry (a, b), a <= b, of Z^T Z goes to the column pair of its rows with the weight of its digits; a pair of
@@ -162,20 +162,15 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
             atomicAdd((unsigned long long *)&A.sum_src, (unsigned long long)(Hx[W2 * HD + NCOL] + n * m));
             atomicAdd((unsigned long long *)&A.n, (unsigned long long)n);
         }
-        __syncthreads();  // the sums have left: start the next unit from zero
-        for (int i = threadIdx.x; i < HD * HD; i += 256) Hx[i] = 0;
     };
-    for (int item = i0; item < i1;) {  // one round per unit of the range: its accumulators live from here to the flush
-        // (a division leaves its result in a vector register: back to a scalar one, or everything derived from the unit is held per lane)
-        const int              unit = __builtin_amdgcn_readfirstlane(item / (gx * gy)), end = min(i1, (unit + 1) * gx * gy);
-        const SvtHipWienerUnit u    = units[unit];
-        v16i                   acc[NTP];
+    v16i acc[NTP];
 #pragma unroll
-        for (int p = 0; p < NTP; p++)
+    for (int p = 0; p < NTP; p++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[p][i] = 0;
-        for (; item < end; item++) {
-        const int rem = item - unit * (gx * gy), cy = __builtin_amdgcn_readfirstlane(rem / gx), x0 = (rem - cy * gx) * TW, y0 = cy * TH;
+        for (int i = 0; i < 16; i++) acc[p][i] = 0;
+    for (int item = i0; item < i1; item++) {
+        // (a division leaves its result in a vector register: back to a scalar one, or everything derived from it is held per lane)
+        const int cy = __builtin_amdgcn_readfirstlane(item / gx), x0 = (item - cy * gx) * TW, y0 = cy * TH;
         const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
         if (x0 >= uw || y0 >= uh)
             continue;
@@ -250,9 +245,8 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
                     for (int tb = ta; tb < NT; tb++, p++) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[ta], f[tb], acc[p], 0, 0, 0);
             }
         }
-        }
-        flush(unit, acc);
     }
+    flush(unit, acc);
 }
 
 // raw moments -> the reference's M / H: fold the mean in, apply the high-bit-depth divider, mirror the lower triangle
@@ -349,28 +343,25 @@ extern "C" int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units, uint32_t 
     SVT_HIP_CHECK(hipMemsetAsync(d_M, 0, sizeof(int64_t) * W2MAX * n_units, st));
     SVT_HIP_CHECK(hipMemsetAsync(d_H, 0, sizeof(int64_t) * W2MAX * W2MAX * n_units, st));
     SVT_HIP_CHECK(hipMemsetAsync(ab.dev, 0, sizeof(StatsAux) * n_units, st));
-    // one workgroup per slot of the GPU (two per CU at this kernel's register count), each with an equal range of (unit, chunk, tile) items.
-    // int32 accumulators: products of two digits are below 2^12 and a wave sees at most a quarter of one unit's samples between two
-    // flushes — units are at most 4096 x 4096, 2^22 samples per wave: safe up to 2^9 per product... so cap a range at 2^19 samples per wave
+    // about one workgroup per slot of the GPU (two per CU at this kernel's register count): every unit gets the same number of
+    // workgroups, each with a contiguous range of the unit's (chunk, tile) items.  int32 accumulators: products of two digits are below
+    // 2^12 and a wave sees a quarter of its workgroup's samples: at most 1024 items (2^21 samples, 2^19 per wave) per workgroup.
     static int slots = 0;
     if (!slots) {
         int cus = 0;
         SVT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
         slots = 2 * (cus > 0 ? cus : 256);
     }
-    const int gx = (max_w + TW - 1) / TW, gy = (max_h + TH - 1) / TH;
-    const long long total = (long long)n_units * gx * gy;
-    if (total > 0x7fffffff) {
-        set_error("svt_hip_wiener_stats: too many tiles");
-        return SVT_HIP_ERR_BAD_PARAMETER;
-    }
-    // at least `slots` workgroups' worth of ranges, and no range longer than 1024 items (2^21 samples, 2^19 per wave: 2^31 / 2^12)
-    const int  nwg = (int)(total < slots ? total : (total / 1024 + 1 > slots ? total / 1024 + 1 : slots));
-    const dim3 grid((unsigned)nwg);
+    const int gx = (max_w + TW - 1) / TW, gy = (max_h + TH - 1) / TH, items = gx * gy;
+    int       k  = slots / (int)n_units > 1 ? slots / (int)n_units : 1;
+    k            = k > items ? items : k;
+    k            = (items + k - 1) / k > 1024 ? (items + 1023) / 1024 : k;
+    const int  per = (items + k - 1) / k;
+    const dim3 grid((unsigned)(n_units * k));
     if (wiener_win == 7)
-        hipLaunchKernelGGL(wiener_stats_kernel<7>, grid, dim3(256), 0, st, d_units, (int)n_units, gx, gy, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
+        hipLaunchKernelGGL(wiener_stats_kernel<7>, grid, dim3(256), 0, st, d_units, k, per, gx, gy, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
     else
-        hipLaunchKernelGGL(wiener_stats_kernel<5>, grid, dim3(256), 0, st, d_units, (int)n_units, gx, gy, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
+        hipLaunchKernelGGL(wiener_stats_kernel<5>, grid, dim3(256), 0, st, d_units, k, per, gx, gy, is_16bit, bit_depth, (long long *)d_M, (long long *)d_H, ab.dev);
     const int divider = is_16bit ? (bit_depth == 12 ? 16 : (bit_depth == 10 ? 4 : 1)) : 1;  // restoration_pick.c:719-723
     hipLaunchKernelGGL(wiener_finalize_kernel, dim3(n_units), dim3(256), 0, st, wiener_win, divider, (long long *)d_M, (long long *)d_H,
                        (const StatsAux *)ab.dev);
