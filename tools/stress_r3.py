@@ -104,6 +104,35 @@ def main():
         ok = all(np.array_equal(want[k], got[k]) for k in want)
         print(f"me   {i:2d} {kind:8s} {w}x{h} {key} tl{tl} refs {n0}+{n1} {tweak} {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += not ok
+    # Wiener statistics (the int8 MFMA Gram-matrix kernel): random unit sizes, offsets, bit depths, window sizes, several units per call
+    import sgr_cases as G
+    from lf_cases import V
+    from svtav1_hip import device
+    for i in range(n):
+        bd, is16 = [(8, 0), (8, 1), (10, 1), (12, 1)][int(rng.integers(0, 4))]
+        win = int(rng.choice([5, 7]))
+        W, H = int(rng.integers(20, 700)), int(rng.integers(20, 500))
+        dat, src = G.sgr_plane(rng, W, H, bd, is16, int(rng.integers(0, 3)))
+        d_dat, d_src = device.DeviceBuffer(hip, dat.nbytes), device.DeviceBuffer(hip, src.nbytes)
+        d_dat.upload(dat), d_src.upload(src)
+        off = (G.B * dat.shape[1] + G.B) * dat.itemsize
+        uw, uh = int(rng.integers(8, max(9, W))), int(rng.integers(8, max(9, H)))
+        limits = [(x, min(x + uw, W), y, min(y + uh, H)) for y in range(0, H, uh) for x in range(0, W, uw)][:40]
+        units = (abi.WienerUnit * len(limits))()
+        for j, (hs, he, vs, ve) in enumerate(limits):
+            units[j] = abi.WienerUnit(d_dat.ptr + off, d_src.ptr + off, dat.shape[1], src.shape[1], hs, he, vs, ve)
+        dM, dH = device.DeviceBuffer(hip, len(limits) * 49 * 8), device.DeviceBuffer(hip, len(limits) * 49 * 49 * 8)
+        device.check(hip, hip.svt_hip_wiener_stats(units, len(limits), win, is16, bd, V(dM.ptr), V(dH.ptr), None), "wiener_stats")
+        device.check(hip, hip.svt_hip_stream_sync(None), "sync")
+        Mg, Hg = dM.download(np.int64, (len(limits), 49)), dH.download(np.int64, (len(limits), 49 * 49))
+        w2, ok = win * win, True
+        for j, (hs, he, vs, ve) in enumerate(limits):
+            M, Hh = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+            orc.orc_wiener_compute_stats(win, V(G.at(dat)), V(G.at(src)), hs, he, vs, ve, dat.shape[1], src.shape[1], M.ctypes.data_as(C.c_void_p),
+                                         Hh.ctypes.data_as(C.c_void_p), is16, bd)
+            ok = ok and np.array_equal(M[:w2], Mg[j, :w2]) and np.array_equal(Hh[:w2 * w2], Hg[j, :w2 * w2])
+        print(f"wien {i:2d} {W}x{H} units {uw}x{uh} x{len(limits)} {bd}-bit is16 {is16} win {win} {'ok' if ok else 'MISMATCH'}", flush=True)
+        bad += not ok
     print("mismatches:", bad)
     return 1 if bad else 0
 
