@@ -345,7 +345,7 @@ extern "C" int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units, uint32_t 
     SVT_HIP_CHECK(hipMemsetAsync(ab.dev, 0, sizeof(StatsAux) * n_units, st));
     // about one workgroup per slot of the GPU (two per CU at this kernel's register count): every unit gets the same number of
     // workgroups, each with a contiguous range of the unit's (chunk, tile) items.  int32 accumulators: products of two digits are below
-    // 2^12 and a wave sees a quarter of its workgroup's samples: at most 1024 items (2^21 samples, 2^19 per wave) per workgroup.
+    // or equal to 2^12 and a wave sees a quarter of its workgroup's samples: at most 512 items (2^20 samples, 2^18 per wave) per workgroup.
     static int slots = 0;
     if (!slots) {
         int cus = 0;
@@ -355,7 +355,7 @@ extern "C" int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units, uint32_t 
     const int gx = (max_w + TW - 1) / TW, gy = (max_h + TH - 1) / TH, items = gx * gy;
     int       k  = slots / (int)n_units > 1 ? slots / (int)n_units : 1;
     k            = k > items ? items : k;
-    k            = (items + k - 1) / k > 1024 ? (items + 1023) / 1024 : k;
+    k            = (items + k - 1) / k > 512 ? (items + 511) / 512 : k;
     const int  per = (items + k - 1) / k;
     const dim3 grid((unsigned)(n_units * k));
     if (wiener_win == 7)
