@@ -94,6 +94,31 @@ def test_tier_b_units_of_a_plane(hip, orc, bd, is16, win):
     assert np.array_equal(d_out.download(dat.dtype, want.shape), want)
 
 
+@pytest.mark.parametrize("bd,is16", [(8, 0), (10, 1), (12, 1)])
+def test_stats_extreme_values(hip, orc, bd, is16):
+    """The statistics are an int8 Gram matrix of digit planes on the matrix cores: the ends of the sample range (largest digits of either
+    sign), alternating extremes and a unit much larger than a workgroup's share of it, against the oracle."""
+    rng = np.random.default_rng(17 + bd)
+    top, dt = (1 << bd) - 1, (np.uint16 if is16 else np.uint8)
+    W, H = 330, 290
+    yy, xx = np.mgrid[0:H + 2 * G.B, 0:W + 2 * G.B]
+    patterns = [np.zeros_like(xx), np.full_like(xx, top), ((xx + yy) & 1) * top, ((xx // 3 + yy // 5) & 1) * top,
+                rng.choice([0, 1, top - 1, top], size=xx.shape)]
+    for pi, pat in enumerate(patterns):
+        for win in (7, 5):
+            dat = np.ascontiguousarray(pat.astype(dt))
+            src = np.ascontiguousarray(patterns[(pi + 2) % len(patterns)].astype(dt))
+            M1, H1 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+            M2, H2 = M1.copy(), H1.copy()
+            orc.orc_wiener_compute_stats(win, V(G.at(dat)), V(G.at(src)), 0, W, 0, H, dat.shape[1], src.shape[1], P(M1), P(H1), is16, bd)
+            if is16:
+                hip.svt_av1_compute_stats_highbd_hip(win, enc(G.at(dat), 1), enc(G.at(src), 1), 0, W, 0, H, dat.shape[1], src.shape[1], P(M2), P(H2), bd)
+            else:
+                hip.svt_av1_compute_stats_hip(win, V(G.at(dat)), V(G.at(src)), 0, W, 0, H, dat.shape[1], src.shape[1], P(M2), P(H2))
+            w2 = win * win
+            assert np.array_equal(M1[:w2], M2[:w2]) and np.array_equal(H1[:w2 * w2], H2[:w2 * w2]), (pi, win)
+
+
 def test_golden(hip):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wiener.npz"))
     for key, bd, is16, win, w, h, seed in G.GOLDEN_WIENER:
