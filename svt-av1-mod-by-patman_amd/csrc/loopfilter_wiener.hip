@@ -81,19 +81,25 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
     constexpr int OFF_DH = 0, OFF_DL = OFF_DH + DROWS * P, OFF_SH = OFF_DL + DROWS * P, OFF_SL = OFF_SH + TH * P, OFF_ONE = OFF_SL + TH * P,
                   OFF_ZERO = OFF_ONE + 128, PL_BYTES = OFF_ZERO + 128;
     constexpr int HD = NCOL + 1;                    // Hx[a][b], a <= b: taps, source, ones
-    __shared__ alignas(16) uint8_t pl[PL_BYTES];
+    __shared__ alignas(16) uint8_t pl[2 * PL_BYTES];  // two tiles: the next item is loaded and converted while this one is multiplied
     __shared__ long long Hx[HD * HD];
-    // Work items of a unit = (chunk of 32 rows, 64-wide tile) over the padded grid gx x gy, tile fastest.  The launch has about as many
-    // workgroups as the GPU holds at once: `wgs_per_unit` per unit, each with a contiguous range of `per` items, so that a workgroup
-    // combines its accumulators and sends them to the unit's sums exactly once.
-    const int unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x / wgs_per_unit), sub = (int)blockIdx.x - unit * wgs_per_unit;
-    const int i0 = sub * per, i1 = min(gx * gy, i0 + per);
+    // Work items of a unit = (chunk of 32 rows, 64-wide tile) of ITS grid, tile fastest.  The launch has about as many workgroups as the
+    // GPU holds at once: `wgs_per_unit` per unit, each with a contiguous range of the unit's items, so that a workgroup combines its
+    // accumulators and sends them to the unit's sums exactly once.  (`per`: the host's bound on the items of one workgroup.)
+    const int              unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x / wgs_per_unit), sub = (int)blockIdx.x - unit * wgs_per_unit;
+    const SvtHipWienerUnit u    = units[unit];
+    const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
+    const int gxu = (uw + TW - 1) / TW, items = gxu * ((uh + TH - 1) / TH);
+    const int peru = __builtin_amdgcn_readfirstlane(min(per, (items + wgs_per_unit - 1) / wgs_per_unit));
+    const int i0 = sub * peru, i1 = min(items, i0 + peru);
     if (i0 >= i1)
         return;
-    const SvtHipWienerUnit u = units[unit];
+    (void)gx, (void)gy;
     for (int i = threadIdx.x; i < HD * HD; i += 256) Hx[i] = 0;
-    if (threadIdx.x < 128)
+    if (threadIdx.x < 128) {
         pl[OFF_ONE + threadIdx.x] = 1, pl[OFF_ZERO + threadIdx.x] = 0;
+        pl[PL_BYTES + OFF_ONE + threadIdx.x] = 1, pl[PL_BYTES + OFF_ZERO + threadIdx.x] = 0;
+    }
     const int mid = 1 << (bd - 1);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5, r_lane = r, kh_lane = kh;
     // where this lane's row of each tile lives: byte offset of (sample row 0, sample 16 * kh) and the row pitch (0: a constant row)
@@ -168,48 +174,65 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
     for (int p = 0; p < NTP; p++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[p][i] = 0;
-    for (int item = i0; item < i1; item++) {
+    // eight samples per load item, every load of a tile issued before the first digit is stored: one memory round trip per tile, and
+    // that one under the multiplications of the tile before it
+    constexpr int NI = 3;  // (32 + 6) rows x 9 groups of the degraded tile <= 2 x 256 load items, 32 x 8 of the source <= 256
+    struct Geo {
+        int x0, y0, tw, tv;
+    };
+    auto geo = [&](int item) {
         // (a division leaves its result in a vector register: back to a scalar one, or everything derived from it is held per lane)
-        const int cy = __builtin_amdgcn_readfirstlane(item / gx), x0 = (item - cy * gx) * TW, y0 = cy * TH;
-        const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
-        if (x0 >= uw || y0 >= uh)
-            continue;
-        const int tw = min(TW, uw - x0), tv = min(TH, uh - y0);
-        __syncthreads();  // previous chunk fully consumed (and the initialisation above done)
-        // eight samples per item, every load of the chunk issued before the first digit is stored: one memory round trip per chunk
-        {
-            constexpr int NI = 3;  // (32 + 6) rows x 9 groups of the degraded tile <= 2 x 256 items, 32 x 8 of the source <= 256
-            const int     gd = (tw + 2 * HALF + 7) >> 3, nd = (tv + 2 * HALF) * gd, gs = (tw + 7) >> 3, ns = tv * gs;
-            Px8           px[NI];
-            int           dst[NI];
+        const int cy = __builtin_amdgcn_readfirstlane(item / gxu);
+        Geo       g;
+        g.x0 = (item - cy * gxu) * TW, g.y0 = cy * TH, g.tw = min(TW, uw - g.x0), g.tv = min(TH, uh - g.y0);
+        return g;
+    };
+    auto issue = [&](const Geo &g, Px8(&px)[NI], int(&dst)[NI]) {
+        const int gd = (g.tw + 2 * HALF + 7) >> 3, nd = (g.tv + 2 * HALF) * gd, gs = (g.tw + 7) >> 3, ns = g.tv * gs;
 #pragma unroll
-            for (int i = 0; i < NI; i++) {
-                const bool deg  = i < NI - 1;
-                const int  item = deg ? (int)threadIdx.x + 256 * i : (int)threadIdx.x;
-                const int  gpr = deg ? gd : gs, n = deg ? nd : ns, cols = deg ? tw + 2 * HALF : tw;
-                dst[i] = -1;
-                if (item < n) {
-                    const int rr = item / gpr, c = 8 * (item - rr * gpr);
-                    dst[i]       = (deg ? OFF_DH : OFF_SH) + rr * P + c;
-                    const size_t e = deg ? (size_t)((ptrdiff_t)(u.v_start + y0 + rr - HALF) * u.dgd_stride + (u.h_start + x0 + c - HALF))
-                                         : (size_t)((ptrdiff_t)(u.v_start + y0 + rr) * u.src_stride + (u.h_start + x0 + c));
-                    px[i] = load_px8(deg ? u.dgd : u.src, e, is16, cols - c);
-                }
+        for (int i = 0; i < NI; i++) {
+            const bool deg = i < NI - 1;
+            const int  li  = deg ? (int)threadIdx.x + 256 * i : (int)threadIdx.x;
+            const int  gpr = deg ? gd : gs, n = deg ? nd : ns, cols = deg ? g.tw + 2 * HALF : g.tw;
+            dst[i] = -1;
+            if (li < n) {
+                const int rr = li / gpr, c = 8 * (li - rr * gpr);
+                dst[i]       = (deg ? OFF_DH : OFF_SH) + rr * P + c;
+                const size_t e = deg ? (size_t)((ptrdiff_t)(u.v_start + g.y0 + rr - HALF) * u.dgd_stride + (u.h_start + g.x0 + c - HALF))
+                                     : (size_t)((ptrdiff_t)(u.v_start + g.y0 + rr) * u.src_stride + (u.h_start + g.x0 + c));
+                px[i] = load_px8(deg ? u.dgd : u.src, e, is16, cols - c);
             }
-#pragma unroll
-            for (int i = 0; i < NI; i++)
-                if (dst[i] >= 0) {
-                    uint32_t hi[2] = {0, 0}, lo[2] = {0, 0};
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int v = (int)px[i].v[k] - mid;
-                        hi[k >> 2] |= (uint32_t)((v >> 5) & 0xff) << (8 * (k & 3)), lo[k >> 2] |= (uint32_t)(v & 31) << (8 * (k & 3));
-                    }
-                    *(uint2 *)&pl[dst[i]] = make_uint2(hi[0], hi[1]);
-                    *(uint2 *)&pl[dst[i] + (i < NI - 1 ? OFF_DL - OFF_DH : OFF_SL - OFF_SH)] = make_uint2(lo[0], lo[1]);
-                }
         }
-        __syncthreads();
+    };
+    auto commit = [&](const Px8(&px)[NI], const int(&dst)[NI], int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            if (dst[i] >= 0) {
+                uint32_t hi[2] = {0, 0}, lo[2] = {0, 0};
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int v = (int)px[i].v[k] - mid;
+                    hi[k >> 2] |= (uint32_t)((v >> 5) & 0xff) << (8 * (k & 3)), lo[k >> 2] |= (uint32_t)(v & 31) << (8 * (k & 3));
+                }
+                *(uint2 *)&pl[buf + dst[i]] = make_uint2(hi[0], hi[1]);
+                *(uint2 *)&pl[buf + dst[i] + (i < NI - 1 ? OFF_DL - OFF_DH : OFF_SL - OFF_SH)] = make_uint2(lo[0], lo[1]);
+            }
+    };
+    Px8 px[NI];
+    int dst[NI];
+    Geo gn = geo(i0);
+    issue(gn, px, dst);
+    commit(px, dst, 0);
+    int buf = 0;
+    for (int item = i0; item < i1; item++) {
+        const Geo g  = gn;
+        const int tw = g.tw, tv = g.tv;
+        __syncthreads();  // this tile is complete, the other one (the item before) fully consumed
+        const bool more = item + 1 < i1;
+        if (more) {
+            gn = geo(item + 1);
+            issue(gn, px, dst);
+        }
         // steps of 32 samples: this wave's rows y = wv, wv + 4, ..., two steps per row when the tile is wider than 32.
         const int nxs = tw > 32 ? 2 : 1, nsteps = ((tv - wv + 3) >> 2) * nxs;  // tv > wv or no step
         auto build = [&](int st, v4i(&f)[NT]) {
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
             const bool edge = xs + 32 > tw;  // uniform
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const uint32_t  a  = addr[t] + (uint32_t)y * pit[t] + (uint32_t)xs;
+                const uint32_t  a  = (uint32_t)buf + addr[t] + (uint32_t)y * pit[t] + (uint32_t)xs;
                 const uint32_t *q  = (const uint32_t *)(pl + (a & ~3u));
                 const uint32_t  sh = a & 3u;
                 const uint32_t  d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
@@ -245,6 +268,9 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
                     for (int tb = ta; tb < NT; tb++, p++) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[ta], f[tb], acc[p], 0, 0, 0);
             }
         }
+        buf ^= PL_BYTES;
+        if (more)
+            commit(px, dst, buf);
     }
     flush(unit, acc);
 }
