@@ -148,6 +148,9 @@ __device__ __forceinline__ void stage_rows16(uint32_t *__restrict__ w0, uint32_t
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
 // ceil(2^32 / d) == floor((2^32 - 1) / d) + 1 for every d >= 1: a 32-bit division (a 64-bit one is ~100 instructions here)
 __device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
+// products of two values below 2^24 with a result below 2^32: one full-rate v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32
+// (declared as the LLVM intrinsic: `__umul24` is expanded to shifts and a generic multiply that the selector does not always narrow again)
+extern "C" __device__ unsigned sad_mul_u24(unsigned, unsigned) __asm("llvm.amdgcn.mul.u24");
 
 // SAD of 4 adjacent positions (window dword `w` onwards) against one block.  src rows are dwords in LDS.
 __device__ __forceinline__ void quad_sad(const uint32_t *__restrict__ w, uint32_t w_row_dw,
@@ -488,10 +491,12 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
             const SearchSeg  sg = sh.seg[s0 + s];
             const SearchDesc &ds = sh.desc[sg.d];
             const uint32_t   li = item - sg.item_base;
-            const uint32_t   jl = fast_div(li, ds.inv_no), q = 2u * (li - jl * ds.no);  // q: first quad of the pair
+            const uint32_t   jl = fast_div(li, ds.inv_no), q = 2u * (li - sad_mul_u24(jl, ds.no));  // q: first quad of the pair
             const uint32_t   step = ds.skip ? 2u : 1u;
-            const uint32_t  *w    = win + sg.lds_dw + (jl * step) * ds.pitch_dw + q;
+            const uint32_t   wpitch = sad_mul_u24(ds.k, ds.pitch_dw);
+            const uint32_t  *w    = win + sg.lds_dw + sad_mul_u24(jl * step, ds.pitch_dw) + q;
             uint32_t         sad[8];
+            bool             plain = false;  // every SAD a real one (the fixed-width walks never leave a slot empty)
             // a half pair (odd quad count) still walks both quads: the second reads at most one dword past its row (staged
             // data or the next LDS object, never used: its positions fail the sa_w test below)
 #ifdef SVT_HIP_ME_ABLATE
@@ -502,17 +507,17 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
 #endif
 #ifndef SVT_HIP_NO_QSAD
             if (src_aligned && bw == 16)
-                oct_sad_fixed<16>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+                oct_sad_fixed<16>(w, wpitch, src, src_row_dw, bh, sad), plain = true;
             else if (src_aligned && bw == 32)
-                oct_sad_fixed<32>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+                oct_sad_fixed<32>(w, wpitch, src, src_row_dw, bh, sad), plain = true;
             else if (src_aligned && bw == 64)
-                oct_sad_fixed<64>(w, ds.k * ds.pitch_dw, src, src_row_dw, bh, sad);
+                oct_sad_fixed<64>(w, wpitch, src, src_row_dw, bh, sad), plain = true;
             else
 #endif
             {
-                quad_sad(w, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad);
+                quad_sad(w, wpitch, src, src_row_dw, bw, bh, sad);
                 if (q + 1 < ds.nq)
-                    quad_sad(w + 1, ds.k * ds.pitch_dw, src, src_row_dw, bw, bh, sad + 4);
+                    quad_sad(w + 1, wpitch, src, src_row_dw, bw, bh, sad + 4);
                 else
                     sad[4] = sad[5] = sad[6] = sad[7] = ~0u;
             }
@@ -524,13 +529,18 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
             // compare and two selects)
             const uint32_t nvalid = saw - 4 * q;  // >= 1
             uint32_t       kmin   = ~0u;
+            if (plain && __all(nvalid >= 8)) {  // the usual item: all eight positions inside the search area (uniform over the wave's active lanes)
 #pragma unroll
-            for (uint32_t p = 0; p < 8; p++) {
-                const uint32_t k = (p < nvalid && sad[p] != ~0u) ? ((sad[p] << 3) | p) : ~0u;
-                kmin             = k < kmin ? k : kmin;
+                for (uint32_t p = 0; p < 8; p += 2) kmin = min(min((sad[p] << 3) | p, (sad[p + 1] << 3) | (p + 1)), kmin);  // v_min3
+            } else {
+#pragma unroll
+                for (uint32_t p = 0; p < 8; p++) {
+                    const uint32_t k = (p < nvalid && sad[p] != ~0u) ? ((sad[p] << 3) | p) : ~0u;
+                    kmin             = k < kmin ? k : kmin;
+                }
             }
             if (kmin != ~0u)
-                atomicMin((unsigned long long *)&sh.best[sg.d], ((unsigned long long)(kmin >> 3) << 32) | (sy * saw + 4 * q + (kmin & 7u)));
+                atomicMin((unsigned long long *)&sh.best[sg.d], ((unsigned long long)(kmin >> 3) << 32) | (sad_mul_u24(sy, saw) + 4 * q + (kmin & 7u)));
         }
         __syncthreads();
         MS_PHASE(2);
