@@ -107,6 +107,10 @@ __device__ __forceinline__ u128v load_u128_any(const uint8_t *g) {
     return *(const __attribute__((address_space(1))) u128_unaligned *)g;
 }
 
+// products of two values below 2^24 with a result below 2^32: one full-rate v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32
+// (declared as the LLVM intrinsic: `__umul24` is expanded to shifts and a generic multiply that the selector does not always narrow again)
+extern "C" __device__ unsigned sad_mul_u24(unsigned, unsigned) __asm("llvm.amdgcn.mul.u24");
+
 // Copy `rows` rows of `pitch` dwords from global memory (row r starts at byte g0 + r * rstride, any alignment) into LDS rows
 // of `pitch` dwords at w0, with `lanes` lanes of which this one is number `lid`.  2 / 4 / 8 / 16 / 32 lanes share a row, one
 // 16-byte load each (a fourth of the load / address instructions of a dword-per-lane copy), two rows in flight per lane.
@@ -125,11 +129,11 @@ __device__ __forceinline__ void stage_rows16(uint32_t *__restrict__ w0, uint32_t
         for (uint32_t row = r0; row < rows; row += 2 * rpi) {
             const uint32_t row1 = row + rpi;
             const bool     two  = row1 < rows;
-            const u128v    a    = load_u128_any(g + (size_t)(row * rstride));
+            const u128v    a    = load_u128_any(g + (size_t)sad_mul_u24(row, rstride));  // rows and strides are far below 2^24
             u128v          b    = {0u, 0u, 0u, 0u};
             if (two)
-                b = load_u128_any(g + (size_t)(row1 * rstride));
-            uint32_t *wa = w + row * pitch, *wb = w + row1 * pitch;
+                b = load_u128_any(g + (size_t)sad_mul_u24(row1, rstride));
+            uint32_t *wa = w + sad_mul_u24(row, pitch), *wb = w + sad_mul_u24(row1, pitch);
             wa[0] = a.x;
             if (nd > 1) wa[1] = a.y;
             if (nd > 2) wa[2] = a.z;
@@ -148,9 +152,6 @@ __device__ __forceinline__ void stage_rows16(uint32_t *__restrict__ w0, uint32_t
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
 // ceil(2^32 / d) == floor((2^32 - 1) / d) + 1 for every d >= 1: a 32-bit division (a 64-bit one is ~100 instructions here)
 __device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
-// products of two values below 2^24 with a result below 2^32: one full-rate v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32
-// (declared as the LLVM intrinsic: `__umul24` is expanded to shifts and a generic multiply that the selector does not always narrow again)
-extern "C" __device__ unsigned sad_mul_u24(unsigned, unsigned) __asm("llvm.amdgcn.mul.u24");
 
 // SAD of 4 adjacent positions (window dword `w` onwards) against one block.  src rows are dwords in LDS.
 __device__ __forceinline__ void quad_sad(const uint32_t *__restrict__ w, uint32_t w_row_dw,
@@ -473,7 +474,7 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
                 if (g_ms_skip & 1)
                     continue;
 #endif
-                stage_rows16(win + sg.lds_dw, ds.pitch_dw, ds.ref + (size_t)(ds.skip ? 2 * sg.j0 + 1 : sg.j0) * rstride, rstride,
+                stage_rows16(win + sg.lds_dw, ds.pitch_dw, ds.ref + (size_t)sad_mul_u24(ds.skip ? 2 * sg.j0 + 1 : sg.j0, rstride), rstride,
                              sg.nstage, lanes, lid);
             }
         }
