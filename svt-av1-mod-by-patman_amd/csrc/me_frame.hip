@@ -72,6 +72,7 @@ struct B64State {
     // another reference (fullpel_prepare_all): centre, whether the centre is probed, the final window (size and origin)
     int16_t  fp_xc[NL * NR], fp_yc[NL * NR], fp_sw[NL * NR], fp_sh[NL * NR], fp_ox[NL * NR], fp_oy[NL * NR];
     uint8_t  fp_centre[NL * NR];
+    uint32_t fp_inv[NL * NR];        // ceil(2^32 / final window width): position index -> (row, column) without a division per lane
     uint32_t first_ref_sad64;        // p_sb_best_sad[0][0][0] (read by later references, :1359)
     uint64_t me_sad_sum[NL][NR];     // sum of the 64 best 8x8 SADs per reference (me_prune_ref, :1605-1611)
 };
@@ -189,9 +190,9 @@ __device__ void decode_result(const SH &sh, uint32_t i, bool sub, uint64_t *sad,
     const uint64_t key = sh.best[i];
     uint64_t       s   = key >> 32;
     if (key != KEY_NONE) {
-        const uint32_t idx = (uint32_t)key, w = (uint32_t)sh.desc[i].sa_w;
-        *x = (int16_t)(idx % w);
-        *y = (int16_t)(idx / w);
+        const uint32_t idx = (uint32_t)key;  // row << 16 | column
+        *x = (int16_t)(idx & 0xffffu);
+        *y = (int16_t)(idx >> 16);
     }
     if (sub)
         s *= 2;
@@ -268,8 +269,8 @@ __device__ void fp_search(LDS &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint
             break;  // nothing left for this wave (the centre probe is ONE item group: three of the four waves skip it)
         const uint32_t item = base + tid;
         const bool     on   = item < nitems;  // uniform over each group of 16 lanes
-        const uint32_t qi = on ? item >> 4 : 0, y = fast_div(qi, inv_nq), q = qi - y * nq;
-        const uint32_t *w = &L.win[(y0 + y + 16 * zy) * pitch + (x0 >> 2) + q + 4 * zx];
+        const uint32_t qi = on ? item >> 4 : 0, y = fast_div(qi, inv_nq), q = qi - sad_mul_u24(y, nq);  // (24-bit products: full rate)
+        const uint32_t *w = &L.win[sad_mul_u24(y0 + y + 16 * zy, pitch) + (x0 >> 2) + q + 4 * zx];
         uint64_t        a00 = 0, a01 = 0, a10 = 0, a11 = 0;
 #pragma unroll
         for (uint32_t r = 0; r < 16; r++) {
@@ -313,7 +314,7 @@ __device__ void fp_search(LDS &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint
         }
         if (on && k16 != ~0u) {
             const uint32_t sh1 = sub ? 1 : 0;  // sub-sampled rows: SAD x 2 (motion_estimation.c:520-530)
-            const uint32_t ord_row = order0 + y * order_pitch + 4 * q;
+            const uint32_t ord_row = order0 + sad_mul_u24(y, order_pitch) + 4 * q;
 #define FP_KEY(k) (((unsigned long long)(((k) >> 2) << sh1) << 32) | (ord_row + ((k) & 3u)))
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++) atomicMin((unsigned long long *)&L.bestkey[21 + 4 * zo + c], FP_KEY(k8[c]));
@@ -1097,6 +1098,7 @@ __device__ void fullpel_prepare_all(LDS &L, const Ctx &c) {
         }
         clamp_me_window(S.fp_xc[g], S.fp_yc[g], ox_b, oy_b, W, H, pad, &sw, &sh_, &ox, &oy);
         S.fp_sw[g] = sw, S.fp_sh[g] = sh_, S.fp_ox[g] = ox, S.fp_oy[g] = oy;
+        S.fp_inv[g] = make_inv((uint32_t)(sw > 0 ? sw : 0));
     }
     __syncthreads();
 }
@@ -1306,8 +1308,8 @@ __device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store, bo
                 if (ord == 0) {
                     mx = S.xc, my = S.yc;
                 } else {
-                    const uint32_t pos = ord - 1;
-                    mx = (int16_t)((int)(pos % sw) + ox), my = (int16_t)((int)(pos / sw) + oy);
+                    const uint32_t pos = ord - 1, row = prepared ? fast_div(pos, S.fp_inv[li * NR + ri]) : pos / sw;
+                    mx = (int16_t)((int)(pos - row * sw) + ox), my = (int16_t)((int)row + oy);
                 }
                 gm[(li * NR + ri) * 85 + pu] = ((uint32_t)(uint16_t)my << 16) | (uint16_t)mx;
             }

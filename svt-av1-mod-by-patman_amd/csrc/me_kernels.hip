@@ -50,8 +50,8 @@ __global__ __launch_bounds__(WG_THREADS) void sad_loop_batch_kernel(const uint8_
                 r.x = r.y = (int16_t)0x7fff;  // "not found": Tier A leaves the caller's x/y untouched
             } else {
                 const uint32_t idx = (uint32_t)key;
-                r.x                = (int16_t)(idx % (uint32_t)d.search_area_width);
-                r.y                = (int16_t)(idx / (uint32_t)d.search_area_width);
+                r.x                = (int16_t)(idx & 0xffffu);  // row << 16 | column
+                r.y                = (int16_t)(idx >> 16);
             }
             results[di] = r;
         }

@@ -38,7 +38,7 @@ struct SearchDesc {
     uint32_t n_srows;   // searched rows
     uint32_t pitch_dw;  // LDS row pitch of the staged window (dwords)
     uint32_t rows_per_pos;  // raw rows spanned by one search position: (bh-1)*k + 1
-    uint32_t inv_pitch, inv_no;  // ceil(2^32 / x): exact quotients for the small dividends used here
+    uint32_t inv_no;    // ceil(2^32 / no): exact quotients for the small dividends used here
     // --- caller's per-descriptor state that has to survive the search (kept here rather than in registers: live values
     // across the inlined search are what the register allocator spills) ---
     int16_t  aux_x, aux_y;
@@ -152,6 +152,16 @@ __device__ __forceinline__ void stage_rows16(uint32_t *__restrict__ w0, uint32_t
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
 // ceil(2^32 / d) == floor((2^32 - 1) / d) + 1 for every d >= 1: a 32-bit division (a 64-bit one is ~100 instructions here)
 __device__ __forceinline__ uint32_t make_inv(uint32_t d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
+// the same from a table for the divisors the search plans use most (items per search row): a 32-bit division is ~40 instructions,
+// a third of them quarter-rate, in a section that one wave runs alone
+__device__ const uint32_t INV_SMALL[65] = {
+    0u, 0u, 0x80000000u, 0x55555556u, 0x40000000u, 0x33333334u, 0x2aaaaaabu, 0x24924925u, 0x20000000u, 0x1c71c71du, 0x1999999au, 0x1745d175u, 0x15555556u,
+    0x13b13b14u, 0x12492493u, 0x11111112u, 0x10000000u, 0x0f0f0f10u, 0x0e38e38fu, 0x0d79435fu, 0x0ccccccdu, 0x0c30c30du, 0x0ba2e8bbu, 0x0b21642du, 0x0aaaaaabu,
+    0x0a3d70a4u, 0x09d89d8au, 0x097b425fu, 0x0924924au, 0x08d3dcb1u, 0x08888889u, 0x08421085u, 0x08000000u, 0x07c1f07du, 0x07878788u, 0x07507508u, 0x071c71c8u,
+    0x06eb3e46u, 0x06bca1b0u, 0x06906907u, 0x06666667u, 0x063e7064u, 0x06186187u, 0x05f417d1u, 0x05d1745eu, 0x05b05b06u, 0x0590b217u, 0x0572620bu, 0x05555556u,
+    0x0539782au, 0x051eb852u, 0x05050506u, 0x04ec4ec5u, 0x04d4873fu, 0x04bda130u, 0x04a7904bu, 0x04924925u, 0x047dc120u, 0x0469ee59u, 0x0456c798u, 0x04444445u,
+    0x04325c54u, 0x04210843u, 0x04104105u, 0x04000000u};
+__device__ __forceinline__ uint32_t make_inv_small(uint32_t d) { return d <= 64 ? INV_SMALL[d] : make_inv(d); }
 
 // SAD of 4 adjacent positions (window dword `w` onwards) against one block.  src rows are dwords in LDS.
 __device__ __forceinline__ void quad_sad(const uint32_t *__restrict__ w, uint32_t w_row_dw,
@@ -287,8 +297,7 @@ __device__ __forceinline__ void search_plan_desc(SearchDesc &d, uint32_t bw, uin
             d.rows_per_pos = (bh - 1) * d.k + 1;
             d.pitch_dw     = (d.nq + ((bw + 3) >> 2) + 1) | 1u;  // odd pitch: rows land on different banks
             d.fast         = (uint64_t)d.pitch_dw * d.rows_per_pos <= win_cap_dw && win_cap_dw <= 65536u;
-            d.inv_pitch    = make_inv(d.pitch_dw);
-            d.inv_no       = make_inv(d.no);
+            d.inv_no       = make_inv_small(d.no);
         }
     }
 }
@@ -308,7 +317,8 @@ template <bool ITEMS, class SH> __device__ __forceinline__ uint32_t find_seg(con
 }
 
 // Exhaustive search of n descriptors (same bw x bh block, `src` = block rows as dwords in LDS).
-// On return sh.best[i] holds the winning key of descriptor i (KEY_NONE if nothing was searched).
+// On return sh.best[i] holds the winning key of descriptor i (KEY_NONE if nothing was searched): SAD << 32 | search row << 16 | column
+// (search areas are int16 in every caller; (row, column) orders like the raster index and decodes without a division).
 // Must be called by all WG_THREADS threads of the workgroup; contains barriers.  Descriptor i must have been
 // written by thread i (or be visible through an earlier barrier).
 template <class SH>
@@ -417,7 +427,7 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
                     nstage              = (nj - 1) * step + ds.rows_per_pos;
                     if (tid == d0 && nstage * ds.pitch_dw > win_cap_dw) {
                         // rows staged for nj searched rows: (nj-1)*step + rows_per_pos ('fast' guarantees nj >= 1)
-                        nj     = (fast_div(win_cap_dw, ds.inv_pitch) - ds.rows_per_pos) / step + 1;
+                        nj     = (win_cap_dw / ds.pitch_dw - ds.rows_per_pos) / step + 1;  // (rare: a window that does not fit alone)
                         nstage = (nj - 1) * step + ds.rows_per_pos;
                         part   = true;
                     }
@@ -541,7 +551,7 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
                 }
             }
             if (kmin != ~0u)
-                atomicMin((unsigned long long *)&sh.best[sg.d], ((unsigned long long)(kmin >> 3) << 32) | (sad_mul_u24(sy, saw) + 4 * q + (kmin & 7u)));
+                atomicMin((unsigned long long *)&sh.best[sg.d], ((unsigned long long)(kmin >> 3) << 32) | ((sy << 16) | (4 * q + (kmin & 7u))));
         }
         __syncthreads();
         MS_PHASE(2);
@@ -567,7 +577,7 @@ __device__ __forceinline__ void wg_multi_search(SH &sh, uint32_t n, const uint32
                     const int dv = (int)sb[r * src_row_dw * 4 + c] - (int)g[(size_t)r * ds.ref_stride + c];
                     sad += (uint32_t)(dv < 0 ? -dv : dv);
                 }
-            const uint64_t kk = ((uint64_t)sad << 32) | (sy * (uint32_t)ds.sa_w + sx);
+            const uint64_t kk = ((uint64_t)sad << 32) | ((sy << 16) | sx);
             key               = kk < key ? kk : key;
         }
         if (key < KEY_NONE)
