@@ -100,6 +100,13 @@ typedef __attribute__((address_space(1))) uint32_t g_u32;  // the result arrays 
 #define MAXV(a, b) ((a) > (b) ? (a) : (b))
 #define ABSV(a) ((a) < 0 ? -(a) : (a))
 
+// x / d for the divisors of the set-up code, which are powers of two in every preset (numbers of search regions, search-range divisors,
+// 64 x 64 samples): a shift when d is one, the division otherwise (both branches only run when a lane of the wave needs the division —
+// it is ~40 instructions, a third of them quarter-rate, in sections that one wave runs alone)
+__device__ __forceinline__ uint32_t div_small(uint32_t x, uint32_t d) {
+    return (d & (d - 1u)) == 0u && d ? x >> (31u - (uint32_t)__builtin_clz(d)) : x / d;
+}
+
 __device__ __forceinline__ uint16_t scaled_dist(uint16_t dist) {
     return (uint16_t)(((dist * 5) / 8) + ((dist % 8) == 0 ? 0 : 1));
 }
@@ -121,7 +128,7 @@ __device__ __forceinline__ uint32_t block_sad16(const uint32_t *src, const uint8
     for (uint32_t idx = lane; idx < nch * rows; idx += nlanes) {
         const uint32_t r = fast_div(idx, inv), ch = idx - r * nch;
         const uint4    sv = *(const uint4 *)&src[(r * row_step) * 16 + 4 * ch];
-        const u128v    v  = load_u128_any(ref + (size_t)((r * row_step) * ref_stride) + 16 * ch);
+        const u128v    v  = load_u128_any(ref + (size_t)sad_mul_u24(r * row_step, ref_stride) + 16 * ch);
         const uint32_t nd = ndw - 4 * ch;
         acc = __builtin_amdgcn_sad_u8(sv.x, v.x, acc);
         acc = __builtin_amdgcn_sad_u8(sv.y, v.y, acc);      // ndw is even: dword 1 of a chunk is always inside the block
@@ -638,7 +645,7 @@ __device__ void zz_sad_all(LDS &L, const Ctx &c) {
         acc = wave_sum(acc);
         if (lane == 0) {
             uint32_t z = acc << 1;
-            z          = (z * 64 * 64) / (b64_w * b64_h);
+            z          = div_small(z * 64 * 64, b64_w * b64_h);
             S.zz_sad[li][ri] = z;
         }
     }
@@ -808,10 +815,10 @@ __device__ void hme_l0_round(LDS &L, const Ctx &c, int f0, int f1, int part, Sea
                 mx.height = (uint16_t)(mx.height / (yo + ri));
             }
             const int32_t factor = scaled_dist(pic_dist(p, li, ri));
-            int16_t       w      = (int16_t)(mn.width / p.num_hme_sa_w);
-            w = (int16_t)MINV((((w * factor) + 15) & ~0x0F), (((mx.width / p.num_hme_sa_w) + 15) & ~0x0F));
-            int16_t h = (int16_t)(mn.height / p.num_hme_sa_h);
-            h         = (int16_t)MINV((h * factor), (mx.height / p.num_hme_sa_h));
+            int16_t       w      = (int16_t)div_small(mn.width, p.num_hme_sa_w);
+            w = (int16_t)MINV((((w * factor) + 15) & ~0x0F), (int32_t)((div_small(mx.width, p.num_hme_sa_w) + 15) & ~0x0Fu));
+            int16_t h = (int16_t)div_small(mn.height, p.num_hme_sa_h);
+            h         = (int16_t)MINV((h * factor), (int32_t)div_small(mx.height, p.num_hme_sa_h));
             const int16_t ox16 = (int16_t)(((int16_t)org_x) >> 2), oy16 = (int16_t)(((int16_t)org_y) >> 2);
             // hme_level_0 (:820-920)
             int16_t       sa_w = (int16_t)((w + 7) & ~0x07), sa_h = h;
@@ -1031,8 +1038,8 @@ __device__ void fullpel_prepare_all(LDS &L, const Ctx &c) {
             if (ABSV(xc) > p.mv_sa_adj_mv_size_th) sw = (int16_t)(sw * p.mv_sa_adj_sa_multiplier);
             if (ABSV(yc) > p.mv_sa_adj_mv_size_th) sh_ = (int16_t)(sh_ * p.mv_sa_adj_sa_multiplier);
         }
-        sw  = (int16_t)((MAXV(1u, ((uint32_t)sw / S.reduce_div[li][ri])) + 7) & ~0x07u);
-        sh_ = (int16_t)MAXV(3u, ((uint32_t)sh_ / S.reduce_div[li][ri]));
+        sw  = (int16_t)((MAXV(1u, div_small((uint32_t)sw, S.reduce_div[li][ri])) + 7) & ~0x07u);
+        sh_ = (int16_t)MAXV(3u, div_small((uint32_t)sh_, S.reduce_div[li][ri]));
         if (S.zz_sad[li][ri] < (p.me_early_exit_th / 6))
             sw = sh_ = 1;
         const int g = li * NR + ri;
@@ -1155,8 +1162,8 @@ __device__ void fullpel_ref(LDS &L, const Ctx &c, int li, int ri, bool store, bo
             if (ABSV(xc) > p.mv_sa_adj_mv_size_th) sw = (int16_t)(sw * p.mv_sa_adj_sa_multiplier);
             if (ABSV(yc) > p.mv_sa_adj_mv_size_th) sh_ = (int16_t)(sh_ * p.mv_sa_adj_sa_multiplier);
         }
-        sw  = (int16_t)((MAXV(1u, ((uint32_t)sw / S.reduce_div[li][ri])) + 7) & ~0x07u);
-        sh_ = (int16_t)MAXV(3u, ((uint32_t)sh_ / S.reduce_div[li][ri]));
+        sw  = (int16_t)((MAXV(1u, div_small((uint32_t)sw, S.reduce_div[li][ri])) + 7) & ~0x07u);
+        sh_ = (int16_t)MAXV(3u, div_small((uint32_t)sh_, S.reduce_div[li][ri]));
         S.xc = xc, S.yc = yc, S.sw = sw, S.sh = sh_;
         S.need_zero_sad = 0, S.need_hme_sad = 0;
         if (p.me_early_exit_th) {
@@ -1386,10 +1393,10 @@ __device__ void finalize_b64(LDS &L, const Ctx &c) {
             const uint32_t pix = b64_w * b64_h;
             out.me_8x8_cost_variance[b64] = (uint32_t)(ssq / 64);
             out.rc_me_distortion[b64]     = p.input_resolution_le_480p ? d8 : d16;
-            out.me_64x64_distortion[b64]  = (d64 * 4096u) / pix;
-            out.me_32x32_distortion[b64]  = (d32 * 4096u) / pix;
-            out.me_16x16_distortion[b64]  = (d16 * 4096u) / pix;
-            out.me_8x8_distortion[b64]    = (d8 * 4096u) / pix;
+            out.me_64x64_distortion[b64]  = div_small(d64 * 4096u, pix);
+            out.me_32x32_distortion[b64]  = div_small(d32 * 4096u, pix);
+            out.me_16x16_distortion[b64]  = div_small(d16 * 4096u, pix);
+            out.me_8x8_distortion[b64]    = div_small(d8 * 4096u, pix);
         }
     }
     if (tid < NL * NR)
