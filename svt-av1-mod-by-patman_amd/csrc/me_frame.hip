@@ -123,7 +123,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *g) { retur
 // in global memory at any byte address: 16 bytes per load, `ndw` = block width in dwords (b64_w / 4, a multiple of 2).
 __device__ __forceinline__ uint32_t block_sad16(const uint32_t *src, const uint8_t *ref, uint32_t ref_stride, uint32_t ndw, uint32_t rows,
                                                 uint32_t row_step, uint32_t lane, uint32_t nlanes) {
-    const uint32_t nch = (ndw + 3) >> 2, inv = make_inv(nch);
+    const uint32_t nch = (ndw + 3) >> 2, inv = make_inv_small(nch);
     uint32_t       acc = 0;
     for (uint32_t idx = lane; idx < nch * rows; idx += nlanes) {
         const uint32_t r = fast_div(idx, inv), ch = idx - r * nch;
@@ -265,7 +265,7 @@ template <class LDS>
 __device__ void fp_search(LDS &L, uint32_t pitch, uint32_t x0, uint32_t y0, uint32_t cw, uint32_t ch, uint32_t order0,
                           uint32_t order_pitch, bool sub) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t nq = (cw + 3) >> 2, nitems = nq * ch * 16, inv_nq = make_inv(nq);
+    const uint32_t nq = (cw + 3) >> 2, nitems = nq * ch * 16, inv_nq = make_inv_small(nq);
     // lane (tid & 15) = z-order index of this lane's 16x16 block (Appendix A.1): the four 16x16 of a 32x32 are the four
     // lanes of a DPP quad, the four 32x32 are the four quads of a DPP row
     const uint32_t zo = tid & 15;
@@ -1105,7 +1105,7 @@ __device__ void fullpel_prepare_all(LDS &L, const Ctx &c) {
         }
         clamp_me_window(S.fp_xc[g], S.fp_yc[g], ox_b, oy_b, W, H, pad, &sw, &sh_, &ox, &oy);
         S.fp_sw[g] = sw, S.fp_sh[g] = sh_, S.fp_ox[g] = ox, S.fp_oy[g] = oy;
-        S.fp_inv[g] = make_inv((uint32_t)(sw > 0 ? sw : 0));
+        S.fp_inv[g] = make_inv_small((uint32_t)(sw > 0 ? sw : 0));
     }
     __syncthreads();
 }
