@@ -374,8 +374,9 @@ extern "C" int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units, uint32_t 
     // or equal to 2^12 and a wave sees a quarter of its workgroup's samples: at most 512 items (2^20 samples, 2^18 per wave) per workgroup.
     static int slots = 0;
     if (!slots) {
-        int cus = 0;
-        SVT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+        int cus = 0, dev = 0;
+        SVT_HIP_CHECK(hipGetDevice(&dev));
+        SVT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         slots = 2 * (cus > 0 ? cus : 256);
     }
     const int gx = (max_w + TW - 1) / TW, gy = (max_h + TH - 1) / TH, items = gx * gy;
