@@ -284,6 +284,9 @@ class TxfmWorkload:
                 cells = torch.rand((ph[p] + 63) // 64, (pw[p] + 63) // 64, device=dev, generator=g)
                 amp = torch.where(cells < 0.70, 60, torch.where(cells < 0.95, 250, 1023)).to(torch.int32)
                 flat = cells > 0.99
+                txamp = os.environ.get("SVTAV1_BENCH_TXAMP", "mixed")  # kernel-analysis aid: one residual amplitude everywhere (60 | 250 | 1023)
+                if txamp != "mixed":
+                    amp, flat = torch.full_like(amp, int(txamp)), torch.zeros_like(flat)
                 amp = amp.repeat_interleave(64, 0).repeat_interleave(64, 1)[:ph[p], :pw[p]]
                 flat = flat.repeat_interleave(64, 0).repeat_interleave(64, 1)[:ph[p], :pw[p]]
                 r = (torch.randint(-1023, 1024, (ph[p], pw[p]), device=dev, generator=g, dtype=torch.int32) * amp) >> 10
