@@ -275,6 +275,17 @@ __global__ __launch_bounds__(256, 2) void wiener_stats_kernel(const SvtHipWiener
     flush(unit, acc);
 }
 
+__global__ __launch_bounds__(256) void wiener_zero_kernel(long long *__restrict__ M, long long *__restrict__ H, long long *__restrict__ A, size_t nM,
+                                                          size_t nH, size_t nA) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // the grid covers nH, the largest of the three
+    if (i < nH)
+        H[i] = 0;
+    if (i < nM)
+        M[i] = 0;
+    if (i < nA)
+        A[i] = 0;
+}
+
 // raw moments -> the reference's M / H: fold the mean in, apply the high-bit-depth divider, mirror the lower triangle
 __global__ __launch_bounds__(256) void wiener_finalize_kernel(int win, int divider, long long *__restrict__ M, long long *__restrict__ H,
                                                               const StatsAux *__restrict__ aux) {
@@ -366,9 +377,11 @@ extern "C" int32_t svt_hip_wiener_stats(const SvtHipWienerUnit *units, uint32_t 
     const SvtHipWienerUnit *d_units = (const SvtHipWienerUnit *)stage_descriptors(units, sizeof(SvtHipWienerUnit) * n_units, st);
     if (!d_units)
         return SVT_HIP_ERR_RUNTIME;
-    SVT_HIP_CHECK(hipMemsetAsync(d_M, 0, sizeof(int64_t) * W2MAX * n_units, st));
-    SVT_HIP_CHECK(hipMemsetAsync(d_H, 0, sizeof(int64_t) * W2MAX * W2MAX * n_units, st));
-    SVT_HIP_CHECK(hipMemsetAsync(ab.dev, 0, sizeof(StatsAux) * n_units, st));
+    // the three sum arrays start from zero: one launch instead of three memsets (a launch costs more than it moves here)
+    {
+        const size_t nM = (size_t)W2MAX * n_units, nH = (size_t)W2MAX * W2MAX * n_units, nA = sizeof(StatsAux) / sizeof(long long) * n_units;
+        hipLaunchKernelGGL(wiener_zero_kernel, dim3((unsigned)((nH + 255) / 256)), dim3(256), 0, st, (long long *)d_M, (long long *)d_H, (long long *)ab.dev, nM, nH, nA);
+    }
     // about one workgroup per slot of the GPU (two per CU at this kernel's register count): every unit gets the same number of
     // workgroups, each with a contiguous range of the unit's (chunk, tile) items.  int32 accumulators: products of two digits are below
     // or equal to 2^12 and a wave sees a quarter of its workgroup's samples: at most 512 items (2^20 samples, 2^18 per wave) per workgroup.
